@@ -1,0 +1,1143 @@
+// hip_backend.hip — the MI355X (gfx950) backend of libggml_hip.so.
+//
+// Fills the plugin slot that crates/ggml/sys/src/cuda.rs:6-77 defines (19 accelerator hooks) and
+// executes whole compute graphs for ggml_graph_compute (crates/ggml/src/lib.rs:374-376).  Design,
+// MI355X-first rather than a translation of ggml-cuda:
+//   * Device residency by address mirroring.  Every host arena (ggml context buffer, scratch buffer)
+//     gets a lazily created device shadow of the same size; a tensor's device address is
+//     shadow + (tensor->data - arena_base).  288 GB of HBM makes the 2-3 GiB of shadows a non-issue and
+//     removes per-node buffer assignment, scratch pools and view bookkeeping from the hot path.
+//   * Weights / KV cache get private persistent buffers (ggml_hip_transform_tensor /
+//     ggml_hip_assign_buffers_no_scratch); quantized 2-D weights are re-laid-out once into the SoA
+//     layout of kernels/common.h so the mat-vec streams them with aligned 16-byte loads.
+//   * One in-order HIP stream; the graph's node order is the dependency order (as in ggml).
+//   * No CPU compute: an unsupported op aborts with a message.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ggml_hip.h"
+#include "internal.h"
+#include "kernels/common.h"
+#include "kernels/mmvq.h"
+#include "kernels/ops.h"
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t err__ = (expr);                                                                   \
+        if (err__ != hipSuccess) {                                                                   \
+            fprintf(stderr, "libggml_hip: HIP error %d (%s) at %s:%d: %s\n", (int)err__,             \
+                    hipGetErrorString(err__), __FILE__, __LINE__, #expr);                            \
+            abort();                                                                                 \
+        }                                                                                            \
+    } while (0)
+
+#define BK_ASSERT(x)                                                                                 \
+    do {                                                                                             \
+        if (!(x)) {                                                                                  \
+            fprintf(stderr, "libggml_hip: assertion failed at %s:%d: %s\n", __FILE__, __LINE__, #x); \
+            abort();                                                                                 \
+        }                                                                                            \
+    } while (0)
+
+namespace {
+
+[[noreturn]] void die(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "libggml_hip: ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    abort();
+}
+
+struct Arena {
+    uintptr_t base = 0;
+    size_t size = 0;
+    char *dev = nullptr;  // lazily allocated shadow
+    bool live = true;
+};
+
+// Record behind ggml_tensor.extra (and behind auto-uploaded persistent leaves).
+struct DevTensor {
+    uint32_t magic = 0x48495054;  // 'HIPT'
+    uintptr_t host = 0;           // host data range this record mirrors
+    size_t nbytes = 0;
+    char *dev = nullptr;          // base of the device allocation
+    size_t dev_bytes = 0;
+    bool soa = false;             // quantized SoA layout (see QWeight)
+    bool auto_uploaded = false;
+    QWeight qw{};
+    ggml_type type = GGML_TYPE_F32;
+    int64_t ne[4] = {0, 0, 0, 0};
+};
+
+struct Timing {
+    bool on = false;
+    struct Rec {
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs[GGML_HIP_KCLASS_COUNT];
+    std::vector<Rec> pool;
+    double bytes[GGML_HIP_KCLASS_COUNT] = {0, 0, 0, 0};
+    int64_t launches[GGML_HIP_KCLASS_COUNT] = {0, 0, 0, 0};
+};
+
+struct Backend {
+    std::recursive_mutex mu;
+    bool inited = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<uintptr_t, Arena> arenas;          // by base
+    std::map<uintptr_t, DevTensor *> tensors;   // by host data base
+    // per-graph workspace (activation re-quantization, temp SoA): bump allocator over chunks; chunks
+    // added mid-graph stay alive until the next graph starts, where they are merged into one.
+    struct WsChunk {
+        char *p;
+        size_t size;
+    };
+    std::vector<WsChunk> ws_chunks;
+    size_t ws_off = 0;  // offset in the last chunk
+    Timing timing;
+    // options
+    int opt_fuse = 1;
+    int opt_mmvq_rows = 0;  // 0 = auto
+    size_t dead_shadow_bytes = 0;
+} g;
+
+int qt_of(ggml_type t) {
+    switch (t) {
+        case GGML_TYPE_Q4_0: return QT_Q4_0;
+        case GGML_TYPE_Q4_1: return QT_Q4_1;
+        case GGML_TYPE_Q5_0: return QT_Q5_0;
+        case GGML_TYPE_Q5_1: return QT_Q5_1;
+        case GGML_TYPE_Q8_0: return QT_Q8_0;
+        default: return -1;
+    }
+}
+
+void ensure_init() {
+    if (g.inited) return;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        die("no HIP device available (hipGetDeviceCount -> %d, n=%d). This library has no CPU compute path.", (int)e, n);
+    // one process per GPU: honour LOCAL_RANK when the launcher did not restrict visibility
+    if (const char *lr = getenv("GGML_HIP_DEVICE")) g.device = atoi(lr);
+    if (g.device >= n) g.device = g.device % n;
+    HIP_CHECK(hipSetDevice(g.device));
+    HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    if (const char *v = getenv("GGML_HIP_FUSE")) g.opt_fuse = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMVQ_R")) g.opt_mmvq_rows = atoi(v);
+    g.inited = true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// address translation
+// ---------------------------------------------------------------------------------------------------
+Arena *find_arena(uintptr_t p) {
+    auto it = g.arenas.upper_bound(p);
+    if (it == g.arenas.begin()) return nullptr;
+    --it;
+    Arena &a = it->second;
+    if (p >= a.base && p < a.base + a.size && a.live) return &a;
+    return nullptr;
+}
+DevTensor *find_tensor(uintptr_t p) {
+    auto it = g.tensors.upper_bound(p);
+    if (it == g.tensors.begin()) return nullptr;
+    --it;
+    DevTensor *t = it->second;
+    if (p >= t->host && p < t->host + std::max<size_t>(t->nbytes, 1)) return t;
+    return nullptr;
+}
+DevTensor *extra_of(const ggml_tensor *t) {
+    DevTensor *e = (DevTensor *)t->extra;
+    if (e && e->magic != 0x48495054) die("tensor '%s': extra does not belong to this backend", t->name);
+    return e;
+}
+char *arena_dev(Arena *a) {
+    if (!a->dev) {
+        ensure_init();
+        HIP_CHECK(hipMalloc((void **)&a->dev, a->size));
+    }
+    return a->dev;
+}
+
+// device address of the raw bytes of `t` (strided views included). Aborts for SoA weights.
+char *dev_ptr(const ggml_tensor *t) {
+    if (DevTensor *e = extra_of(t)) {
+        if (e->soa) die("tensor '%s' is a re-laid-out quantized weight; only mul_mat/get_rows may read it", t->name);
+        return e->dev + ((uintptr_t)t->data - e->host);
+    }
+    const uintptr_t p = (uintptr_t)t->data;
+    if (p == 0) die("tensor '%s' has no data", t->name);
+    if (DevTensor *e = find_tensor(p)) {
+        if (e->soa) die("tensor '%s' aliases a re-laid-out quantized weight", t->name);
+        return e->dev + (p - e->host);
+    }
+    if (Arena *a = find_arena(p)) return arena_dev(a) + (p - a->base);
+    die("tensor '%s' (op %s): data pointer %p is in no registered arena and has no device copy", t->name,
+        ggml_op_name(t->op), t->data);
+}
+
+TView view_of(const ggml_tensor *t) {
+    TView v;
+    v.p = dev_ptr(t);
+    for (int i = 0; i < 4; i++) {
+        v.ne[i] = t->ne[i];
+        v.nb[i] = (int64_t)t->nb[i];
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------
+struct QActBuf {
+    const void *src_data = nullptr;  // host address identity of the source tensor data
+    size_t src_bytes = 0;
+    bool f16_d = false;
+    int64_t nb = 0, ncols = 0;
+    QAct act{};
+    bool valid = false;
+} g_qact;
+
+char *ws_alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (g.ws_chunks.empty() || g.ws_off + bytes > g.ws_chunks.back().size) {
+        size_t total = 0;
+        for (auto &c : g.ws_chunks) total += c.size;
+        const size_t want = std::max<size_t>(std::max<size_t>(bytes, total), (size_t)256 << 20);
+        Backend::WsChunk c{nullptr, want};
+        HIP_CHECK(hipMalloc((void **)&c.p, want));
+        g.ws_chunks.push_back(c);
+        g.ws_off = 0;
+    }
+    char *p = g.ws_chunks.back().p + g.ws_off;
+    g.ws_off += bytes;
+    return p;
+}
+// called at the start of every graph: rewind, and merge chunks that were added during the last graph
+void ws_reset() {
+    g.ws_off = 0;
+    if (g.ws_chunks.size() <= 1) return;
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    size_t total = 0;
+    for (auto &c : g.ws_chunks) {
+        total += c.size;
+        HIP_CHECK(hipFree(c.p));
+    }
+    g.ws_chunks.clear();
+    Backend::WsChunk c{nullptr, total};
+    HIP_CHECK(hipMalloc((void **)&c.p, total));
+    g.ws_chunks.push_back(c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// timing (HIP events on the backend stream, per kernel class)
+// ---------------------------------------------------------------------------------------------------
+struct Timed {
+    int k;
+    Timing::Rec rec{};
+    bool on;
+    Timed(int kclass, double algo_bytes) : k(kclass), on(g.timing.on) {
+        if (!on) return;
+        if (!g.timing.pool.empty()) {
+            rec = g.timing.pool.back();
+            g.timing.pool.pop_back();
+        } else {
+            HIP_CHECK(hipEventCreate(&rec.a));
+            HIP_CHECK(hipEventCreate(&rec.b));
+        }
+        HIP_CHECK(hipEventRecord(rec.a, g.stream));
+        g.timing.bytes[k] += algo_bytes;
+        g.timing.launches[k]++;
+    }
+    ~Timed() {
+        if (!on) return;
+        HIP_CHECK(hipEventRecord(rec.b, g.stream));
+        g.timing.recs[k].push_back(rec);
+    }
+};
+
+inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// ---------------------------------------------------------------------------------------------------
+// persistent device tensors
+// ---------------------------------------------------------------------------------------------------
+size_t qw_layout(int qt, int64_t nblocks, size_t off[5]) {
+    // returns total bytes; off = {qs, qs2, qh, d, m}
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    off[0] = o;
+    o = al(o + (size_t)nblocks * 16);
+    off[1] = o;
+    if (qt == QT_Q8_0) o = al(o + (size_t)nblocks * 16);
+    off[2] = o;
+    if (qt == QT_Q5_0 || qt == QT_Q5_1) o = al(o + (size_t)nblocks * 4);
+    off[3] = o;
+    o = al(o + (size_t)nblocks * 2);
+    off[4] = o;
+    if (qt == QT_Q4_1 || qt == QT_Q5_1) o = al(o + (size_t)nblocks * 2);
+    return o;
+}
+
+QWeight qw_at(char *base, int qt, int64_t M, int64_t nb) {
+    size_t off[5];
+    qw_layout(qt, M * nb, off);
+    QWeight w;
+    w.qs = (const uint8_t *)(base + off[0]);
+    w.qs2 = (const uint8_t *)(base + off[1]);
+    w.qh = (const uint32_t *)(base + off[2]);
+    w.d = (const __half *)(base + off[3]);
+    w.m = (const __half *)(base + off[4]);
+    w.M = M;
+    w.nb = nb;
+    w.qt = qt;
+    return w;
+}
+
+void relayout_launch(const char *raw_dev, int qt, int64_t M, int64_t nb, char *soa_base) {
+    QWeight w = qw_at(soa_base, qt, M, nb);
+    const int64_t nblocks = M * nb;
+    hipLaunchKernelGGL(k_relayout_q, grid1(nblocks), dim3(256), 0, g.stream, (const uint8_t *)raw_dev, qt, nblocks,
+                       (uint8_t *)w.qs, (uint8_t *)w.qs2, (uint32_t *)w.qh, (__half *)w.d, (__half *)w.m);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool wants_soa(const ggml_tensor *t) {
+    return qt_of(t->type) >= 0 && t->ne[2] == 1 && t->ne[3] == 1 && t->ne[0] % 32 == 0 && ggml_is_contiguous(t);
+}
+
+// Uploads `nbytes` from host `data` as the device copy of `t`. Returns the record (registered in g.tensors).
+DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill) {
+    ensure_init();
+    const size_t nbytes = ggml_nbytes(t);
+    DevTensor *e = new DevTensor();
+    e->host = (uintptr_t)data;
+    e->nbytes = nbytes;
+    e->type = t->type;
+    for (int i = 0; i < 4; i++) e->ne[i] = t->ne[i];
+    if (!zero_fill && wants_soa(t)) {
+        const int qt = qt_of(t->type);
+        const int64_t M = t->ne[1], nb = t->ne[0] / 32;
+        size_t off[5];
+        const size_t total = qw_layout(qt, M * nb, off);
+        HIP_CHECK(hipMalloc((void **)&e->dev, total));
+        e->dev_bytes = total;
+        char *tmp = nullptr;
+        HIP_CHECK(hipMalloc((void **)&tmp, nbytes));
+        HIP_CHECK(hipMemcpyAsync(tmp, data, nbytes, hipMemcpyHostToDevice, g.stream));
+        relayout_launch(tmp, qt, M, nb, e->dev);
+        HIP_CHECK(hipStreamSynchronize(g.stream));
+        HIP_CHECK(hipFree(tmp));
+        e->soa = true;
+        e->qw = qw_at(e->dev, qt, M, nb);
+    } else {
+        HIP_CHECK(hipMalloc((void **)&e->dev, std::max<size_t>(nbytes, 16)));
+        e->dev_bytes = nbytes;
+        if (zero_fill)
+            HIP_CHECK(hipMemsetAsync(e->dev, 0, std::max<size_t>(nbytes, 16), g.stream));
+        else
+            HIP_CHECK(hipMemcpyAsync(e->dev, data, nbytes, hipMemcpyHostToDevice, g.stream));
+        HIP_CHECK(hipStreamSynchronize(g.stream));
+    }
+    // replace any stale record at the same host base
+    auto it = g.tensors.find(e->host);
+    if (it != g.tensors.end()) {
+        DevTensor *old = it->second;
+        HIP_CHECK(hipFree(old->dev));
+        old->magic = 0;
+        delete old;
+        g.tensors.erase(it);
+    }
+    g.tensors[e->host] = e;
+    return e;
+}
+
+void free_dev_tensor(DevTensor *e) {
+    auto it = g.tensors.find(e->host);
+    if (it != g.tensors.end() && it->second == e) g.tensors.erase(it);
+    if (g.stream) HIP_CHECK(hipStreamSynchronize(g.stream));
+    if (e->dev) HIP_CHECK(hipFree(e->dev));
+    e->magic = 0;
+    delete e;
+}
+
+// the SoA view of a quantized mul_mat / get_rows operand; re-lays-out on the fly for raw arena tensors
+QWeight qweight_of(const ggml_tensor *t) {
+    DevTensor *e = extra_of(t);
+    if (!e) e = find_tensor((uintptr_t)t->data);
+    if (e && e->soa) {
+        if ((uintptr_t)t->data != e->host || t->ne[0] != e->ne[0] || t->ne[1] != e->ne[1])
+            die("tensor '%s': views of re-laid-out quantized weights are not supported", t->name);
+        return e->qw;
+    }
+    if (!wants_soa(t)) die("tensor '%s': quantized operand must be a contiguous 2-D matrix with ne0 %% 32 == 0", t->name);
+    // raw GGML blocks in an arena (e.g. a weight created in the compute context): convert into workspace
+    const int qt = qt_of(t->type);
+    const int64_t M = t->ne[1], nb = t->ne[0] / 32;
+    size_t off[5];
+    const size_t total = qw_layout(qt, M * nb, off);
+    char *raw = dev_ptr(t);
+    char *soa = ws_alloc(total);
+    relayout_launch(raw, qt, M, nb, soa);
+    return qw_at(soa, qt, M, nb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// op launchers
+// ---------------------------------------------------------------------------------------------------
+bool is_contig_f32(const ggml_tensor *t) { return t->type == GGML_TYPE_F32 && ggml_is_contiguous(t); }
+
+QAct quantize_activation(const ggml_tensor *src1, bool f16_d) {
+    BK_ASSERT(src1->type == GGML_TYPE_F32 && src1->nb[0] == 4 && src1->ne[2] == 1 && src1->ne[3] == 1);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
+    if (g_qact.valid && g_qact.src_data == src1->data && g_qact.f16_d == f16_d && g_qact.nb == nb && g_qact.ncols == N)
+        return g_qact.act;
+    const size_t nblk = (size_t)nb * N;
+    char *blk = ws_alloc(nblk * 40);
+    char *lo = blk, *hi = blk + nblk * 16, *d = blk + nblk * 32, *s = blk + nblk * 36;
+    const char *x = dev_ptr(src1);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)(K * N * 4 + nblk * 40));
+    const int64_t threads = (int64_t)nblk * 32;
+    if (f16_d)
+        hipLaunchKernelGGL(k_quantize_act<true>, grid1(threads), dim3(256), 0, g.stream, x, (int64_t)src1->nb[1], nb, N,
+                           (int8_t *)lo, (int8_t *)hi, (float *)d, (int *)s);
+    else
+        hipLaunchKernelGGL(k_quantize_act<false>, grid1(threads), dim3(256), 0, g.stream, x, (int64_t)src1->nb[1], nb,
+                           N, (int8_t *)lo, (int8_t *)hi, (float *)d, (int *)s);
+    HIP_CHECK(hipGetLastError());
+    g_qact.valid = true;
+    g_qact.src_data = src1->data;
+    g_qact.src_bytes = ggml_nbytes(src1);
+    g_qact.f16_d = f16_d;
+    g_qact.nb = nb;
+    g_qact.ncols = N;
+    g_qact.act = QAct{(const i32x4 *)lo, (const i32x4 *)hi, (const float *)d, (const int *)s};
+    return g_qact.act;
+}
+
+size_t blk_bytes(int qt) { return qt == QT_Q4_0 ? 18 : qt == QT_Q4_1 ? 20 : qt == QT_Q5_0 ? 22 : qt == QT_Q5_1 ? 24 : 34; }
+
+template <int QT, int NCOLS>
+void launch_mmvq_r(const MmvqArgs &a, int R, int nwg, size_t lds) {
+    switch (R) {
+        case 1: hipLaunchKernelGGL((k_mmvq<QT, NCOLS, 1>), dim3(nwg), dim3(256), lds, g.stream, a); break;
+        case 2: hipLaunchKernelGGL((k_mmvq<QT, NCOLS, 2>), dim3(nwg), dim3(256), lds, g.stream, a); break;
+        default: hipLaunchKernelGGL((k_mmvq<QT, NCOLS, 4>), dim3(nwg), dim3(256), lds, g.stream, a); break;
+    }
+}
+template <int QT>
+void launch_mmvq_c(const MmvqArgs &a, int ncols, int R, int nwg, size_t lds) {
+    switch (ncols) {
+        case 1: launch_mmvq_r<QT, 1>(a, R, nwg, lds); break;
+        case 2: launch_mmvq_r<QT, 2>(a, R, nwg, lds); break;
+        case 4: launch_mmvq_r<QT, 4>(a, R, nwg, lds); break;
+        case 8: launch_mmvq_r<QT, 8>(a, R, nwg, lds); break;
+        default: die("mmvq: bad ncols %d", ncols);
+    }
+}
+void launch_mmvq(int qt, const MmvqArgs &a, int ncols, int R, int nwg, size_t lds) {
+    switch (qt) {
+        case QT_Q4_0: launch_mmvq_c<QT_Q4_0>(a, ncols, R, nwg, lds); break;
+        case QT_Q4_1: launch_mmvq_c<QT_Q4_1>(a, ncols, R, nwg, lds); break;
+        case QT_Q5_0: launch_mmvq_c<QT_Q5_0>(a, ncols, R, nwg, lds); break;
+        case QT_Q5_1: launch_mmvq_c<QT_Q5_1>(a, ncols, R, nwg, lds); break;
+        case QT_Q8_0: launch_mmvq_c<QT_Q8_0>(a, ncols, R, nwg, lds); break;
+        default: die("mmvq: bad weight type");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+int pick_rows(int64_t M) {
+    if (g.opt_mmvq_rows == 1 || g.opt_mmvq_rows == 2 || g.opt_mmvq_rows == 4) return g.opt_mmvq_rows;
+    return M >= 16384 ? 2 : 1;
+}
+
+// Quantized mat-vec over up to 3 weight matrices sharing src1 (same type, same K).
+void mul_mat_q(int nmat, const ggml_tensor *const *src0s, const ggml_tensor *src1, ggml_tensor *const *dsts) {
+    const int qt = qt_of(src0s[0]->type);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
+    BK_ASSERT(K % 32 == 0);
+    QWeight ws[3];
+    for (int i = 0; i < nmat; i++) {
+        BK_ASSERT(src0s[i]->type == src0s[0]->type && src0s[i]->ne[0] == K);
+        BK_ASSERT(dsts[i]->type == GGML_TYPE_F32 && dsts[i]->nb[0] == 4);
+        ws[i] = qweight_of(src0s[i]);
+    }
+    const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
+    const QAct act = quantize_activation(src1, f16_d);
+    const int64_t max_cols_lds = (int64_t)(64 * 1024) / (nb * 40);
+    if (max_cols_lds < 1) die("mul_mat: K=%lld too large for the LDS-staged mat-vec", (long long)K);
+    int64_t c0 = 0;
+    while (c0 < N) {
+        int ncols = 8;
+        while (ncols > 1 && (ncols > N - c0 || ncols > max_cols_lds)) ncols >>= 1;
+        MmvqArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nseg = nmat;
+        a.nb = nb;
+        a.x.lo = act.lo + c0 * nb;
+        a.x.hi = act.hi + c0 * nb;
+        a.x.d = act.d + c0 * nb;
+        a.x.sum = act.sum + c0 * nb;
+        int nwg = 0;
+        int64_t Mmax = 0;
+        for (int i = 0; i < nmat; i++) Mmax = std::max(Mmax, ws[i].M);
+        const int R = pick_rows(Mmax);
+        double bytes = 0;
+        for (int i = 0; i < nmat; i++) {
+            a.seg[i].w = ws[i];
+            a.seg[i].dst = (float *)(dev_ptr(dsts[i]) + c0 * dsts[i]->nb[1]);
+            a.seg[i].ldd = (int64_t)dsts[i]->nb[1] / 4;
+            a.seg[i].wg_begin = nwg;
+            nwg += (int)((ws[i].M + 4 * R - 1) / (4 * R));
+            bytes += (double)ws[i].M * nb * blk_bytes(qt) + (double)ws[i].M * ncols * 4;
+        }
+        bytes += (double)ncols * nb * 40;
+        Timed tm(GGML_HIP_KCLASS_MMVQ, bytes);
+        launch_mmvq(qt, a, ncols, R, nwg, (size_t)ncols * nb * 40);
+        c0 += ncols;
+    }
+}
+
+void op_mul_mat(ggml_tensor *dst) {
+    const ggml_tensor *a = dst->src[0], *b = dst->src[1];
+    if (qt_of(a->type) >= 0) {
+        const ggml_tensor *s0[1] = {a};
+        ggml_tensor *d[1] = {dst};
+        mul_mat_q(1, s0, b, d);
+        return;
+    }
+    BK_ASSERT(b->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32);
+    BK_ASSERT(b->nb[0] == 4);
+    const TView va = view_of(a), vb = view_of(b), vd = view_of(dst);
+    const dim3 grid((unsigned)((a->ne[1] + 3) / 4), (unsigned)b->ne[1], (unsigned)(b->ne[2] * b->ne[3]));
+    const double bytes = (double)ggml_nelements(a) * ggml_element_size(a) * 1.0 + (double)ggml_nelements(b) * 4 +
+                         (double)ggml_nelements(dst) * 4;
+    Timed tm(GGML_HIP_KCLASS_ATTN, bytes);
+    if (a->type == GGML_TYPE_F16) {
+        BK_ASSERT(a->nb[0] == 2);
+        hipLaunchKernelGGL(k_mul_mat_f16, grid, dim3(256), 0, g.stream, va, vb, vd);
+    } else if (a->type == GGML_TYPE_F32) {
+        BK_ASSERT(a->nb[0] == 4);
+        hipLaunchKernelGGL(k_mul_mat_f32, grid, dim3(256), 0, g.stream, va, vb, vd);
+    } else {
+        die("mul_mat: unsupported src0 type %s", ggml_type_name(a->type));
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_rms_norm(ggml_tensor *dst, const ggml_tensor *weight /* nullable: fused mul */, ggml_tensor *out) {
+    const ggml_tensor *x = dst->src[0];
+    BK_ASSERT(x->type == GGML_TYPE_F32 && x->nb[0] == 4 && out->nb[0] == 4);
+    float eps;
+    memcpy(&eps, dst->op_params, sizeof(float));
+    const int64_t rows = ggml_nrows(x);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)ggml_nelements(x) * 8);
+    if (weight) {
+        BK_ASSERT(is_contig_f32(weight) && weight->ne[0] == x->ne[0] && ggml_nelements(weight) == x->ne[0]);
+        hipLaunchKernelGGL(k_rms_norm<true>, dim3((unsigned)rows), dim3(256), 0, g.stream, view_of(x), view_of(out),
+                           (const float *)dev_ptr(weight), eps);
+    } else {
+        hipLaunchKernelGGL(k_rms_norm<false>, dim3((unsigned)rows), dim3(256), 0, g.stream, view_of(x), view_of(out),
+                           (const float *)nullptr, eps);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_norm(ggml_tensor *dst) {
+    const ggml_tensor *x = dst->src[0];
+    BK_ASSERT(x->type == GGML_TYPE_F32 && x->nb[0] == 4 && dst->nb[0] == 4);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)ggml_nelements(x) * 8);
+    hipLaunchKernelGGL(k_norm, dim3((unsigned)ggml_nrows(x)), dim3(256), 0, g.stream, view_of(x), view_of(dst), 1e-5f);
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_bin(ggml_tensor *dst, int op) {
+    const ggml_tensor *a = dst->src[0], *b = dst->src[1];
+    BK_ASSERT(dst->type == GGML_TYPE_F32);
+    const int64_t n = ggml_nelements(dst);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)n * 12);
+    if (op == BIN_REPEAT) {
+        BK_ASSERT(a->type == GGML_TYPE_F32);
+        const TView va = view_of(a), vd = view_of(dst);
+        hipLaunchKernelGGL(k_bin<BIN_REPEAT>, grid1(n), dim3(256), 0, g.stream, va, va, vd, n);
+    } else {
+        BK_ASSERT(a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_F32);
+        const TView va = view_of(a), vb = view_of(b), vd = view_of(dst);
+        if (op == BIN_ADD)
+            hipLaunchKernelGGL(k_bin<BIN_ADD>, grid1(n), dim3(256), 0, g.stream, va, vb, vd, n);
+        else
+            hipLaunchKernelGGL(k_bin<BIN_MUL>, grid1(n), dim3(256), 0, g.stream, va, vb, vd, n);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_unary(ggml_tensor *dst, const ggml_tensor *mul_b /* nullable: fused silu*b */, ggml_tensor *out) {
+    const ggml_tensor *a = dst->src[0];
+    const int32_t uop = dst->op_params[0];
+    BK_ASSERT(is_contig_f32(a) && is_contig_f32(out));
+    const int64_t n = ggml_nelements(a);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)n * (mul_b ? 12 : 8));
+    const float *pa = (const float *)dev_ptr(a);
+    float *pd = (float *)dev_ptr(out);
+    if (uop == GGML_UNARY_OP_SILU) {
+        if (mul_b) {
+            BK_ASSERT(is_contig_f32(mul_b) && ggml_nelements(mul_b) == n);
+            hipLaunchKernelGGL((k_unary<UN_SILU, true>), grid1(n), dim3(256), 0, g.stream, pa,
+                               (const float *)dev_ptr(mul_b), pd, n);
+        } else {
+            hipLaunchKernelGGL((k_unary<UN_SILU, false>), grid1(n), dim3(256), 0, g.stream, pa, (const float *)nullptr,
+                               pd, n);
+        }
+    } else if (uop == GGML_UNARY_OP_GELU) {
+        BK_ASSERT(!mul_b);
+        hipLaunchKernelGGL((k_unary<UN_GELU, false>), grid1(n), dim3(256), 0, g.stream, pa, (const float *)nullptr, pd,
+                           n);
+    } else {
+        die("unary op %d is outside the accelerated path", (int)uop);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_scale(ggml_tensor *dst) {
+    const ggml_tensor *a = dst->src[0], *s = dst->src[1];
+    BK_ASSERT(is_contig_f32(a) && is_contig_f32(dst) && s->type == GGML_TYPE_F32);
+    const int64_t n = ggml_nelements(a);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)n * 8);
+    hipLaunchKernelGGL(k_scale, grid1(n), dim3(256), 0, g.stream, (const float *)dev_ptr(a), (const float *)dev_ptr(s),
+                       (float *)dev_ptr(dst), n);
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_diag_mask_inf(ggml_tensor *dst) {
+    const ggml_tensor *a = dst->src[0];
+    BK_ASSERT(is_contig_f32(a) && is_contig_f32(dst));
+    const int64_t n = ggml_nelements(a);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)n * 8);
+    hipLaunchKernelGGL(k_diag_mask_inf, grid1(n), dim3(256), 0, g.stream, (const float *)dev_ptr(a),
+                       (float *)dev_ptr(dst), a->ne[0], a->ne[1], n, (int)dst->op_params[0]);
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_soft_max(ggml_tensor *dst) {
+    const ggml_tensor *a = dst->src[0];
+    BK_ASSERT(is_contig_f32(a) && is_contig_f32(dst));
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)ggml_nelements(a) * 8);
+    hipLaunchKernelGGL(k_soft_max<false>, dim3((unsigned)ggml_nrows(a)), dim3(256), 0, g.stream,
+                       (const float *)dev_ptr(a), (float *)dev_ptr(dst), a->ne[0], a->ne[1], (const float *)nullptr, 0);
+    HIP_CHECK(hipGetLastError());
+}
+
+// fused scale -> diag_mask_inf -> soft_max (all three in-place on the KQ tensor)
+void op_scale_mask_softmax(const ggml_tensor *kq, const ggml_tensor *scale, int n_past, ggml_tensor *out) {
+    BK_ASSERT(is_contig_f32(kq) && is_contig_f32(out));
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)ggml_nelements(kq) * 8);
+    hipLaunchKernelGGL(k_soft_max<true>, dim3((unsigned)ggml_nrows(kq)), dim3(256), 0, g.stream,
+                       (const float *)dev_ptr(kq), (float *)dev_ptr(out), kq->ne[0], kq->ne[1],
+                       (const float *)dev_ptr(scale), n_past);
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_rope(ggml_tensor *dst) {
+    const ggml_tensor *a = dst->src[0];
+    BK_ASSERT(a->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32);
+    const int n_past = dst->op_params[0], n_dims = dst->op_params[1], mode = dst->op_params[2];
+    float freq_base, freq_scale;
+    memcpy(&freq_base, dst->op_params + 4, 4);
+    memcpy(&freq_scale, dst->op_params + 5, 4);
+    if ((mode & ~1) != 0) die("rope mode %d (NeoX/GLM) is outside the accelerated LLaMA path", mode);
+    BK_ASSERT(a->ne[0] % 2 == 0);
+    const float theta_scale = powf(freq_base, -2.0f / n_dims);
+    const int64_t total = (a->ne[0] / 2) * a->ne[1] * a->ne[2] * a->ne[3];
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)ggml_nelements(a) * 8);
+    hipLaunchKernelGGL(k_rope, grid1(total), dim3(256), 0, g.stream, view_of(a), view_of(dst), n_past, theta_scale,
+                       freq_scale, mode);
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_cpy(const ggml_tensor *src, ggml_tensor *dst) {
+    const int64_t n = ggml_nelements(src);
+    BK_ASSERT(n == ggml_nelements(dst));
+    const TView vs = view_of(src), vd = view_of(dst);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)n * (ggml_element_size(src) + ggml_element_size(dst)));
+    const ggml_type ts = src->type, td = dst->type;
+    if (ts == GGML_TYPE_F32 && td == GGML_TYPE_F32)
+        hipLaunchKernelGGL((k_cpy<float, float>), grid1(n), dim3(256), 0, g.stream, vs, vd, n);
+    else if (ts == GGML_TYPE_F32 && td == GGML_TYPE_F16)
+        hipLaunchKernelGGL((k_cpy<float, __half>), grid1(n), dim3(256), 0, g.stream, vs, vd, n);
+    else if (ts == GGML_TYPE_F16 && td == GGML_TYPE_F16)
+        hipLaunchKernelGGL((k_cpy<__half, __half>), grid1(n), dim3(256), 0, g.stream, vs, vd, n);
+    else if (ts == GGML_TYPE_F16 && td == GGML_TYPE_F32)
+        hipLaunchKernelGGL((k_cpy<__half, float>), grid1(n), dim3(256), 0, g.stream, vs, vd, n);
+    else if (ts == GGML_TYPE_I32 && td == GGML_TYPE_I32)
+        hipLaunchKernelGGL((k_cpy<int, int>), grid1(n), dim3(256), 0, g.stream, vs, vd, n);
+    else
+        die("cpy %s -> %s is outside the accelerated path", ggml_type_name(ts), ggml_type_name(td));
+    HIP_CHECK(hipGetLastError());
+}
+
+void op_get_rows(ggml_tensor *dst) {
+    const ggml_tensor *tab = dst->src[0], *ids = dst->src[1];
+    BK_ASSERT(ids->type == GGML_TYPE_I32 && is_contig_f32(dst));
+    const int64_t N = ids->ne[0], ne0 = tab->ne[0];
+    const int *pid = (const int *)dev_ptr(ids);
+    float *pd = (float *)dev_ptr(dst);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)N * ne0 * 5);
+    if (qt_of(tab->type) >= 0) {
+        const QWeight w = qweight_of(tab);
+        hipLaunchKernelGGL(k_get_rows_q, dim3((unsigned)((w.nb + 255) / 256), (unsigned)N), dim3(256), 0, g.stream, w,
+                           pid, pd, ne0);
+    } else if (tab->type == GGML_TYPE_F16) {
+        hipLaunchKernelGGL(k_get_rows<__half>, dim3((unsigned)((ne0 + 255) / 256), (unsigned)N), dim3(256), 0, g.stream,
+                           (const char *)dev_ptr(tab), (int64_t)tab->nb[1], pid, pd, ne0);
+    } else if (tab->type == GGML_TYPE_F32) {
+        hipLaunchKernelGGL(k_get_rows<float>, dim3((unsigned)((ne0 + 255) / 256), (unsigned)N), dim3(256), 0, g.stream,
+                           (const char *)dev_ptr(tab), (int64_t)tab->nb[1], pid, pd, ne0);
+    } else {
+        die("get_rows on %s is outside the accelerated path", ggml_type_name(tab->type));
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graph executor
+// ---------------------------------------------------------------------------------------------------
+bool is_view_op(ggml_op op) {
+    return op == GGML_OP_NONE || op == GGML_OP_RESHAPE || op == GGML_OP_VIEW || op == GGML_OP_PERMUTE ||
+           op == GGML_OP_TRANSPOSE;
+}
+
+struct GraphInfo {
+    std::vector<int> n_uses;  // consumers per node index
+};
+
+int node_index(const ggml_cgraph *gr, const ggml_tensor *t, const std::map<const ggml_tensor *, int> &idx) {
+    (void)gr;
+    auto it = idx.find(t);
+    return it == idx.end() ? -1 : it->second;
+}
+
+void upload_inputs(ggml_cgraph *gr) {
+    if (gr->n_nodes == 0) return;
+    // the compute context = the arena holding the tensor headers of the graph's nodes
+    Arena *r0 = find_arena((uintptr_t)gr->nodes[gr->n_nodes - 1]);
+    for (int i = 0; i < gr->n_leafs; i++) {
+        ggml_tensor *leaf = gr->leafs[i];
+        if (leaf->data == nullptr) continue;
+        if (extra_of(leaf)) continue;
+        const uintptr_t p = (uintptr_t)leaf->data;
+        if (DevTensor *e = find_tensor(p)) {
+            // auto-uploaded earlier; make sure it still describes this tensor
+            if (e->auto_uploaded && (e->host != p || e->nbytes != ggml_nbytes(leaf) || e->type != leaf->type)) {
+                free_dev_tensor(e);
+            } else {
+                continue;
+            }
+        }
+        Arena *hdr = find_arena((uintptr_t)leaf);
+        const bool per_eval = r0 && hdr == r0;
+        if (per_eval) {
+            // inputs written by the host before every compute (token ids, scalar constants, test operands)
+            const size_t nbytes = ggml_nbytes(leaf);
+            if (nbytes == 0) continue;
+            HIP_CHECK(hipMemcpyAsync(dev_ptr(leaf), leaf->data, nbytes, hipMemcpyHostToDevice, g.stream));
+        } else {
+            // persistent tensor (weight / KV memory) that was never offloaded by the caller: upload once
+            DevTensor *e = upload_tensor(leaf->data, leaf, false);
+            e->auto_uploaded = true;
+        }
+    }
+}
+
+void download_outputs(ggml_cgraph *gr) {
+    bool any = false;
+    for (int i = 0; i < gr->n_nodes; i++) {
+        ggml_tensor *n = gr->nodes[i];
+        if (n->backend != GGML_BACKEND_CPU || is_view_op(n->op) || n->op == GGML_OP_CPY) continue;
+        if (!ggml_is_contiguous(n) || n->data == nullptr) continue;
+        if (extra_of(n) || find_tensor((uintptr_t)n->data)) continue;  // result aliases a device-resident tensor
+        HIP_CHECK(hipMemcpyAsync(n->data, dev_ptr(n), ggml_nbytes(n), hipMemcpyDeviceToHost, g.stream));
+        any = true;
+    }
+    (void)any;
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+
+void invalidate_qact_if_overwritten(const ggml_tensor *n) {
+    if (!g_qact.valid || n->data == nullptr) return;
+    const uintptr_t a0 = (uintptr_t)g_qact.src_data, a1 = a0 + g_qact.src_bytes;
+    const uintptr_t b0 = (uintptr_t)n->data, b1 = b0 + ggml_nbytes(n);
+    if (b0 < a1 && a0 < b1) g_qact.valid = false;
+}
+
+void execute_graph(ggml_cgraph *gr) {
+    ensure_init();
+    ws_reset();
+    g_qact.valid = false;
+    upload_inputs(gr);
+
+    std::map<const ggml_tensor *, int> idx;
+    std::vector<int> uses(gr->n_nodes, 0);
+    for (int i = 0; i < gr->n_nodes; i++) idx[gr->nodes[i]] = i;
+    for (int i = 0; i < gr->n_nodes; i++)
+        for (int s = 0; s < GGML_MAX_SRC; s++)
+            if (gr->nodes[i]->src[s]) {
+                int j = node_index(gr, gr->nodes[i]->src[s], idx);
+                if (j >= 0) uses[j]++;
+            }
+    std::vector<char> done(gr->n_nodes, 0);
+    const bool fuse = g.opt_fuse != 0;
+
+    for (int i = 0; i < gr->n_nodes; i++) {
+        ggml_tensor *n = gr->nodes[i];
+        if (done[i] || is_view_op(n->op)) continue;
+        invalidate_qact_if_overwritten(n);
+        ggml_tensor *next = i + 1 < gr->n_nodes ? gr->nodes[i + 1] : nullptr;
+        switch (n->op) {
+            case GGML_OP_GET_ROWS: op_get_rows(n); break;
+            case GGML_OP_RMS_NORM: {
+                // fuse the broadcast multiply by the norm weight that follows (llama lib.rs:183-186)
+                if (fuse && next && next->op == GGML_OP_MUL && next->src[0] == n && uses[i] == 1 && !done[i + 1] &&
+                    is_contig_f32(next->src[1]) && ggml_nelements(next->src[1]) == n->ne[0] && next->nb[0] == 4) {
+                    op_rms_norm(n, next->src[1], next);
+                    done[i + 1] = 1;
+                } else {
+                    op_rms_norm(n, nullptr, n);
+                }
+            } break;
+            case GGML_OP_NORM: op_norm(n); break;
+            case GGML_OP_ADD: op_bin(n, BIN_ADD); break;
+            case GGML_OP_MUL: op_bin(n, BIN_MUL); break;
+            case GGML_OP_REPEAT: op_bin(n, BIN_REPEAT); break;
+            case GGML_OP_UNARY: {
+                if (fuse && n->op_params[0] == GGML_UNARY_OP_SILU && next && next->op == GGML_OP_MUL &&
+                    next->src[0] == n && uses[i] == 1 && !done[i + 1] && is_contig_f32(next->src[1]) &&
+                    ggml_nelements(next->src[1]) == ggml_nelements(n) && is_contig_f32(next)) {
+                    op_unary(n, next->src[1], next);
+                    done[i + 1] = 1;
+                } else {
+                    op_unary(n, nullptr, n);
+                }
+            } break;
+            case GGML_OP_MUL_MAT: op_mul_mat(n); break;
+            case GGML_OP_SCALE: {
+                // fuse scale -> diag_mask_inf -> soft_max when chained in place (llama lib.rs:268-281)
+                ggml_tensor *n1 = next, *n2 = i + 2 < gr->n_nodes ? gr->nodes[i + 2] : nullptr;
+                if (fuse && n1 && n2 && n1->op == GGML_OP_DIAG_MASK_INF && n1->src[0] == n && n2->op == GGML_OP_SOFT_MAX &&
+                    n2->src[0] == n1 && uses[i] == 1 && uses[i + 1] == 1 && n->data == n->src[0]->data &&
+                    n1->data == n->data && n2->data == n->data && is_contig_f32(n)) {
+                    op_scale_mask_softmax(n->src[0], n->src[1], (int)n1->op_params[0], n2);
+                    done[i + 1] = done[i + 2] = 1;
+                } else {
+                    op_scale(n);
+                }
+            } break;
+            case GGML_OP_DIAG_MASK_INF: op_diag_mask_inf(n); break;
+            case GGML_OP_SOFT_MAX: op_soft_max(n); break;
+            case GGML_OP_ROPE: op_rope(n); break;
+            case GGML_OP_CPY: op_cpy(n->src[0], n->src[1]); break;
+            case GGML_OP_CONT:
+            case GGML_OP_DUP: op_cpy(n->src[0], n); break;
+            default:
+                die("op %s (node '%s') is outside the accelerated path and this library has no CPU fallback",
+                    ggml_op_name(n->op), n->name);
+        }
+    }
+    download_outputs(gr);
+}
+
+}  // namespace
+
+// ===================================================================================================
+// exported: internal seam
+// ===================================================================================================
+extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    const uintptr_t b = (uintptr_t)host_base;
+    if (size == 0) return;
+    auto it = g.arenas.find(b);
+    if (it != g.arenas.end() && it->second.size == size) {
+        if (!it->second.live && it->second.dev) g.dead_shadow_bytes -= it->second.size;
+        it->second.live = true;  // same buffer re-initialised (ctx0.recreate()): keep the device shadow
+        return;
+    }
+    // drop arenas that overlap the new range (the host memory was recycled)
+    for (auto jt = g.arenas.begin(); jt != g.arenas.end();) {
+        Arena &a = jt->second;
+        if (a.base < b + size && b < a.base + a.size) {
+            if (a.dev) {
+                if (g.stream) HIP_CHECK(hipStreamSynchronize(g.stream));
+                HIP_CHECK(hipFree(a.dev));
+                if (!a.live) g.dead_shadow_bytes -= a.size;
+            }
+            jt = g.arenas.erase(jt);
+        } else {
+            ++jt;
+        }
+    }
+    Arena a;
+    a.base = b;
+    a.size = size;
+    g.arenas[b] = a;
+}
+
+extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    const uintptr_t b = (uintptr_t)host_base;
+    auto it = g.arenas.find(b);
+    if (it == g.arenas.end()) return;
+    Arena &a = it->second;
+    // auto-uploaded persistent tensors whose host bytes lived in this arena die with it
+    for (auto jt = g.tensors.begin(); jt != g.tensors.end();) {
+        DevTensor *e = jt->second;
+        ++jt;
+        if (e->auto_uploaded && e->host >= a.base && e->host < a.base + a.size) free_dev_tensor(e);
+    }
+    a.live = false;
+    if (a.dev) {
+        g.dead_shadow_bytes += a.size;
+        if (g.dead_shadow_bytes > ((size_t)8 << 30)) {  // bound the memory parked in dead shadows
+            if (g.stream) HIP_CHECK(hipStreamSynchronize(g.stream));
+            for (auto jt = g.arenas.begin(); jt != g.arenas.end();) {
+                if (!jt->second.live) {
+                    if (jt->second.dev) HIP_CHECK(hipFree(jt->second.dev));
+                    jt = g.arenas.erase(jt);
+                } else {
+                    ++jt;
+                }
+            }
+            g.dead_shadow_bytes = 0;
+        }
+    } else {
+        g.arenas.erase(it);
+    }
+}
+
+extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    execute_graph(cgraph);
+}
+
+// ===================================================================================================
+// exported: the 19 accelerator hooks (crates/ggml/sys/src/cuda.rs:6-77)
+// ===================================================================================================
+extern "C" {
+
+void ggml_init_hipblas(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+}
+void ggml_hip_set_main_device(int main_device) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (g.inited && main_device != g.device)
+        die("ggml_hip_set_main_device(%d) after initialisation on device %d: one process drives one GPU", main_device,
+            g.device);
+    g.device = main_device;
+}
+void ggml_hip_set_tensor_split(const float *tensor_split) {
+    // The reference always passes a single 1.0 (crates/ggml/src/accelerator/mod.rs:74-75). Multi-GPU here is a
+    // layer split across processes (one per GPU, RCCL send/recv of the residual), not an intra-tensor row split.
+    (void)tensor_split;
+}
+void ggml_hip_set_mul_mat_q(bool) {}  // quantized kernels are always used
+void ggml_hip_set_scratch_size(size_t) {}  // activations live in arena shadows, there is no scratch pool
+void ggml_hip_free_scratch(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (!g.inited) return;
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    // release shadows of arenas that are no longer live (session buffers) and the workspace
+    for (auto it = g.arenas.begin(); it != g.arenas.end();) {
+        if (!it->second.live) {
+            if (it->second.dev) HIP_CHECK(hipFree(it->second.dev));
+            it = g.arenas.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    g.dead_shadow_bytes = 0;
+}
+void *ggml_hip_host_malloc(size_t size) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    void *p = nullptr;
+    if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void ggml_hip_host_free(void *ptr) {
+    if (ptr) HIP_CHECK(hipHostFree(ptr));
+}
+void ggml_hip_transform_tensor(void *data, struct ggml_tensor *tensor) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (extra_of(tensor)) return;
+    tensor->backend = GGML_BACKEND_GPU;
+    tensor->extra = upload_tensor(data, tensor, false);
+}
+void ggml_hip_free_data(struct ggml_tensor *tensor) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (!tensor || !tensor->extra) return;
+    DevTensor *e = (DevTensor *)tensor->extra;
+    if (e->magic != 0x48495054) return;  // scratch-assigned node: nothing to free (as in the reference)
+    free_dev_tensor(e);
+    tensor->extra = nullptr;
+}
+void ggml_hip_assign_buffers(struct ggml_tensor *tensor) {
+    // Compute nodes need no per-node device buffer: their device address is the arena mirror of
+    // tensor->data. Marking the backend keeps the results device-only (no D2H after compute).
+    tensor->backend = GGML_BACKEND_GPU;
+}
+void ggml_hip_assign_buffers_force_inplace(struct ggml_tensor *tensor) { tensor->backend = GGML_BACKEND_GPU; }
+void ggml_hip_assign_buffers_no_scratch(struct ggml_tensor *tensor) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    tensor->backend = GGML_BACKEND_GPU;
+    if (tensor->op != GGML_OP_NONE || extra_of(tensor)) return;
+    // persistent, zero-initialised device tensor (the K/V memory: inference_session.rs:996-1021)
+    tensor->extra = upload_tensor(tensor->data, tensor, true);
+}
+bool ggml_hip_can_mul_mat(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    const bool q = qt_of(src0->type) >= 0 || src0->type == GGML_TYPE_F16 || src0->type == GGML_TYPE_F32;
+    return q && src1->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32;
+}
+size_t ggml_hip_mul_mat_get_wsize(const struct ggml_tensor *, const struct ggml_tensor *, struct ggml_tensor *) {
+    return 0;
+}
+void ggml_hip_mul_mat(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst, void *,
+                      size_t) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    BK_ASSERT(dst->src[0] == src0 && dst->src[1] == src1);
+    op_mul_mat(dst);
+}
+void ggml_hip_mul(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    BK_ASSERT(dst->src[0] == src0 && dst->src[1] == src1);
+    op_bin(dst, BIN_MUL);
+}
+bool ggml_hip_compute_forward(struct ggml_compute_params *params, struct ggml_tensor *tensor) {
+    // Per-node hook of the reference's CPU executor. This library executes whole graphs itself
+    // (ggml_graph_compute), so the hook only has to answer for callers that drive nodes one by one.
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (params && (params->ith != 0 || params->type != GGML_TASK_COMPUTE)) return true;
+    ensure_init();
+    ggml_cgraph *gr = (ggml_cgraph *)calloc(1, sizeof(ggml_cgraph));
+    // single-node graph: sources must already be device-visible
+    gr->nodes[0] = tensor;
+    gr->n_nodes = 1;
+    execute_graph(gr);
+    free(gr);
+    return true;
+}
+
+// cublas-named aliases (zero-change drop-in for the reference's `cublas` cfg arms)
+void ggml_init_cublas(void) { ggml_init_hipblas(); }
+void ggml_cuda_set_tensor_split(const float *s) { ggml_hip_set_tensor_split(s); }
+void ggml_cuda_mul(const struct ggml_tensor *a, const struct ggml_tensor *b, struct ggml_tensor *d) { ggml_hip_mul(a, b, d); }
+bool ggml_cuda_can_mul_mat(const struct ggml_tensor *a, const struct ggml_tensor *b, struct ggml_tensor *d) {
+    return ggml_hip_can_mul_mat(a, b, d);
+}
+size_t ggml_cuda_mul_mat_get_wsize(const struct ggml_tensor *a, const struct ggml_tensor *b, struct ggml_tensor *d) {
+    return ggml_hip_mul_mat_get_wsize(a, b, d);
+}
+void ggml_cuda_mul_mat(const struct ggml_tensor *a, const struct ggml_tensor *b, struct ggml_tensor *d, void *w, size_t s) {
+    ggml_hip_mul_mat(a, b, d, w, s);
+}
+void *ggml_cuda_host_malloc(size_t size) { return ggml_hip_host_malloc(size); }
+void ggml_cuda_host_free(void *ptr) { ggml_hip_host_free(ptr); }
+void ggml_cuda_transform_tensor(void *data, struct ggml_tensor *t) { ggml_hip_transform_tensor(data, t); }
+void ggml_cuda_free_data(struct ggml_tensor *t) { ggml_hip_free_data(t); }
+void ggml_cuda_assign_buffers(struct ggml_tensor *t) { ggml_hip_assign_buffers(t); }
+void ggml_cuda_assign_buffers_no_scratch(struct ggml_tensor *t) { ggml_hip_assign_buffers_no_scratch(t); }
+void ggml_cuda_assign_buffers_force_inplace(struct ggml_tensor *t) { ggml_hip_assign_buffers_force_inplace(t); }
+void ggml_cuda_set_main_device(int d) { ggml_hip_set_main_device(d); }
+void ggml_cuda_set_mul_mat_q(bool q) { ggml_hip_set_mul_mat_q(q); }
+void ggml_cuda_set_scratch_size(size_t s) { ggml_hip_set_scratch_size(s); }
+void ggml_cuda_free_scratch(void) { ggml_hip_free_scratch(); }
+bool ggml_cuda_compute_forward(struct ggml_compute_params *p, struct ggml_tensor *t) { return ggml_hip_compute_forward(p, t); }
+
+// ===================================================================================================
+// exported: extensions
+// ===================================================================================================
+int ggml_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+void ggml_hip_synchronize(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (g.inited) HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void ggml_hip_tensor_get(const struct ggml_tensor *tensor, void *host_dst, size_t offset, size_t nbytes) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    HIP_CHECK(hipMemcpyAsync(host_dst, dev_ptr(tensor) + offset, nbytes, hipMemcpyDeviceToHost, g.stream));
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_t offset, size_t nbytes) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    HIP_CHECK(hipMemcpyAsync(dev_ptr(tensor) + offset, host_src, nbytes, hipMemcpyHostToDevice, g.stream));
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void *ggml_hip_tensor_device_ptr(const struct ggml_tensor *tensor) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    return dev_ptr(tensor);
+}
+void ggml_hip_timing_begin(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < GGML_HIP_KCLASS_COUNT; k++) {
+        for (auto &r : g.timing.recs[k]) g.timing.pool.push_back(r);
+        g.timing.recs[k].clear();
+        g.timing.bytes[k] = 0;
+        g.timing.launches[k] = 0;
+    }
+    g.timing.on = true;
+}
+void ggml_hip_timing_end(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    g.timing.on = false;
+    if (g.inited) HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    double total = 0;
+    if (kclass >= 0 && kclass < GGML_HIP_KCLASS_COUNT) {
+        for (auto &r : g.timing.recs[kclass]) {
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+            total += t;
+        }
+        if (ms) *ms = total;
+        if (launches) *launches = g.timing.launches[kclass];
+        if (algo_bytes) *algo_bytes = g.timing.bytes[kclass];
+    }
+}
+void ggml_hip_set_option(const char *key, int value) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    const std::string k(key);
+    if (k == "fuse")
+        g.opt_fuse = value;
+    else if (k == "mmvq_rows")
+        g.opt_mmvq_rows = value;
+    else
+        die("ggml_hip_set_option: unknown key '%s'", key);
+}
+const char *ggml_hip_version(void) { return "libggml_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

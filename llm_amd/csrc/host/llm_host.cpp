@@ -1,0 +1,463 @@
+// llm_host.cpp — C++ mirror of the host code on the hot path of rustformers/llm:
+//   crates/llm-base/src/inference_session.rs  InferenceSession {new, compute, feed_prompt,
+//                                              infer_next_token, rewind}            (:114-424)
+//   crates/llm-base/src/model/{mod,common}.rs  ModelParameters, OutputRequest, read_last_token …
+//   crates/models/llama/src/lib.rs             Llama {new, start_session, evaluate}  (:43-368)
+// The reference is Rust and no Rust toolchain exists in this image; this file keeps its structure,
+// names and call order so that the graph handed to ggml_graph_compute is node-for-node the graph the
+// Rust code builds (tests/test_graph_shape.py counts the nodes).  All compute goes through the C ABI
+// of include/ggml_hip.h.
+#include "llm_host.h"
+
+#include <cmath>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "ggml_wrap.hpp"
+
+using ggml::Backend;
+using ggml::Buffer;
+using ggml::ComputationGraph;
+using ggml::Context;
+using ggml::GraphExecutionPlan;
+using ggml::Tensor;
+
+namespace llm {
+
+using TokenId = int32_t;
+
+// crates/llm-base/src/model/mod.rs:196-251
+struct ModelParameters {
+    size_t context_size = 2048;
+    bool use_gpu = false;
+    long gpu_layers = -1;  // None
+    bool has_rope_overrides = false;
+    ggml::RoPEOverrides rope_overrides;
+    long n_gqa = -1;
+    // layer-split extension: this process owns layers [layer_begin, layer_end)
+    size_t layer_begin = 0, layer_end = (size_t)-1;
+
+    bool should_offload(size_t layer) const {
+        if (!use_gpu) return false;
+        return gpu_layers < 0 ? true : (long)layer < gpu_layers;
+    }
+    Backend backend(size_t layer) const { return should_offload(layer) ? Backend::Gpu : Backend::Cpu; }
+};
+
+// crates/llm-base/src/inference_session.rs:799-841
+struct InferenceSessionConfig {
+    ggml::Type memory_k_type = GGML_TYPE_F16;
+    ggml::Type memory_v_type = GGML_TYPE_F16;
+    size_t n_batch = 8;
+    size_t n_threads = 8;
+};
+
+// crates/llm-base/src/model/mod.rs:257-266
+struct OutputRequest {
+    std::vector<float> *all_logits = nullptr;
+    std::vector<float> *embeddings = nullptr;
+};
+
+struct GraphOutputs {  // inference_session.rs:31-37
+    Tensor result;
+    Tensor embedding_result;
+};
+
+constexpr size_t SCRATCH_SIZE = 512ull * 1024 * 1024;  // inference_session.rs:19
+
+struct BuildContext {  // inference_session.rs:96-109
+    Context *ctx0;
+    const Tensor *embd;
+    const Tensor *memory_k;
+    const Tensor *memory_v;
+    const std::shared_ptr<Buffer> *scratch;
+    const Buffer *get_scratch(size_t idx) const { return scratch[idx].get(); }
+};
+
+class InferenceSession {
+   public:
+    // inference_session.rs:114-217
+    InferenceSession(const InferenceSessionConfig &config, const ModelParameters &params, size_t n_layer,
+                     size_t n_embd, size_t n_vocab)
+        : config(config), n_embd_(n_embd) {
+        const size_t context_size = params.context_size;
+        const size_t context_byte_size = [&] {
+            double size = 0;
+            size += (double)context_size * (double)n_layer * (double)n_embd * (double)ggml_type_sizef(config.memory_k_type);
+            size += (double)context_size * (double)n_layer * (double)n_embd * (double)ggml_type_sizef(config.memory_v_type);
+            return (size_t)size + (5 + 10 * n_layer) * 256;  // object overhead
+        }();
+        if (params.use_gpu) {
+            ggml::accelerator::initialize(0);
+            ggml::accelerator::set_scratch_size(config.n_batch * 1024 * 1024);
+        }
+        session_ctx_ = std::make_shared<Context>(Context::new_with_allocate(context_byte_size));
+        memory_size_ = context_byte_size;
+        // Initialize key + value memory tensors (kv_memory, inference_session.rs:996-1021)
+        const size_t n_mem = n_layer * context_size;
+        const size_t n_elements = n_embd * n_mem;
+        memory_k = session_ctx_->new_tensor_1d(config.memory_k_type, n_elements).set_name("memory_k");
+        memory_v = session_ctx_->new_tensor_1d(config.memory_v_type, n_elements).set_name("memory_v");
+        if (params.use_gpu) {
+            memory_k.offload_no_scratch();
+            memory_v.offload_no_scratch();
+        }
+        scratch_[0] = std::make_shared<Buffer>(SCRATCH_SIZE);
+        scratch_[1] = std::make_shared<Buffer>(SCRATCH_SIZE);
+        const size_t buf_size_mb = n_layer >= 80 ? 1536 : n_layer >= 60 ? 1280 : 1024;
+        const size_t buf_size = buf_size_mb * 1024 * 1024 + ggml_graph_overhead();
+        ctx0_ = Context::new_with_buffer(std::make_shared<Buffer>(buf_size));
+        last_logits.assign(n_vocab, 0.0f);
+    }
+    ~InferenceSession() {
+        // inference_session.rs:659-665: free accelerator scratch; K/V are freed by the session ctx destructor
+        ggml::accelerator::free_scratch();
+    }
+
+    // inference_session.rs:220-295
+    GraphOutputs compute(const std::vector<TokenId> &input_tokens,
+                         const std::function<std::pair<ComputationGraph, GraphOutputs>(BuildContext &)> &builder) {
+        ctx0_.recreate();
+        Tensor embd = ctx0_.new_tensor_1d(GGML_TYPE_I32, input_tokens.size()).set_name("embd");
+        BuildContext bc{&ctx0_, &embd, &memory_k, &memory_v, scratch_};
+        auto built = builder(bc);
+        ComputationGraph &built_gf = built.first;
+        GraphOutputs &built_result = built.second;
+        embd.write_data(input_tokens.data(), input_tokens.size() * sizeof(TokenId));  // Write input tokens
+        built_gf.build_forward_expand(built_result.result);                          // Compute the graph
+        {
+            GraphExecutionPlan plan(built_gf, config.n_threads);
+            plan.execute(ctx0_);
+        }
+        last_n_nodes = built_gf.raw()->n_nodes;
+        last_n_leafs = built_gf.raw()->n_leafs;
+        if (mem_per_token == 0) mem_per_token = ctx0_.used_mem() / n_embd_;
+        n_past += input_tokens.size();
+        return GraphOutputs{built_result.result.share(), built_result.embedding_result.share()};
+    }
+
+    InferenceSessionConfig config;
+    Tensor memory_k, memory_v;
+    size_t n_past = 0;
+    size_t mem_per_token = 0;
+    std::vector<TokenId> tokens;
+    std::vector<float> last_logits;
+    int last_n_nodes = 0, last_n_leafs = 0;
+
+   private:
+    std::shared_ptr<Context> session_ctx_;
+    size_t memory_size_ = 0;
+    Context ctx0_;
+    size_t n_embd_;
+    std::shared_ptr<Buffer> scratch_[2];
+};
+
+// crates/llm-base/src/model/common.rs:6-59
+namespace common {
+inline void read_last_token(InferenceSession &session, const Tensor &input_layer, size_t n_vocab, size_t n) {
+    if (session.last_logits.size() != n_vocab) ggml::panic("last_logits size mismatch");
+    input_layer.read_data(n_vocab * (n - 1) * sizeof(float), session.last_logits.data(), n_vocab * sizeof(float));
+}
+inline void extract_logits(OutputRequest &req, const Tensor &input_layer, size_t n_vocab, size_t n) {
+    if (!req.all_logits) return;
+    req.all_logits->assign(n_vocab * n, 0.0f);
+    if (input_layer.nelements() != n_vocab * n) ggml::panic("extract_logits: element count mismatch");
+    input_layer.read_data(0, req.all_logits->data(), n_vocab * n * sizeof(float));
+}
+inline void extract_embeddings(OutputRequest &req, const Tensor &embeddings_tensor, size_t n_embd, size_t n) {
+    if (!req.embeddings) return;
+    req.embeddings->assign(n_embd, 0.0f);
+    std::vector<float> all(n_embd * n);
+    if (embeddings_tensor.nelements() != n_embd * n) ggml::panic("extract_embeddings: element count mismatch");
+    // The reference reads the host pointer (common.rs:52-56); the node is device-resident when offloaded, so
+    // the mirror asks the backend for the device copy instead of reading stale host memory.
+    ggml_hip_tensor_get(embeddings_tensor.ptr(), all.data(), 0, all.size() * sizeof(float));
+    std::copy(all.begin() + n_embd * (n - 1), all.end(), req.embeddings->begin());
+}
+}  // namespace common
+
+struct Hyperparameters {  // models/llama/src/lib.rs:399-416
+    size_t n_vocab = 0, n_embd = 0, n_mult = 0, n_head = 0, n_head_kv = 0, n_layer = 0, n_rot = 0;
+    int32_t file_type = 0;
+};
+
+struct Layer {  // models/llama/src/lib.rs:474-488
+    Tensor attention_norm, wq, wk, wv, wo, ffn_norm, w1, w2, w3;
+};
+
+// TensorLoader (crates/llm-base/src/loader.rs:651-678): creates the named tensor in the model context and
+// points its data at the caller's bytes (the mmap flavour: loader.rs:733-737).
+class TensorLoader {
+   public:
+    TensorLoader(const llm_tensor_desc *t, int n) : descs_(t, t + n) {
+        ctx_ = std::make_shared<Context>(
+            Context::new_with_mmap((size_t)n * (sizeof(ggml_tensor) + sizeof(ggml_object) + 64) + 1024));
+    }
+    Tensor load(const std::string &name) {
+        for (auto &d : descs_) {
+            if (name != d.name) continue;
+            Tensor t = d.n_dims == 1 ? ctx_->new_tensor_1d((ggml_type)d.type, (size_t)d.ne[0])
+                                     : ctx_->new_tensor_2d((ggml_type)d.type, (size_t)d.ne[0], (size_t)d.ne[1]);
+            t.set_data(d.data);
+            t.set_name(name.c_str());
+            return t;
+        }
+        fprintf(stderr, "llm: unknown tensor '%s'\n", name.c_str());  // LoadError::UnknownTensor
+        abort();
+    }
+    std::shared_ptr<Context> finish() { return ctx_; }
+
+   private:
+    std::vector<llm_tensor_desc> descs_;
+    std::shared_ptr<Context> ctx_;
+};
+
+class Llama {
+   public:
+    // models/llama/src/lib.rs:43-130
+    Llama(Hyperparameters hp, ModelParameters params, TensorLoader tl) : hyperparameters(hp), params(params) {
+        wte = tl.load("tok_embeddings.weight");
+        const Backend backend = params.backend(0);
+        norm = tl.load("norm.weight").transfer_to(backend);
+        output = tl.load("output.weight").transfer_to(backend);
+        for (size_t i = 0; i < hp.n_layer; i++) {
+            const Backend b = params.backend(i);
+            auto name = [&](const char *s) { return "layers." + std::to_string(i) + "." + s; };
+            Layer l;
+            l.attention_norm = tl.load(name("attention_norm.weight")).transfer_to(b);
+            l.wq = tl.load(name("attention.wq.weight")).transfer_to(b);
+            l.wk = tl.load(name("attention.wk.weight")).transfer_to(b);
+            l.wv = tl.load(name("attention.wv.weight")).transfer_to(b);
+            l.wo = tl.load(name("attention.wo.weight")).transfer_to(b);
+            l.ffn_norm = tl.load(name("ffn_norm.weight")).transfer_to(b);
+            l.w1 = tl.load(name("feed_forward.w1.weight")).transfer_to(b);
+            l.w2 = tl.load(name("feed_forward.w2.weight")).transfer_to(b);
+            l.w3 = tl.load(name("feed_forward.w3.weight")).transfer_to(b);
+            layers.push_back(l);
+        }
+        context = tl.finish();
+    }
+
+    InferenceSession *start_session(const InferenceSessionConfig &config) const {  // :133-141
+        return new InferenceSession(config, params, hyperparameters.n_layer, hyperparameters.n_embd,
+                                    hyperparameters.n_vocab);
+    }
+
+    // models/llama/src/lib.rs:144-368 — line numbers of the Rust builder are cited per step
+    void evaluate(InferenceSession &session, const std::vector<TokenId> &input_tokens, OutputRequest &output_request) {
+        const size_t input_len = input_tokens.size();
+        const size_t session_len = session.n_past;
+        const size_t ctx_size = params.context_size;
+        const size_t n_vocab = hyperparameters.n_vocab, n_embd = hyperparameters.n_embd, n_head = hyperparameters.n_head,
+                     n_head_kv = hyperparameters.n_head_kv, n_layer = hyperparameters.n_layer, n_rot = hyperparameters.n_rot;
+        const size_t n_embd_gqa = n_embd / (n_head / n_head_kv);
+
+        GraphOutputs outputs = session.compute(input_tokens, [&](BuildContext &builder) {
+            Context &ctx0 = *builder.ctx0;
+            const Tensor &embd = *builder.embd;
+            Tensor input_layer = ctx0.op_get_rows(wte, embd);  // :170
+            ComputationGraph gf = ctx0.create_compute_graph();  // :172
+            for (size_t il = 0; il < n_layer; il++) {
+                ctx0.set_offloading(params.should_offload(il));  // :175
+                Tensor input_self_attention = input_layer.share();
+                Tensor current;
+                ctx0.use_scratch(builder.get_scratch(0));  // :180
+                current = ctx0.op_rms_norm(input_layer);  // :183
+                current = ctx0.op_mul(current, layers[il].attention_norm);  // :186
+                const ggml::RoPEOverrides *overrides = params.has_rope_overrides ? &params.rope_overrides : nullptr;
+                Tensor q_current =  // :191-204
+                    ctx0.op_rope_inplace(ctx0.op_reshape_3d(ctx0.op_mul_mat(layers[il].wq, current), n_embd / n_head,
+                                                            n_head, input_len),
+                                         session_len, n_rot, 0, overrides)
+                        .set_name("Qcur");
+                Tensor k_current =  // :205-218
+                    ctx0.op_rope_inplace(ctx0.op_reshape_3d(ctx0.op_mul_mat(layers[il].wk, current), n_embd / n_head,
+                                                            n_head_kv, input_len),
+                                         session_len, n_rot, 0, overrides)
+                        .set_name("Kcur");
+                Tensor v_current = ctx0.op_transpose(  // :222-226
+                    ctx0.op_reshape_2d(ctx0.op_mul_mat(layers[il].wv, current), n_embd_gqa, input_len));
+                const size_t kes = builder.memory_k->element_size(), ves = builder.memory_v->element_size();
+                Tensor k = ctx0.op_view_1d(*builder.memory_k, input_len * n_embd_gqa,  // :228-232
+                                           (kes * n_embd_gqa) * (il * ctx_size + session_len));
+                Tensor v = ctx0.op_view_2d(*builder.memory_v, input_len, n_embd_gqa, ctx_size * ves,  // :234-240
+                                           (il * ctx_size) * ves * n_embd_gqa + session_len * ves);
+                gf.build_forward_expand(ctx0.op_cpy(k_current, k));  // :243
+                gf.build_forward_expand(ctx0.op_cpy(v_current, v));  // :244
+                Tensor q = ctx0.op_permute(q_current, 0, 2, 1, 3).set_name("Q");  // :246
+                Tensor kk = ctx0.op_permute(  // :248-262
+                                    ctx0.op_reshape_3d(ctx0.op_view_1d(*builder.memory_k,
+                                                                       (session_len + input_len) * n_embd_gqa,
+                                                                       il * ctx_size * kes * n_embd_gqa),
+                                                       n_embd / n_head, n_head_kv, session_len + input_len),
+                                    0, 2, 1, 3)
+                                .set_name("K");
+                Tensor k_q = ctx0.op_mul_mat(kk, q).set_name("KQ");  // :265
+                Tensor kq_scale =  // :268-270
+                    ctx0.new_f32(1.0f / std::sqrt((float)n_embd / (float)n_head)).set_name("1/sqrt(n_embd/n_head)");
+                Tensor k_q_scaled = ctx0.op_scale_inplace(k_q, kq_scale).set_name("KQ_scaled");  // :271
+                Tensor k_q_masked = ctx0.op_diag_mask_inf_inplace(k_q_scaled, session_len).set_name("KQ_masked");  // :274
+                Tensor k_q_soft_max = ctx0.op_soft_max_inplace(k_q_masked).set_name("KQ_soft_max");  // :279
+                Tensor vv = ctx0.op_view_3d(*builder.memory_v, session_len + input_len, n_embd / n_head, n_head_kv,  // :284-294
+                                            ctx_size * ves, ctx_size * ves * n_embd / n_head,
+                                            il * ctx_size * ves * n_embd_gqa)
+                                .set_name("V");
+                Tensor k_q_v = ctx0.op_mul_mat(vv, k_q_soft_max).set_name("KQV");  // :296
+                Tensor k_q_v_merged = ctx0.op_permute(k_q_v, 0, 2, 1, 3).set_name("KQV_merged");  // :299
+                current = ctx0.op_cpy(k_q_v_merged, ctx0.new_tensor_2d(GGML_TYPE_F32, n_embd, input_len))  // :302-307
+                              .set_name("KQV_merged_contiguous");
+                current = ctx0.op_mul_mat(layers[il].wo, current);  // :310
+                ctx0.use_scratch(builder.get_scratch(1));  // :312
+                Tensor input_feed_forward = ctx0.op_add(current, input_self_attention);  // :314
+                current = ctx0.op_rms_norm(input_feed_forward);  // :318
+                current = ctx0.op_mul(current, layers[il].ffn_norm);  // :321
+                Tensor tmp = ctx0.op_mul_mat(layers[il].w3, current);  // :323
+                current = ctx0.op_mul_mat(layers[il].w1, current);  // :325
+                current = ctx0.op_silu(current);  // :328
+                current = ctx0.op_mul(current, tmp);  // :330
+                current = ctx0.op_mul_mat(layers[il].w2, current);  // :332
+                current = ctx0.op_add(current, input_feed_forward);  // :334
+                input_layer = current;  // :337
+            }
+            ctx0.use_scratch(builder.get_scratch(0));  // :340
+            input_layer = ctx0.op_rms_norm(input_layer);  // :343
+            input_layer = ctx0.op_mul(input_layer, norm);  // :346
+            Tensor embedding_result = input_layer.share();
+            ctx0.set_offloading(false);  // :350
+            input_layer = ctx0.op_mul_mat(output, input_layer);  // :352 lm_head
+            ctx0.use_scratch(nullptr);  // :354
+            return std::make_pair(gf, GraphOutputs{input_layer, embedding_result});
+        });
+        // finish evaluation (:364-367)
+        common::read_last_token(session, outputs.result, n_vocab, input_len);
+        common::extract_logits(output_request, outputs.result, n_vocab, input_len);
+        common::extract_embeddings(output_request, outputs.embedding_result, n_embd, input_len);
+    }
+
+    Hyperparameters hyperparameters;
+    ModelParameters params;
+    Tensor wte, norm, output;
+    std::vector<Layer> layers;
+    std::shared_ptr<Context> context;  // must be kept alive for the model
+};
+
+}  // namespace llm
+
+// ---------------------------------------------------------------------------------------------------
+// C entry points
+// ---------------------------------------------------------------------------------------------------
+struct llm_model {
+    llm::Llama *llama;
+};
+struct llm_session {
+    llm::InferenceSession *s;
+};
+
+extern "C" {
+
+llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp, const llm_tensor_desc *tensors,
+                         int n_tensors) {
+    llm::Hyperparameters h;
+    h.n_vocab = hp->n_vocab;
+    h.n_embd = hp->n_embd;
+    h.n_mult = hp->n_mult;
+    h.n_head = hp->n_head;
+    h.n_head_kv = hp->n_head_kv > 0 ? hp->n_head_kv : hp->n_head;
+    h.n_layer = hp->n_layer;
+    h.n_rot = hp->n_rot;
+    h.file_type = hp->file_type;
+    llm::ModelParameters p;
+    p.context_size = mp->context_size > 0 ? mp->context_size : 2048;
+    p.use_gpu = mp->use_gpu != 0;
+    p.gpu_layers = mp->gpu_layers;
+    p.has_rope_overrides = mp->has_rope_overrides != 0;
+    p.rope_overrides.frequency_scale = mp->rope_frequency_scale;
+    p.rope_overrides.frequency_base = (size_t)mp->rope_frequency_base;
+    if (!p.use_gpu) {
+        fprintf(stderr, "llm_llama_new: use_gpu=0 requested, but libggml_hip has no CPU compute path\n");
+        abort();
+    }
+    llm::TensorLoader tl(tensors, n_tensors);
+    llm_model *m = new llm_model();
+    m->llama = new llm::Llama(h, p, std::move(tl));
+    return m;
+}
+void llm_model_free(llm_model *m) {
+    if (!m) return;
+    delete m->llama;
+    delete m;
+}
+llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
+    llm::InferenceSessionConfig c;
+    if (cfg) {
+        c.memory_k_type = (ggml_type)cfg->memory_k_type;
+        c.memory_v_type = (ggml_type)cfg->memory_v_type;
+        c.n_batch = cfg->n_batch > 0 ? (size_t)cfg->n_batch : 8;
+        c.n_threads = cfg->n_threads > 0 ? (size_t)cfg->n_threads : 8;
+    }
+    llm_session *s = new llm_session();
+    s->s = m->llama->start_session(c);
+    return s;
+}
+void llm_session_free(llm_session *s) {
+    if (!s) return;
+    delete s->s;
+    delete s;
+}
+void llm_evaluate(llm_model *m, llm_session *s, const int32_t *tokens, int n, float *all_logits, float *embeddings) {
+    std::vector<llm::TokenId> toks(tokens, tokens + n);
+    std::vector<float> logits, emb;
+    llm::OutputRequest req;
+    if (all_logits) req.all_logits = &logits;
+    if (embeddings) req.embeddings = &emb;
+    m->llama->evaluate(*s->s, toks, req);
+    if (all_logits) memcpy(all_logits, logits.data(), logits.size() * sizeof(float));
+    if (embeddings) memcpy(embeddings, emb.data(), emb.size() * sizeof(float));
+}
+void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *tokens, int n) {
+    // inference_session.rs:311-316: ContextFull check, then chunks(n_batch)
+    if (s->s->n_past + (size_t)n >= m->llama->params.context_size) {
+        fprintf(stderr, "llm_feed_prompt: InferenceError::ContextFull\n");
+        abort();
+    }
+    const size_t nb = s->s->config.n_batch;
+    llm::OutputRequest req;
+    for (size_t i = 0; i < (size_t)n; i += nb) {
+        const size_t len = std::min(nb, (size_t)n - i);
+        std::vector<llm::TokenId> batch(tokens + i, tokens + i + len);
+        m->llama->evaluate(*s->s, batch, req);
+        for (auto tk : batch) s->s->tokens.push_back(tk);
+    }
+}
+int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
+    // inference_session.rs:381-424 with the sampler chain replaced by argmax over last_logits
+    if (s->s->n_past + 1 >= m->llama->params.context_size) {
+        fprintf(stderr, "llm_infer_next_token: InferenceError::ContextFull\n");
+        abort();
+    }
+    const std::vector<float> &l = s->s->last_logits;
+    size_t best = 0;
+    for (size_t i = 1; i < l.size(); i++)
+        if (l[i] > l[best]) best = i;
+    const llm::TokenId next = (llm::TokenId)best;
+    s->s->tokens.push_back(next);
+    llm::OutputRequest req;
+    m->llama->evaluate(*s->s, std::vector<llm::TokenId>{next}, req);
+    return next;
+}
+int llm_session_rewind(llm_session *s, int num) {
+    if ((size_t)num >= s->s->n_past) return -1;  // RewindError::NotEnoughTokens
+    if ((size_t)num <= s->s->tokens.size()) s->s->tokens.resize(s->s->tokens.size() - (size_t)num);
+    s->s->n_past -= (size_t)num;
+    return 0;
+}
+const float *llm_session_last_logits(const llm_session *s) { return s->s->last_logits.data(); }
+int llm_session_n_past(const llm_session *s) { return (int)s->s->n_past; }
+int llm_model_n_vocab(const llm_model *m) { return (int)m->llama->hyperparameters.n_vocab; }
+void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_leafs) {
+    if (n_nodes) *n_nodes = s->s->last_n_nodes;
+    if (n_leafs) *n_leafs = s->s->last_n_leafs;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+/* llm_host.h — C entry points of the host-side mirror (llm_host.cpp) of the reference's
+ * crates/llm-base InferenceSession + crates/models/llama, so that tests and bench.py (Python, ctypes)
+ * can drive the SAME call sequence a Rust user of rustformers/llm drives:
+ *   llm::load → Model::start_session → InferenceSession::{feed_prompt, infer_next_token} → Model::evaluate.
+ * Not part of the ggml drop-in ABI (include/ggml_hip.h); exported from the same shared object. */
+#ifndef LLM_HOST_H
+#define LLM_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ggml_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* crates/models/llama/src/lib.rs:399-416 Hyperparameters (+ n_ff, which the reference derives from
+ * the w1 tensor shape in the file) */
+typedef struct {
+    int32_t n_vocab, n_embd, n_mult, n_head, n_head_kv, n_layer, n_rot, file_type;
+} llm_llama_hparams;
+
+/* crates/llm-base/src/model/mod.rs:196-229 ModelParameters (the fields that touch this path) */
+typedef struct {
+    int32_t context_size;   /* default 2048 */
+    int32_t use_gpu;        /* must be 1: this library has no CPU compute path */
+    int32_t gpu_layers;     /* -1 = all */
+    int32_t has_rope_overrides;
+    float rope_frequency_scale;
+    int32_t rope_frequency_base;
+    /* layer-split extension: this process owns layers [layer_begin, layer_end) */
+    int32_t layer_begin, layer_end; /* 0,-1 = all */
+} llm_model_params;
+
+/* crates/llm-base/src/inference_session.rs:799-841 InferenceSessionConfig */
+typedef struct {
+    int32_t memory_k_type; /* ggml_type: F16 (default) or F32 */
+    int32_t memory_v_type;
+    int32_t n_batch;   /* default 8 */
+    int32_t n_threads; /* default 8 (ignored by the device executor) */
+} llm_session_config;
+
+/* one tensor handed to the loader: the TensorLoader::load(name) contract of
+ * crates/llm-base/src/loader.rs:651-678 — name, type, dims ([in, out]) and a host pointer to the GGML
+ * bytes (an mmap'd file region or a caller-owned buffer that outlives the model). */
+typedef struct {
+    const char *name;
+    int32_t type; /* ggml_type */
+    int32_t n_dims;
+    int64_t ne[2];
+    void *data;
+} llm_tensor_desc;
+
+typedef struct llm_model llm_model;
+typedef struct llm_session llm_session;
+
+GGML_API llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *params,
+                                  const llm_tensor_desc *tensors, int n_tensors);
+GGML_API void llm_model_free(llm_model *m);
+GGML_API llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg);
+GGML_API void llm_session_free(llm_session *s);
+/* Model::evaluate (models/llama/src/lib.rs:144-368): feeds n tokens at the session's n_past.
+ * all_logits (nullable): n*n_vocab floats (OutputRequest.all_logits); embeddings (nullable): n_embd floats. */
+GGML_API void llm_evaluate(llm_model *m, llm_session *s, const int32_t *tokens, int n, float *all_logits,
+                           float *embeddings);
+/* InferenceSession::feed_prompt with Prompt::Tokens (inference_session.rs:299-349): chunks by n_batch */
+GGML_API void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *tokens, int n);
+/* InferenceSession::infer_next_token with a greedy (argmax) sampler; returns the sampled token id */
+GGML_API int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s);
+/* InferenceSession::rewind (inference_session.rs:352-378) */
+GGML_API int llm_session_rewind(llm_session *s, int num);
+GGML_API const float *llm_session_last_logits(const llm_session *s);
+GGML_API int llm_session_n_past(const llm_session *s);
+GGML_API int llm_model_n_vocab(const llm_model *m);
+/* graph statistics of the last evaluate (for tests): nodes, leafs */
+GGML_API void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_leafs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

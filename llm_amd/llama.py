@@ -1,0 +1,148 @@
+"""ctypes handle on the host mirror (llm_amd/csrc/host/llm_host.cpp): the call sequence of
+crates/llm-base (Model::start_session, InferenceSession::feed_prompt / infer_next_token,
+Model::evaluate) as a rustformers/llm user drives it."""
+import ctypes as C
+
+import numpy as np
+
+from . import ggml
+
+
+class _HP(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_vocab", "n_embd", "n_mult", "n_head", "n_head_kv", "n_layer", "n_rot", "file_type")]
+
+
+class _MP(C.Structure):
+    _fields_ = [("context_size", C.c_int32), ("use_gpu", C.c_int32), ("gpu_layers", C.c_int32),
+                ("has_rope_overrides", C.c_int32), ("rope_frequency_scale", C.c_float),
+                ("rope_frequency_base", C.c_int32), ("layer_begin", C.c_int32), ("layer_end", C.c_int32)]
+
+
+class _SC(C.Structure):
+    _fields_ = [("memory_k_type", C.c_int32), ("memory_v_type", C.c_int32), ("n_batch", C.c_int32),
+                ("n_threads", C.c_int32)]
+
+
+class _TD(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("n_dims", C.c_int32), ("ne", C.c_int64 * 2),
+                ("data", C.c_void_p)]
+
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = ggml.lib()
+    if not _bound:
+        L.llm_llama_new.restype = C.c_void_p
+        L.llm_llama_new.argtypes = [C.POINTER(_HP), C.POINTER(_MP), C.POINTER(_TD), C.c_int]
+        L.llm_model_free.argtypes = [C.c_void_p]
+        L.llm_start_session.restype = C.c_void_p
+        L.llm_start_session.argtypes = [C.c_void_p, C.POINTER(_SC)]
+        L.llm_session_free.argtypes = [C.c_void_p]
+        L.llm_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.llm_feed_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.llm_infer_next_token_greedy.restype = C.c_int32
+        L.llm_infer_next_token_greedy.argtypes = [C.c_void_p, C.c_void_p]
+        L.llm_session_rewind.restype = C.c_int
+        L.llm_session_rewind.argtypes = [C.c_void_p, C.c_int]
+        L.llm_session_last_logits.restype = C.POINTER(C.c_float)
+        L.llm_session_last_logits.argtypes = [C.c_void_p]
+        L.llm_session_n_past.restype = C.c_int
+        L.llm_session_n_past.argtypes = [C.c_void_p]
+        L.llm_session_last_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _bound = True
+    return L
+
+
+class Llama:
+    """models/llama Llama + ModelParameters{use_gpu: true}.  `weights`: {name: ndarray} as produced by
+    llm_amd.synth (raw GGML bytes for 2-D tensors) — must outlive the model (mmap semantics)."""
+
+    def __init__(self, hp, weights, context_size=2048, gpu_layers=-1, rope_overrides=None):
+        from .synth import tensor_shapes
+        self.hp = dict(hp)
+        self.weights = weights
+        L = _lib()
+        shapes = tensor_shapes(hp)
+        descs = (_TD * len(shapes))()
+        self._names = []
+        for i, (name, (ne0, ne1)) in enumerate(shapes.items()):
+            b = name.encode()
+            self._names.append(b)
+            descs[i].name = b
+            descs[i].type = ggml.TYPE_F32 if ne1 is None else hp["wtype"]
+            descs[i].n_dims = 1 if ne1 is None else 2
+            descs[i].ne[0] = ne0
+            descs[i].ne[1] = 1 if ne1 is None else ne1
+            arr = weights[name]
+            exp = ne0 * 4 if ne1 is None else ggml.row_bytes(hp["wtype"], ne0) * ne1
+            assert arr.nbytes == exp, (name, arr.nbytes, exp)
+            descs[i].data = arr.ctypes.data
+        h = _HP(hp["n_vocab"], hp["n_embd"], hp.get("n_mult", 256), hp["n_head"], hp["n_head_kv"], hp["n_layer"],
+                hp["n_rot"], 2 * 1000 + ggml.FTYPE_OF[hp["wtype"]])
+        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, 0, -1)
+        if rope_overrides:
+            mp.has_rope_overrides = 1
+            mp.rope_frequency_scale = rope_overrides["frequency_scale"]
+            mp.rope_frequency_base = rope_overrides["frequency_base"]
+        self.context_size = context_size
+        self.ptr = L.llm_llama_new(C.byref(h), C.byref(mp), descs, len(shapes))
+
+    def start_session(self, n_batch=8, kv_type=ggml.TYPE_F16):
+        return Session(self, n_batch, kv_type)
+
+    def free(self):
+        if self.ptr:
+            _lib().llm_model_free(self.ptr)
+            self.ptr = None
+
+
+class Session:
+    def __init__(self, model, n_batch, kv_type):
+        self.model = model
+        cfg = _SC(kv_type, kv_type, n_batch, 8)
+        self.ptr = _lib().llm_start_session(model.ptr, C.byref(cfg))
+
+    @property
+    def n_past(self):
+        return _lib().llm_session_n_past(self.ptr)
+
+    def evaluate(self, tokens, want_all_logits=True, want_embeddings=False):
+        """Model::evaluate: returns all logits [N, n_vocab] (OutputRequest.all_logits) if requested."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        V, E = self.model.hp["n_vocab"], self.model.hp["n_embd"]
+        logits = np.zeros((tokens.size, V), np.float32) if want_all_logits else None
+        emb = np.zeros(E, np.float32) if want_embeddings else None
+        _lib().llm_evaluate(self.model.ptr, self.ptr, tokens.ctypes.data, tokens.size,
+                            logits.ctypes.data if logits is not None else None,
+                            emb.ctypes.data if emb is not None else None)
+        if want_embeddings:
+            return logits, emb
+        return logits
+
+    def feed_prompt(self, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        _lib().llm_feed_prompt(self.model.ptr, self.ptr, tokens.ctypes.data, tokens.size)
+
+    def infer_next_token(self):
+        return int(_lib().llm_infer_next_token_greedy(self.model.ptr, self.ptr))
+
+    def rewind(self, num):
+        return _lib().llm_session_rewind(self.ptr, num)
+
+    def last_logits(self):
+        V = self.model.hp["n_vocab"]
+        return np.ctypeslib.as_array(_lib().llm_session_last_logits(self.ptr), shape=(V,)).copy()
+
+    def graph_stats(self):
+        a, b = C.c_int(0), C.c_int(0)
+        _lib().llm_session_last_graph_stats(self.ptr, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def free(self):
+        if self.ptr:
+            _lib().llm_session_free(self.ptr)
+            self.ptr = None

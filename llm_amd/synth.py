@@ -1,0 +1,80 @@
+"""Synthetic GGML-format LLaMA weights: N(0, 0.02²) f32 matrices quantized with the
+product's own ggml_quantize_q* (the function the reference's `llm quantize` calls,
+crates/llm-base/src/quantize.rs:363-379), norm weights 1 + N(0, 0.01²) kept f32 (1-D tensors are never
+quantized, quantize.rs:332-335).  Tensor names / dims follow crates/models/llama/src/lib.rs:52-91:
+2-D weights are [in_features (ne0), out_features (ne1)]."""
+import numpy as np
+
+from . import ggml
+
+LLAMA_7B = dict(n_vocab=32000, n_embd=4096, n_head=32, n_head_kv=32, n_layer=32, n_rot=128, n_ff=11008, n_mult=256)
+LLAMA_13B = dict(n_vocab=32000, n_embd=5120, n_head=40, n_head_kv=40, n_layer=40, n_rot=128, n_ff=13824, n_mult=256)
+LLAMA_65B = dict(n_vocab=32000, n_embd=8192, n_head=64, n_head_kv=64, n_layer=80, n_rot=128, n_ff=22016, n_mult=256)
+TINY = dict(n_vocab=256, n_embd=128, n_head=4, n_head_kv=4, n_layer=2, n_rot=32, n_ff=352, n_mult=32)
+
+
+def tensor_shapes(hp):
+    """name -> (ne0, ne1 or None)"""
+    E, F, V = hp["n_embd"], hp["n_ff"], hp["n_vocab"]
+    Egqa = E // (hp["n_head"] // hp["n_head_kv"])
+    s = {"tok_embeddings.weight": (E, V), "norm.weight": (E, None), "output.weight": (E, V)}
+    for i in range(hp["n_layer"]):
+        p = f"layers.{i}."
+        s[p + "attention_norm.weight"] = (E, None)
+        s[p + "attention.wq.weight"] = (E, E)
+        s[p + "attention.wk.weight"] = (E, Egqa)
+        s[p + "attention.wv.weight"] = (E, Egqa)
+        s[p + "attention.wo.weight"] = (E, E)
+        s[p + "ffn_norm.weight"] = (E, None)
+        s[p + "feed_forward.w1.weight"] = (E, F)
+        s[p + "feed_forward.w2.weight"] = (F, E)
+        s[p + "feed_forward.w3.weight"] = (E, F)
+    return s
+
+
+def _layer_of(name):
+    return int(name.split(".")[1]) if name.startswith("layers.") else -1
+
+
+def make_llama(hp, wtype, seed=1234, std=0.02):
+    """Returns (hp_with_wtype, {name: np.ndarray}) — 2-D weights as raw GGML bytes (uint8), norms f32.
+    Exact path: gaussian f32 -> ggml_quantize_q*.  Use for parity tests (small models)."""
+    out = {}
+    for name, (ne0, ne1) in tensor_shapes(hp).items():
+        rng = np.random.default_rng([seed, _layer_of(name) + 1, sum(map(ord, name))])
+        if ne1 is None:
+            out[name] = (1.0 + 0.01 * rng.standard_normal(ne0)).astype(np.float32)
+        else:
+            w = (std * rng.standard_normal((ne1, ne0))).astype(np.float32)
+            out[name] = ggml.quantize(wtype, w)
+    h = dict(hp)
+    h["wtype"] = wtype
+    return h, out
+
+
+def make_llama_fast(hp, wtype, seed=1234, d_scale=0.0043):
+    """Full-size synthetic weights for bench.py: writes random GGML blocks directly (uniform quants, f16
+    scales around `d_scale` so that dequantized weights have std ≈ 0.02) instead of quantizing 6.7e9
+    gaussians.  Same container format, same bytes-per-weight, valid for every block type."""
+    out = {}
+    bs, be = ggml.BLOCK_BYTES[wtype], ggml.BLOCK_ELEMS[wtype]
+    for name, (ne0, ne1) in tensor_shapes(hp).items():
+        rng = np.random.default_rng([seed, _layer_of(name) + 1, sum(map(ord, name))])
+        if ne1 is None:
+            out[name] = (1.0 + 0.01 * rng.standard_normal(ne0)).astype(np.float32)
+            continue
+        nblk = ne1 * (ne0 // be)
+        raw = rng.integers(0, 256, size=(nblk, bs), dtype=np.uint8)
+        # per-type scale so that dequantized std stays ≈ 0.02: q4 std≈4.6, q5 std≈9.2, q8 std≈74
+        sc = {ggml.TYPE_Q4_0: d_scale, ggml.TYPE_Q4_1: d_scale, ggml.TYPE_Q5_0: d_scale / 2,
+              ggml.TYPE_Q5_1: d_scale / 2, ggml.TYPE_Q8_0: d_scale / 16}[wtype]
+        d = (sc * (0.5 + rng.random(nblk))).astype(np.float16)
+        raw[:, 0:2] = d.view(np.uint8).reshape(nblk, 2)
+        if wtype in (ggml.TYPE_Q4_1, ggml.TYPE_Q5_1):  # min = -(levels/2)*d: centred blocks
+            lv = 7.5 if wtype == ggml.TYPE_Q4_1 else 15.5
+            m = (-lv * d.astype(np.float32)).astype(np.float16)
+            raw[:, 2:4] = m.view(np.uint8).reshape(nblk, 2)
+        out[name] = raw.reshape(-1)
+    h = dict(hp)
+    h["wtype"] = wtype
+    return h, out

@@ -1,0 +1,886 @@
+/*
+ * ggml_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the arithmetic that rustformers/llm's hot path executes below
+ * `ggml_graph_compute` (reference call site: crates/ggml/src/lib.rs:374-376) for the LLaMA graph
+ * built at crates/models/llama/src/lib.rs:166-362.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this file's shared object; the product library
+ * (llm_amd/csrc → libggml_hip.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED.  The arithmetic itself lives in the git submodule
+ * `crates/ggml/sys/llama-cpp` (ggerganov/llama.cpp: ggml.c, k_quants.c; .gitmodules:1-3;
+ * compiled by crates/ggml/sys/build.rs:12-17), which is EMPTY in /root/reference and whose pinned
+ * commit is unrecoverable (no .git; API surface dates it to 2023-07-29…2023-08-21, pre-GGUF,
+ * see SURVEY.md F1/F2).  The reference holds no golden vector, known-answer test or fixture for
+ * this path that works offline.  Every function below therefore restates the
+ * *published* upstream algorithm of that window from memory — the scalar `*_reference` /
+ * non-SIMD code paths — and is anchored on what IS in tree: type ids and block byte sizes
+ * (crates/ggml/sys/src/lib.rs:51-69; sizing rule crates/ggml/src/format/loader.rs:122-124), the
+ * vec_dot_type table shape (lib.rs:2900-2906), eps (sys/src/llama.rs:15), and the op wiring of
+ * the LLaMA graph.  Each function cites the reference call site it serves.
+ *
+ * Two modes for every matmul-bearing function:
+ *   mode 0 "exact": ggml CPU semantics — activations re-quantized to the weight type's
+ *           vec_dot_type (Q8_0 / Q8_1), integer block dot products, f32 accumulate across blocks;
+ *           F16 matmuls round src1 to f16; softmax / SiLU through f16 rounding (ggml's lookup
+ *           tables table_exp_f16 / table_silu_f16).
+ *   mode 1 "math":  dequantized weights × f32 activations, f64 accumulation, exact expf — the
+ *           yardstick that says how much of a difference is activation-quantization noise.
+ *
+ * Build: make -C oracle   (gcc -O3 -mavx2 -mfma -mf16c -fopenmp; flags of sys/build.rs:46-62)
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QK 32
+#define EXPORT __attribute__((visibility("default")))
+
+typedef uint16_t fp16_t;
+
+/* ---- fp16 <-> fp32: IEEE binary16, round-to-nearest-even (what F16C _cvtss_sh/_cvtsh_ss do,
+ * which is what ggml uses on the x86 hosts build.rs targets with -mf16c) ----------------------- */
+static inline float fp16_to_fp32(fp16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal: normalise */
+            int e = -1;
+            do {
+                man <<= 1;
+                e++;
+            } while ((man & 0x400u) == 0);
+            man &= 0x3FFu;
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static inline fp16_t fp32_to_fp16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t absx = x & 0x7FFFFFFFu;
+    if (absx >= 0x7F800000u) { /* inf / nan */
+        return (fp16_t)(sign | 0x7C00u | ((absx > 0x7F800000u) ? (0x200u | ((absx >> 13) & 0x3FFu)) : 0));
+    }
+    if (absx >= 0x477FF000u) { /* >= 65520 rounds to inf */
+        return (fp16_t)(sign | 0x7C00u);
+    }
+    if (absx < 0x33000001u) { /* <= 2^-25: rounds to zero (tie at exactly 2^-25 goes to even = 0) */
+        return (fp16_t)sign;
+    }
+    int32_t e = (int32_t)(absx >> 23) - 127;
+    uint32_t man = (absx & 0x7FFFFFu) | 0x800000u; /* 24-bit significand */
+    uint32_t shift;
+    uint32_t hexp;
+    if (e < -14) { /* subnormal half */
+        shift = (uint32_t)(13 + (-14 - e));
+        hexp = 0;
+    } else {
+        shift = 13;
+        hexp = (uint32_t)(e + 15);
+    }
+    uint32_t hman = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u);
+    const uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (hman & 1u))) hman++;
+    /* hman carries the implicit bit for normals: combine by addition so mantissa overflow bumps exp */
+    uint32_t out;
+    if (hexp == 0) {
+        out = hman; /* may carry into exp=1, which is correct */
+    } else {
+        out = ((hexp - 1) << 10) + hman; /* hman in [0x400,0x800] */
+    }
+    return (fp16_t)(sign | out);
+}
+
+EXPORT float orc_fp16_to_fp32(fp16_t h) { return fp16_to_fp32(h); }
+EXPORT fp16_t orc_fp32_to_fp16(float f) { return fp32_to_fp16(f); }
+EXPORT void orc_fp32_to_fp16_row(const float *x, fp16_t *y, int64_t n) {
+    for (int64_t i = 0; i < n; i++) y[i] = fp32_to_fp16(x[i]);
+}
+EXPORT void orc_fp16_to_fp32_row(const fp16_t *x, float *y, int64_t n) {
+    for (int64_t i = 0; i < n; i++) y[i] = fp16_to_fp32(x[i]);
+}
+
+/* ---- block formats (upstream ggml.c, restated; sizes cross-checked against the in-tree sizing
+ * rule bytes = type_size*n/blck_size and the LLaMA-7B Q4_0 file size) --------- */
+#pragma pack(push, 1)
+typedef struct { fp16_t d; uint8_t qs[16]; } block_q4_0;                       /* 18 B */
+typedef struct { fp16_t d; fp16_t m; uint8_t qs[16]; } block_q4_1;             /* 20 B */
+typedef struct { fp16_t d; uint8_t qh[4]; uint8_t qs[16]; } block_q5_0;        /* 22 B */
+typedef struct { fp16_t d; fp16_t m; uint8_t qh[4]; uint8_t qs[16]; } block_q5_1; /* 24 B */
+typedef struct { fp16_t d; int8_t qs[32]; } block_q8_0;                        /* 34 B */
+typedef struct { float d; float s; int8_t qs[32]; } block_q8_1;                /* 40 B */
+#pragma pack(pop)
+_Static_assert(sizeof(block_q4_0) == 18, "q4_0");
+_Static_assert(sizeof(block_q4_1) == 20, "q4_1");
+_Static_assert(sizeof(block_q5_0) == 22, "q5_0");
+_Static_assert(sizeof(block_q5_1) == 24, "q5_1");
+_Static_assert(sizeof(block_q8_0) == 34, "q8_0");
+_Static_assert(sizeof(block_q8_1) == 40, "q8_1");
+
+enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9 };
+
+EXPORT int orc_type_size(int type) {
+    switch (type) {
+        case T_F32: return 4;
+        case T_F16: return 2;
+        case T_Q4_0: return 18;
+        case T_Q4_1: return 20;
+        case T_Q5_0: return 22;
+        case T_Q5_1: return 24;
+        case T_Q8_0: return 34;
+        case T_Q8_1: return 40;
+    }
+    return 0;
+}
+EXPORT int orc_blck_size(int type) { return (type == T_F32 || type == T_F16) ? 1 : QK; }
+/* vec_dot_type column of ggml's type_traits table (shape visible at sys/src/lib.rs:2900-2906) */
+EXPORT int orc_vec_dot_type(int type) {
+    switch (type) {
+        case T_Q4_0: case T_Q5_0: case T_Q8_0: return T_Q8_0;
+        case T_Q4_1: case T_Q5_1: return T_Q8_1;
+        case T_F16: return T_F16;
+    }
+    return T_F32;
+}
+
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+
+/* quantize_row_q*_reference (upstream ggml.c).  Serves ggml_quantize_q* (sys/src/lib.rs:2779-2822,
+ * caller crates/llm-base/src/quantize.rs:363-379) and the activation re-quantization inside
+ * ggml_compute_forward_mul_mat. */
+static void quantize_row_q4_0(const float *x, block_q4_0 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float amax = 0.0f, max = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = x[i * QK + j];
+            if (amax < fabsf(v)) { amax = fabsf(v); max = v; }
+        }
+        const float d = max / -8;
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d);
+        for (int j = 0; j < QK / 2; ++j) {
+            const float x0 = x[i * QK + 0 + j] * id;
+            const float x1 = x[i * QK + QK / 2 + j] * id;
+            const uint8_t xi0 = MIN(15, (int8_t)(x0 + 8.5f));
+            const uint8_t xi1 = MIN(15, (int8_t)(x1 + 8.5f));
+            y[i].qs[j] = xi0 | (xi1 << 4);
+        }
+    }
+}
+static void quantize_row_q4_1(const float *x, block_q4_1 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float min = FLT_MAX, max = -FLT_MAX;
+        for (int j = 0; j < QK; j++) {
+            const float v = x[i * QK + j];
+            if (v < min) min = v;
+            if (v > max) max = v;
+        }
+        const float d = (max - min) / ((1 << 4) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d);
+        y[i].m = fp32_to_fp16(min);
+        for (int j = 0; j < QK / 2; ++j) {
+            const float x0 = (x[i * QK + 0 + j] - min) * id;
+            const float x1 = (x[i * QK + QK / 2 + j] - min) * id;
+            const uint8_t xi0 = MIN(15, (int8_t)(x0 + 0.5f));
+            const uint8_t xi1 = MIN(15, (int8_t)(x1 + 0.5f));
+            y[i].qs[j] = xi0 | (xi1 << 4);
+        }
+    }
+}
+static void quantize_row_q5_0(const float *x, block_q5_0 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float amax = 0.0f, max = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = x[i * QK + j];
+            if (amax < fabsf(v)) { amax = fabsf(v); max = v; }
+        }
+        const float d = max / -16;
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d);
+        uint32_t qh = 0;
+        for (int j = 0; j < QK / 2; ++j) {
+            const float x0 = x[i * QK + 0 + j] * id;
+            const float x1 = x[i * QK + QK / 2 + j] * id;
+            const uint8_t xi0 = MIN(31, (int8_t)(x0 + 16.5f));
+            const uint8_t xi1 = MIN(31, (int8_t)(x1 + 16.5f));
+            y[i].qs[j] = (xi0 & 0x0F) | ((xi1 & 0x0F) << 4);
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0);
+            qh |= ((xi1 & 0x10u) >> 4) << (j + QK / 2);
+        }
+        memcpy(&y[i].qh, &qh, sizeof(qh));
+    }
+}
+static void quantize_row_q5_1(const float *x, block_q5_1 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float min = FLT_MAX, max = -FLT_MAX;
+        for (int j = 0; j < QK; j++) {
+            const float v = x[i * QK + j];
+            if (v < min) min = v;
+            if (v > max) max = v;
+        }
+        const float d = (max - min) / ((1 << 5) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d);
+        y[i].m = fp32_to_fp16(min);
+        uint32_t qh = 0;
+        for (int j = 0; j < QK / 2; ++j) {
+            const float x0 = (x[i * QK + 0 + j] - min) * id;
+            const float x1 = (x[i * QK + QK / 2 + j] - min) * id;
+            const uint8_t xi0 = (uint8_t)(x0 + 0.5f);
+            const uint8_t xi1 = (uint8_t)(x1 + 0.5f);
+            y[i].qs[j] = (xi0 & 0x0F) | ((xi1 & 0x0F) << 4);
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0);
+            qh |= ((xi1 & 0x10u) >> 4) << (j + QK / 2);
+        }
+        memcpy(&y[i].qh, &qh, sizeof(qh));
+    }
+}
+static void quantize_row_q8_0(const float *x, block_q8_0 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = x[i * QK + j];
+            amax = amax > fabsf(v) ? amax : fabsf(v);
+        }
+        const float d = amax / ((1 << 7) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d);
+        for (int j = 0; j < QK; ++j) {
+            const float x0 = x[i * QK + j] * id;
+            y[i].qs[j] = (int8_t)roundf(x0);
+        }
+    }
+}
+static void quantize_row_q8_1(const float *x, block_q8_1 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = x[i * QK + j];
+            amax = amax > fabsf(v) ? amax : fabsf(v);
+        }
+        const float d = amax / ((1 << 7) - 1);
+        const float id = d ? 1.0f / d : 0.0f;
+        y[i].d = d;
+        int sum = 0;
+        for (int j = 0; j < QK / 2; ++j) {
+            const float v0 = x[i * QK + j] * id;
+            const float v1 = x[i * QK + QK / 2 + j] * id;
+            y[i].qs[j] = (int8_t)roundf(v0);
+            y[i].qs[QK / 2 + j] = (int8_t)roundf(v1);
+            sum += y[i].qs[j];
+            sum += y[i].qs[QK / 2 + j];
+        }
+        y[i].s = sum * d;
+    }
+}
+
+EXPORT void orc_quantize_row(int type, const float *x, void *y, int k) {
+    switch (type) {
+        case T_Q4_0: quantize_row_q4_0(x, (block_q4_0 *)y, k); break;
+        case T_Q4_1: quantize_row_q4_1(x, (block_q4_1 *)y, k); break;
+        case T_Q5_0: quantize_row_q5_0(x, (block_q5_0 *)y, k); break;
+        case T_Q5_1: quantize_row_q5_1(x, (block_q5_1 *)y, k); break;
+        case T_Q8_0: quantize_row_q8_0(x, (block_q8_0 *)y, k); break;
+        case T_Q8_1: quantize_row_q8_1(x, (block_q8_1 *)y, k); break;
+        case T_F16: orc_fp32_to_fp16_row(x, (fp16_t *)y, k); break;
+        case T_F32: memcpy(y, x, (size_t)k * 4); break;
+        default: fprintf(stderr, "orc_quantize_row: bad type %d\n", type); abort();
+    }
+}
+
+/* dequantize_row_q* (upstream ggml.c).  Serves get_rows (models/llama/src/lib.rs:170) and the
+ * "math" yardstick. */
+EXPORT void orc_dequantize_row(int type, const void *vx, float *y, int k) {
+    const int nb = k / QK;
+    switch (type) {
+        case T_Q4_0: {
+            const block_q4_0 *x = (const block_q4_0 *)vx;
+            for (int i = 0; i < nb; i++) {
+                const float d = fp16_to_fp32(x[i].d);
+                for (int j = 0; j < QK / 2; ++j) {
+                    const int x0 = (x[i].qs[j] & 0x0F) - 8;
+                    const int x1 = (x[i].qs[j] >> 4) - 8;
+                    y[i * QK + j + 0] = x0 * d;
+                    y[i * QK + j + QK / 2] = x1 * d;
+                }
+            }
+        } break;
+        case T_Q4_1: {
+            const block_q4_1 *x = (const block_q4_1 *)vx;
+            for (int i = 0; i < nb; i++) {
+                const float d = fp16_to_fp32(x[i].d);
+                const float m = fp16_to_fp32(x[i].m);
+                for (int j = 0; j < QK / 2; ++j) {
+                    const int x0 = (x[i].qs[j] & 0x0F);
+                    const int x1 = (x[i].qs[j] >> 4);
+                    y[i * QK + j + 0] = x0 * d + m;
+                    y[i * QK + j + QK / 2] = x1 * d + m;
+                }
+            }
+        } break;
+        case T_Q5_0: {
+            const block_q5_0 *x = (const block_q5_0 *)vx;
+            for (int i = 0; i < nb; i++) {
+                const float d = fp16_to_fp32(x[i].d);
+                uint32_t qh;
+                memcpy(&qh, x[i].qh, sizeof(qh));
+                for (int j = 0; j < QK / 2; ++j) {
+                    const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10;
+                    const uint8_t xh_1 = ((qh >> (j + 12))) & 0x10;
+                    const int32_t x0 = ((x[i].qs[j] & 0x0F) | xh_0) - 16;
+                    const int32_t x1 = ((x[i].qs[j] >> 4) | xh_1) - 16;
+                    y[i * QK + j + 0] = x0 * d;
+                    y[i * QK + j + QK / 2] = x1 * d;
+                }
+            }
+        } break;
+        case T_Q5_1: {
+            const block_q5_1 *x = (const block_q5_1 *)vx;
+            for (int i = 0; i < nb; i++) {
+                const float d = fp16_to_fp32(x[i].d);
+                const float m = fp16_to_fp32(x[i].m);
+                uint32_t qh;
+                memcpy(&qh, x[i].qh, sizeof(qh));
+                for (int j = 0; j < QK / 2; ++j) {
+                    const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10;
+                    const uint8_t xh_1 = ((qh >> (j + 12))) & 0x10;
+                    const int x0 = (x[i].qs[j] & 0x0F) | xh_0;
+                    const int x1 = (x[i].qs[j] >> 4) | xh_1;
+                    y[i * QK + j + 0] = x0 * d + m;
+                    y[i * QK + j + QK / 2] = x1 * d + m;
+                }
+            }
+        } break;
+        case T_Q8_0: {
+            const block_q8_0 *x = (const block_q8_0 *)vx;
+            for (int i = 0; i < nb; i++) {
+                const float d = fp16_to_fp32(x[i].d);
+                for (int j = 0; j < QK; ++j) y[i * QK + j] = x[i].qs[j] * d;
+            }
+        } break;
+        case T_F16: orc_fp16_to_fp32_row((const fp16_t *)vx, y, k); break;
+        case T_F32: memcpy(y, vx, (size_t)k * 4); break;
+        default: fprintf(stderr, "orc_dequantize_row: bad type %d\n", type); abort();
+    }
+}
+
+/* ggml_quantize_q*(src, dst, n, k, hist) — sys/src/lib.rs:2779-2822.  n elements total in rows of k. */
+EXPORT size_t orc_quantize(int type, const float *src, void *dst, int n, int k, int64_t *hist) {
+    const int nb = k / QK;
+    const size_t bs = (size_t)orc_type_size(type);
+    for (int b = 0; b < n; b += k) {
+        uint8_t *y = (uint8_t *)dst + (size_t)(b / QK) * bs;
+        orc_quantize_row(type, src + b, y, k);
+        if (!hist) continue;
+        for (int i = 0; i < nb; i++) {
+            const uint8_t *blk = y + (size_t)i * bs;
+            switch (type) {
+                case T_Q4_0:
+                case T_Q4_1: {
+                    const uint8_t *qs = blk + (type == T_Q4_0 ? 2 : 4);
+                    for (int j = 0; j < QK; j += 2) {
+                        hist[qs[j / 2] & 0xF]++;
+                        hist[qs[j / 2] >> 4]++;
+                    }
+                } break;
+                case T_Q5_0:
+                case T_Q5_1: {
+                    const uint8_t *qhp = blk + (type == T_Q5_0 ? 2 : 4);
+                    const uint8_t *qs = qhp + 4;
+                    uint32_t qh;
+                    memcpy(&qh, qhp, 4);
+                    for (int j = 0; j < QK; j += 2) {
+                        const uint8_t vh0 = ((qh & (1u << (j + 0))) >> (j + 0)) << 4;
+                        const uint8_t vh1 = ((qh & (1u << (j + 16))) >> (j + 12));
+                        /* cast to 16 bins */
+                        const uint8_t vi0 = ((qs[j / 2] & 0x0F) | vh0) / 2;
+                        const uint8_t vi1 = ((qs[j / 2] >> 4) | vh1) / 2;
+                        hist[vi0]++;
+                        hist[vi1]++;
+                    }
+                } break;
+                case T_Q8_0: {
+                    const int8_t *qs = (const int8_t *)(blk + 2);
+                    for (int j = 0; j < QK; ++j) hist[qs[j] / 16 + 8]++;
+                } break;
+            }
+        }
+    }
+    return (size_t)(n / QK) * bs;
+}
+
+/* ---- vec_dot (upstream ggml_vec_dot_q*_q8_*, scalar branch).  The heart of
+ * ggml_compute_forward_mul_mat for quantized src0. ------------------------- */
+static float vec_dot_q4_0_q8_0(int n, const block_q4_0 *x, const block_q8_0 *y) {
+    const int nb = n / QK;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        int sumi = 0;
+        for (int j = 0; j < QK / 2; ++j) {
+            const int v0 = (x[i].qs[j] & 0x0F) - 8;
+            const int v1 = (x[i].qs[j] >> 4) - 8;
+            sumi += (v0 * y[i].qs[j]) + (v1 * y[i].qs[j + QK / 2]);
+        }
+        sumf += sumi * fp16_to_fp32(x[i].d) * fp16_to_fp32(y[i].d);
+    }
+    return sumf;
+}
+static float vec_dot_q4_1_q8_1(int n, const block_q4_1 *x, const block_q8_1 *y) {
+    const int nb = n / QK;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        int sumi = 0;
+        for (int j = 0; j < QK / 2; ++j) {
+            const int v0 = (x[i].qs[j] & 0x0F);
+            const int v1 = (x[i].qs[j] >> 4);
+            sumi += (v0 * y[i].qs[j]) + (v1 * y[i].qs[j + QK / 2]);
+        }
+        sumf += (fp16_to_fp32(x[i].d) * y[i].d) * sumi + fp16_to_fp32(x[i].m) * y[i].s;
+    }
+    return sumf;
+}
+static float vec_dot_q5_0_q8_0(int n, const block_q5_0 *x, const block_q8_0 *y) {
+    const int nb = n / QK;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        uint32_t qh;
+        memcpy(&qh, x[i].qh, sizeof(qh));
+        int sumi = 0;
+        for (int j = 0; j < QK / 2; ++j) {
+            const uint8_t xh_0 = ((qh & (1u << (j + 0))) >> (j + 0)) << 4;
+            const uint8_t xh_1 = ((qh & (1u << (j + 16))) >> (j + 12));
+            const int32_t x0 = ((x[i].qs[j] & 0x0F) | xh_0) - 16;
+            const int32_t x1 = ((x[i].qs[j] >> 4) | xh_1) - 16;
+            sumi += (x0 * y[i].qs[j]) + (x1 * y[i].qs[j + QK / 2]);
+        }
+        sumf += (fp16_to_fp32(x[i].d) * fp16_to_fp32(y[i].d)) * sumi;
+    }
+    return sumf;
+}
+static float vec_dot_q5_1_q8_1(int n, const block_q5_1 *x, const block_q8_1 *y) {
+    const int nb = n / QK;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        uint32_t qh;
+        memcpy(&qh, x[i].qh, sizeof(qh));
+        int sumi = 0;
+        for (int j = 0; j < QK / 2; ++j) {
+            const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10;
+            const uint8_t xh_1 = ((qh >> (j + 12))) & 0x10;
+            const int32_t x0 = (x[i].qs[j] & 0xF) | xh_0;
+            const int32_t x1 = (x[i].qs[j] >> 4) | xh_1;
+            sumi += (x0 * y[i].qs[j]) + (x1 * y[i].qs[j + QK / 2]);
+        }
+        sumf += (fp16_to_fp32(x[i].d) * y[i].d) * sumi + fp16_to_fp32(x[i].m) * y[i].s;
+    }
+    return sumf;
+}
+static float vec_dot_q8_0_q8_0(int n, const block_q8_0 *x, const block_q8_0 *y) {
+    const int nb = n / QK;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        int sumi = 0;
+        for (int j = 0; j < QK; j++) sumi += x[i].qs[j] * y[i].qs[j];
+        sumf += sumi * (fp16_to_fp32(x[i].d) * fp16_to_fp32(y[i].d));
+    }
+    return sumf;
+}
+EXPORT float orc_vec_dot(int type, int n, const void *x, const void *y) {
+    switch (type) {
+        case T_Q4_0: return vec_dot_q4_0_q8_0(n, (const block_q4_0 *)x, (const block_q8_0 *)y);
+        case T_Q4_1: return vec_dot_q4_1_q8_1(n, (const block_q4_1 *)x, (const block_q8_1 *)y);
+        case T_Q5_0: return vec_dot_q5_0_q8_0(n, (const block_q5_0 *)x, (const block_q8_0 *)y);
+        case T_Q5_1: return vec_dot_q5_1_q8_1(n, (const block_q5_1 *)x, (const block_q8_1 *)y);
+        case T_Q8_0: return vec_dot_q8_0_q8_0(n, (const block_q8_0 *)x, (const block_q8_0 *)y);
+    }
+    fprintf(stderr, "orc_vec_dot: bad type %d\n", type);
+    abort();
+}
+
+/* ---- mul_mat: dst[n][m] = sum_k A[m][k] * B[n][k]   (crates/ggml/src/context.rs:314-324 doc;
+ * call sites models/llama/src/lib.rs:194,208,223,310,323,325,332,352).
+ * A: M rows of K (type), contiguous rows.  B: N rows of K f32 (row stride ldb floats).
+ * dst: N rows of M f32. -------------------------------------------------------------------------- */
+EXPORT void orc_mul_mat(int type, const void *A, int64_t M, int64_t K, const float *B, int64_t N, int64_t ldb,
+                        float *dst, int mode) {
+    const size_t row_bytes = (size_t)(K / orc_blck_size(type)) * (size_t)orc_type_size(type);
+    if (mode == 0 && type != T_F32) {
+        const int vdt = orc_vec_dot_type(type);
+        const size_t qrow = (size_t)(K / orc_blck_size(vdt)) * (size_t)orc_type_size(vdt);
+        uint8_t *wdata = (uint8_t *)malloc(qrow * (size_t)N); /* ggml: cplan.work_data, INIT phase */
+        for (int64_t n = 0; n < N; n++) orc_quantize_row(vdt, B + n * ldb, wdata + (size_t)n * qrow, (int)K);
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; m++) {
+            const uint8_t *a = (const uint8_t *)A + (size_t)m * row_bytes;
+            for (int64_t n = 0; n < N; n++) {
+                const uint8_t *b = wdata + (size_t)n * qrow;
+                float r;
+                if (type == T_F16) {
+                    /* ggml_vec_dot_f16, scalar branch: f32 products, ggml_float (double) sum */
+                    const fp16_t *x = (const fp16_t *)a, *y = (const fp16_t *)b;
+                    double s = 0.0;
+                    for (int64_t k = 0; k < K; k++) s += (double)(fp16_to_fp32(x[k]) * fp16_to_fp32(y[k]));
+                    r = (float)s;
+                } else {
+                    r = orc_vec_dot(type, (int)K, a, b);
+                }
+                dst[n * M + m] = r;
+            }
+        }
+        free(wdata);
+        return;
+    }
+    /* math mode (and f32 weights): dequantize the row, accumulate in f64 */
+#pragma omp parallel
+    {
+        float *arow = (float *)malloc((size_t)K * 4);
+#pragma omp for schedule(static)
+        for (int64_t m = 0; m < M; m++) {
+            orc_dequantize_row(type, (const uint8_t *)A + (size_t)m * row_bytes, arow, (int)K);
+            for (int64_t n = 0; n < N; n++) {
+                const float *b = B + n * ldb;
+                double s = 0.0;
+                for (int64_t k = 0; k < K; k++) s += (double)arow[k] * (double)b[k];
+                dst[n * M + m] = (float)s;
+            }
+        }
+        free(arow);
+    }
+}
+
+/* ---- small ops -------------------------------------------------------------------------------- */
+/* ggml_compute_forward_rms_norm_f32 (upstream): models/llama/src/lib.rs:183,318,343; eps from
+ * crates/ggml/src/lib.rs:131-132.  x,y: nrows rows of ne0 floats. */
+EXPORT void orc_rms_norm(const float *x, float *y, int64_t ne0, int64_t nrows, float eps) {
+    for (int64_t r = 0; r < nrows; r++) {
+        const float *xr = x + r * ne0;
+        float *yr = y + r * ne0;
+        double sum = 0.0;
+        for (int64_t i = 0; i < ne0; i++) sum += (double)(xr[i] * xr[i]);
+        const float mean = (float)(sum / (double)ne0);
+        const float scale = 1.0f / sqrtf(mean + eps);
+        for (int64_t i = 0; i < ne0; i++) yr[i] = xr[i] * scale;
+    }
+}
+/* ggml_mul with src1 broadcast along rows (models/llama/src/lib.rs:186,321,346) */
+EXPORT void orc_mul_rows(const float *x, const float *w, float *y, int64_t ne0, int64_t nrows) {
+    for (int64_t r = 0; r < nrows; r++)
+        for (int64_t i = 0; i < ne0; i++) y[r * ne0 + i] = x[r * ne0 + i] * w[i];
+}
+EXPORT void orc_add(const float *a, const float *b, float *y, int64_t n) {
+    for (int64_t i = 0; i < n; i++) y[i] = a[i] + b[i];
+}
+EXPORT void orc_mul(const float *a, const float *b, float *y, int64_t n) {
+    for (int64_t i = 0; i < n; i++) y[i] = a[i] * b[i];
+}
+/* ggml_vec_silu_f32 with GGML_SILU_FP16 (upstream default): silu through the f16 table,
+ * table_silu_f16[i] = f16(silu_f32(f32(i))), silu_f32(x) = x/(1+expf(-x)).  models/llama:328 */
+EXPORT void orc_silu(const float *x, float *y, int64_t n, int mode) {
+    for (int64_t i = 0; i < n; i++) {
+        if (mode == 0) {
+            const float xf = fp16_to_fp32(fp32_to_fp16(x[i]));
+            y[i] = fp16_to_fp32(fp32_to_fp16(xf / (1.0f + expf(-xf))));
+        } else {
+            y[i] = (float)((double)x[i] / (1.0 + exp(-(double)x[i])));
+        }
+    }
+}
+/* ggml_compute_forward_gelu_f32 with GGML_GELU_FP16 (upstream default): table_gelu_f16, tanh form.
+ * Used only by the GPT-2 plumbing config (models/gpt2/src/lib.rs). */
+static inline float gelu_f32(float x) {
+    const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(SQRT_2_OVER_PI * x * (1.0f + GELU_COEF_A * x * x)));
+}
+EXPORT void orc_gelu(const float *x, float *y, int64_t n, int mode) {
+    for (int64_t i = 0; i < n; i++) {
+        if (mode == 0) {
+            const float xf = fp16_to_fp32(fp32_to_fp16(x[i]));
+            y[i] = fp16_to_fp32(fp32_to_fp16(gelu_f32(xf)));
+        } else {
+            y[i] = gelu_f32(x[i]);
+        }
+    }
+}
+/* ggml_compute_forward_norm_f32 (LayerNorm without affine; eps 1e-5 hard-coded upstream in that
+ * window).  GPT-2 plumbing only. */
+EXPORT void orc_norm(const float *x, float *y, int64_t ne0, int64_t nrows) {
+    const float eps = 1e-5f;
+    for (int64_t r = 0; r < nrows; r++) {
+        const float *xr = x + r * ne0;
+        float *yr = y + r * ne0;
+        double sum = 0.0;
+        for (int64_t i = 0; i < ne0; i++) sum += (double)xr[i];
+        const float mean = (float)(sum / (double)ne0);
+        double sum2 = 0.0;
+        for (int64_t i = 0; i < ne0; i++) {
+            const float v = xr[i] - mean;
+            yr[i] = v;
+            sum2 += (double)(v * v);
+        }
+        const float variance = (float)(sum2 / (double)ne0);
+        const float scale = 1.0f / sqrtf(variance + eps);
+        for (int64_t i = 0; i < ne0; i++) yr[i] *= scale;
+    }
+}
+/* ggml_compute_forward_rope_f32, mode 0 (adjacent pairs), upstream window: theta is an iterated f32
+ * product over the WHOLE row (ne0), n_dims only sets theta_scale.  x: [ne0, n_head, N] contiguous,
+ * in place.  models/llama/src/lib.rs:191-218; builder crates/ggml/src/context.rs:557-590. */
+EXPORT void orc_rope(float *x, int64_t ne0, int64_t n_head, int64_t N, int n_past, int n_dims, float freq_base,
+                     float freq_scale) {
+    const float theta_scale = powf(freq_base, -2.0f / n_dims);
+    for (int64_t i2 = 0; i2 < N; i2++) {
+        const int64_t p = n_past + i2;
+        for (int64_t i1 = 0; i1 < n_head; i1++) {
+            float theta = freq_scale * (float)p;
+            float *row = x + (i2 * n_head + i1) * ne0;
+            for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
+                const float cos_theta = cosf(theta);
+                const float sin_theta = sinf(theta);
+                theta *= theta_scale;
+                const float x0 = row[i0], x1 = row[i0 + 1];
+                row[i0] = x0 * cos_theta - x1 * sin_theta;
+                row[i0 + 1] = x0 * sin_theta + x1 * cos_theta;
+            }
+        }
+    }
+}
+/* scale → diag_mask_inf(n_past) → soft_max on rows (models/llama/src/lib.rs:268-281).
+ * x: [nc, nr_per_head(N), n_head]; row j of a head masks columns i > n_past + j.
+ * soft_max (upstream): max; exp through table_exp_f16 on f16(x-max); ggml_float sum; scale by 1/sum. */
+EXPORT void orc_scale_mask_softmax(float *x, int64_t nc, int64_t N, int64_t n_head, float scale, int n_past,
+                                   int mode) {
+    for (int64_t h = 0; h < n_head; h++) {
+        for (int64_t j = 0; j < N; j++) {
+            float *row = x + (h * N + j) * nc;
+            for (int64_t i = 0; i < nc; i++) {
+                row[i] = row[i] * scale;
+                if (i > n_past + j) row[i] = -INFINITY;
+            }
+            float max = -INFINITY;
+            for (int64_t i = 0; i < nc; i++) max = row[i] > max ? row[i] : max;
+            double sum = 0.0;
+            for (int64_t i = 0; i < nc; i++) {
+                if (row[i] == -INFINITY) {
+                    row[i] = 0.0f;
+                } else if (mode == 0) {
+                    const fp16_t s = fp32_to_fp16(row[i] - max);
+                    const float val = fp16_to_fp32(fp32_to_fp16(expf(fp16_to_fp32(s))));
+                    sum += (double)val;
+                    row[i] = val;
+                } else {
+                    const float val = (float)exp((double)row[i] - (double)max);
+                    sum += (double)val;
+                    row[i] = val;
+                }
+            }
+            sum = 1.0 / sum;
+            for (int64_t i = 0; i < nc; i++) row[i] *= (float)sum;
+        }
+    }
+}
+/* soft_max alone (rows of nc) */
+EXPORT void orc_soft_max(float *x, int64_t nc, int64_t nrows, int mode) {
+    for (int64_t r = 0; r < nrows; r++) {
+        float *row = x + r * nc;
+        float max = -INFINITY;
+        for (int64_t i = 0; i < nc; i++) max = row[i] > max ? row[i] : max;
+        double sum = 0.0;
+        for (int64_t i = 0; i < nc; i++) {
+            if (row[i] == -INFINITY) {
+                row[i] = 0.0f;
+            } else if (mode == 0) {
+                const fp16_t s = fp32_to_fp16(row[i] - max);
+                const float val = fp16_to_fp32(fp32_to_fp16(expf(fp16_to_fp32(s))));
+                sum += (double)val;
+                row[i] = val;
+            } else {
+                const float val = (float)exp((double)row[i] - (double)max);
+                sum += (double)val;
+                row[i] = val;
+            }
+        }
+        sum = 1.0 / sum;
+        for (int64_t i = 0; i < nc; i++) row[i] *= (float)sum;
+    }
+}
+
+/* ---- whole LLaMA forward, node for node as crates/models/llama/src/lib.rs:166-362 ------------- */
+typedef struct {
+    int32_t n_vocab, n_embd, n_head, n_head_kv, n_layer, n_rot, n_ff, n_ctx;
+    int32_t wtype;       /* ggml type of the 2-D weights */
+    float rms_eps;       /* LLAMA_DEFAULT_RMS_EPS */
+    float freq_base, freq_scale;
+    const void *tok_embeddings; /* [n_embd, n_vocab] wtype */
+    const float *norm;          /* [n_embd] f32 */
+    const void *output;         /* [n_embd, n_vocab] wtype */
+    /* per layer arrays of pointers */
+    const float **attention_norm;
+    const void **wq, **wk, **wv, **wo;
+    const float **ffn_norm;
+    const void **w1, **w2, **w3;
+    /* session state: f16 KV, layouts of inference_session.rs:155-160 + llama lib.rs:228-244:
+     * K element (layer il, pos p, chan c) at (il*n_ctx + p)*E_gqa + c ;
+     * V element (layer il, chan c, pos p) at il*n_ctx*E_gqa + c*n_ctx + p  (transposed) */
+    fp16_t *memory_k, *memory_v;
+} orc_llama;
+
+/* Optional taps on interior nodes for tensor-by-tensor parity tests. */
+typedef struct {
+    float *inpL0;       /* get_rows output [E,N] */
+    float *layer0_attn_norm; /* after rms_norm*weight, layer 0 [E,N] */
+    float *layer0_q;    /* Qcur after rope, layer 0 [D,H,N] */
+    float *layer0_kq;   /* KQ_soft_max, layer 0 [P+N, N, H] */
+    float *layer0_out;  /* layer 0 output residual [E,N] */
+    float *final_norm;  /* embedding_result [E,N] */
+} orc_taps;
+
+EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int n_past, float *logits /* [V,N] */,
+                           int mode, const orc_taps *taps) {
+    const int64_t E = m->n_embd, H = m->n_head, Hkv = m->n_head_kv, D = E / H, L = m->n_layer, F = m->n_ff;
+    const int64_t V = m->n_vocab, C = m->n_ctx, Egqa = E / (H / Hkv), P = n_past, T = P + N;
+    const size_t erow = (size_t)(E / orc_blck_size(m->wtype)) * (size_t)orc_type_size(m->wtype);
+
+    float *inpL = (float *)malloc((size_t)E * N * 4);
+    float *cur = (float *)malloc((size_t)E * N * 4);
+    float *q = (float *)malloc((size_t)E * N * 4);
+    float *k = (float *)malloc((size_t)Egqa * N * 4);
+    float *v = (float *)malloc((size_t)Egqa * N * 4);
+    float *kq = (float *)malloc((size_t)T * N * H * 4);
+    float *kqv = (float *)malloc((size_t)E * N * 4);
+    float *att = (float *)malloc((size_t)E * N * 4);
+    float *inpFF = (float *)malloc((size_t)E * N * 4);
+    float *t1 = (float *)malloc((size_t)F * N * 4);
+    float *t3 = (float *)malloc((size_t)F * N * 4);
+
+    /* get_rows(wte, embd): dequantize_row (llama lib.rs:170) */
+    for (int n = 0; n < N; n++)
+        orc_dequantize_row(m->wtype, (const uint8_t *)m->tok_embeddings + (size_t)tokens[n] * erow, inpL + (size_t)n * E,
+                           (int)E);
+    if (taps && taps->inpL0) memcpy(taps->inpL0, inpL, (size_t)E * N * 4);
+
+    for (int64_t il = 0; il < L; il++) {
+        /* attention norm (:183-186) */
+        orc_rms_norm(inpL, cur, E, N, m->rms_eps);
+        orc_mul_rows(cur, m->attention_norm[il], cur, E, N);
+        if (il == 0 && taps && taps->layer0_attn_norm) memcpy(taps->layer0_attn_norm, cur, (size_t)E * N * 4);
+        /* Q, K (+RoPE), V (:191-226) */
+        orc_mul_mat(m->wtype, m->wq[il], E, E, cur, N, E, q, mode);
+        orc_rope(q, D, H, N, n_past, m->n_rot, m->freq_base, m->freq_scale);
+        orc_mul_mat(m->wtype, m->wk[il], Egqa, E, cur, N, E, k, mode);
+        orc_rope(k, D, Hkv, N, n_past, m->n_rot, m->freq_base, m->freq_scale);
+        orc_mul_mat(m->wtype, m->wv[il], Egqa, E, cur, N, E, v, mode);
+        if (il == 0 && taps && taps->layer0_q) memcpy(taps->layer0_q, q, (size_t)E * N * 4);
+        /* KV store: CPY f32 -> f16 (:228-244); V scatter-transposed */
+        for (int n = 0; n < N; n++) {
+            for (int64_t c = 0; c < Egqa; c++) {
+                m->memory_k[((size_t)il * C + P + n) * Egqa + c] = fp32_to_fp16(k[(size_t)n * Egqa + c]);
+                m->memory_v[(size_t)il * C * Egqa + (size_t)c * C + (P + n)] = fp32_to_fp16(v[(size_t)n * Egqa + c]);
+            }
+        }
+        /* KQ = mul_mat(K f16 [D,T,Hkv], Q f32 [D,N,H]) -> [T,N,H] (:246-265) */
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int64_t h = 0; h < H; h++) {
+            for (int64_t n = 0; n < N; n++) {
+                const int64_t hk = h / (H / Hkv);
+                const float *qrow = q + ((size_t)n * H + h) * D;
+                float qh[512]; /* D <= 512 */
+                for (int64_t d = 0; d < D; d++) qh[d] = mode == 0 ? fp16_to_fp32(fp32_to_fp16(qrow[d])) : qrow[d];
+                for (int64_t t = 0; t < T; t++) {
+                    const fp16_t *krow = m->memory_k + ((size_t)il * C + t) * Egqa + hk * D;
+                    double s = 0.0;
+                    if (mode == 0) {
+                        for (int64_t d = 0; d < D; d++) s += (double)(fp16_to_fp32(krow[d]) * qh[d]);
+                    } else {
+                        for (int64_t d = 0; d < D; d++) s += (double)fp16_to_fp32(krow[d]) * (double)qh[d];
+                    }
+                    kq[((size_t)h * N + n) * T + t] = (float)s;
+                }
+            }
+        }
+        /* scale, mask, softmax (:268-281) */
+        orc_scale_mask_softmax(kq, T, N, H, 1.0f / sqrtf((float)E / (float)H), n_past, mode);
+        if (il == 0 && taps && taps->layer0_kq) memcpy(taps->layer0_kq, kq, (size_t)T * N * H * 4);
+        /* KQV = mul_mat(V f16 [T,D,Hkv], probs [T,N,H]) -> [D,N,H]; permute -> [D,H,N]; cpy contiguous (:284-307) */
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int64_t h = 0; h < H; h++) {
+            for (int64_t n = 0; n < N; n++) {
+                const int64_t hk = h / (H / Hkv);
+                const float *prow = kq + ((size_t)h * N + n) * T;
+                for (int64_t d = 0; d < D; d++) {
+                    const fp16_t *vrow = m->memory_v + (size_t)il * C * Egqa + (size_t)(hk * D + d) * C;
+                    double s = 0.0;
+                    if (mode == 0) {
+                        for (int64_t t = 0; t < T; t++)
+                            s += (double)(fp16_to_fp32(vrow[t]) * fp16_to_fp32(fp32_to_fp16(prow[t])));
+                    } else {
+                        for (int64_t t = 0; t < T; t++) s += (double)fp16_to_fp32(vrow[t]) * (double)prow[t];
+                    }
+                    kqv[((size_t)n * H + h) * D + d] = (float)s;
+                }
+            }
+        }
+        /* out proj + residual (:310-314) */
+        orc_mul_mat(m->wtype, m->wo[il], E, E, kqv, N, E, att, mode);
+        orc_add(att, inpL, inpFF, E * N);
+        /* FFN (:318-334) */
+        orc_rms_norm(inpFF, cur, E, N, m->rms_eps);
+        orc_mul_rows(cur, m->ffn_norm[il], cur, E, N);
+        orc_mul_mat(m->wtype, m->w3[il], F, E, cur, N, E, t3, mode);
+        orc_mul_mat(m->wtype, m->w1[il], F, E, cur, N, E, t1, mode);
+        orc_silu(t1, t1, F * N, mode);
+        orc_mul(t1, t3, t1, F * N);
+        orc_mul_mat(m->wtype, m->w2[il], E, F, t1, N, F, cur, mode);
+        orc_add(cur, inpFF, inpL, E * N);
+        if (il == 0 && taps && taps->layer0_out) memcpy(taps->layer0_out, inpL, (size_t)E * N * 4);
+    }
+    /* final norm + lm_head (:343-352) */
+    orc_rms_norm(inpL, cur, E, N, m->rms_eps);
+    orc_mul_rows(cur, m->norm, cur, E, N);
+    if (taps && taps->final_norm) memcpy(taps->final_norm, cur, (size_t)E * N * 4);
+    orc_mul_mat(m->wtype, m->output, V, E, cur, N, E, logits, mode);
+
+    free(inpL); free(cur); free(q); free(k); free(v); free(kq); free(kqv); free(att); free(inpFF); free(t1); free(t3);
+}
+
+EXPORT int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+EXPORT void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,252 @@
+"""ctypes loader for the CPU oracle (oracle/ggml_oracle.c) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+PARITY UNPINNED: see the header of ggml_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libggml_oracle.so")
+
+T_F32, T_F16, T_Q4_0, T_Q4_1, T_Q5_0, T_Q5_1, T_Q8_0, T_Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9
+QUANT_TYPES = (T_Q4_0, T_Q4_1, T_Q5_0, T_Q5_1, T_Q8_0)
+TYPE_NAMES = {T_F32: "f32", T_F16: "f16", T_Q4_0: "q4_0", T_Q4_1: "q4_1", T_Q5_0: "q5_0", T_Q5_1: "q5_1",
+              T_Q8_0: "q8_0", T_Q8_1: "q8_1"}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ggml_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_fp16_to_fp32.restype = C.c_float
+        L.orc_fp16_to_fp32.argtypes = [C.c_uint16]
+        L.orc_fp32_to_fp16.restype = C.c_uint16
+        L.orc_fp32_to_fp16.argtypes = [C.c_float]
+        L.orc_type_size.restype = C.c_int
+        L.orc_blck_size.restype = C.c_int
+        L.orc_vec_dot_type.restype = C.c_int
+        L.orc_quantize.restype = C.c_size_t
+        L.orc_quantize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_quantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_dequantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_vec_dot.restype = C.c_float
+        L.orc_vec_dot.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_mul_mat.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_int]
+        L.orc_rms_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float]
+        L.orc_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+        L.orc_mul_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+        L.orc_silu.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.orc_gelu.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.orc_rope.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_scale_mask_softmax.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_int]
+        L.orc_soft_max.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+        L.orc_fp32_to_fp16_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_fp16_to_fp32_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_llama_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def type_size(t):
+    return lib().orc_type_size(t)
+
+
+def blck_size(t):
+    return lib().orc_blck_size(t)
+
+
+def row_bytes(t, k):
+    return k // blck_size(t) * type_size(t)
+
+
+def quantize(t, x, k=None):
+    """ggml_quantize_q*: x f32 [..., k] -> raw block bytes (uint8 1-D)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    k = x.shape[-1] if k is None else k
+    n = x.size
+    out = np.zeros(n // blck_size(t) * type_size(t), dtype=np.uint8)
+    hist = np.zeros(16, dtype=np.int64)
+    if t == T_F32:
+        return x.view(np.uint8).reshape(-1).copy()
+    if t == T_F16:
+        return x.astype(np.float16).view(np.uint8).reshape(-1).copy()
+    got = lib().orc_quantize(t, _p(x), _p(out), n, k, _p(hist))
+    assert got == out.size
+    return out
+
+
+def quantize_row(t, x):
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    out = np.zeros(row_bytes(t, x.size), dtype=np.uint8)
+    lib().orc_quantize_row(t, _p(x), _p(out), x.size)
+    return out
+
+
+def dequantize(t, raw, n):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    y = np.zeros(n, dtype=np.float32)
+    lib().orc_dequantize_row(t, _p(raw), _p(y), n)
+    return y
+
+
+def mul_mat(t, A_raw, M, K, B, mode=0):
+    """A_raw: raw bytes of [M rows of K] in type t.  B: f32 [N, K].  Returns f32 [N, M]."""
+    A_raw = np.ascontiguousarray(A_raw)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    N = B.shape[0]
+    dst = np.zeros((N, M), dtype=np.float32)
+    lib().orc_mul_mat(t, _p(A_raw), M, K, _p(B), N, K, _p(dst), mode)
+    return dst
+
+
+def rms_norm(x, eps=5e-6):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().orc_rms_norm(_p(x), _p(y), x.shape[-1], x.size // x.shape[-1], eps)
+    return y
+
+
+def norm(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().orc_norm(_p(x), _p(y), x.shape[-1], x.size // x.shape[-1])
+    return y
+
+
+def silu(x, mode=0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().orc_silu(_p(x), _p(y), x.size, mode)
+    return y
+
+
+def gelu(x, mode=0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().orc_gelu(_p(x), _p(y), x.size, mode)
+    return y
+
+
+def rope(x, n_past, n_dims, freq_base=10000.0, freq_scale=1.0):
+    """x: f32 [N, n_head, ne0] (numpy order; ggml [ne0, n_head, N]).  Returns rotated copy."""
+    y = np.ascontiguousarray(x, dtype=np.float32).copy()
+    N, H, D = y.shape
+    lib().orc_rope(_p(y), D, H, N, n_past, n_dims, freq_base, freq_scale)
+    return y
+
+
+def scale_mask_softmax(x, scale, n_past, mode=0):
+    """x: f32 [n_head, N, nc]."""
+    y = np.ascontiguousarray(x, dtype=np.float32).copy()
+    H, N, nc = y.shape
+    lib().orc_scale_mask_softmax(_p(y), nc, N, H, scale, n_past, mode)
+    return y
+
+
+def soft_max(x, mode=0):
+    y = np.ascontiguousarray(x, dtype=np.float32).copy()
+    lib().orc_soft_max(_p(y), y.shape[-1], y.size // y.shape[-1], mode)
+    return y
+
+
+class _LlamaC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_vocab", "n_embd", "n_head", "n_head_kv", "n_layer", "n_rot", "n_ff", "n_ctx", "wtype")] + [
+        ("rms_eps", C.c_float), ("freq_base", C.c_float), ("freq_scale", C.c_float),
+        ("tok_embeddings", C.c_void_p), ("norm", C.c_void_p), ("output", C.c_void_p),
+        ("attention_norm", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p),
+        ("wo", C.c_void_p), ("ffn_norm", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p),
+        ("memory_k", C.c_void_p), ("memory_v", C.c_void_p)]
+
+
+class _Taps(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("inpL0", "layer0_attn_norm", "layer0_q", "layer0_kq", "layer0_out", "final_norm")]
+
+
+class Llama:
+    """Oracle-side LLaMA session over a dict of raw weight arrays (see llm_amd.synth.make_llama)."""
+
+    def __init__(self, hp, weights, n_ctx):
+        self.hp = dict(hp)
+        self.w = weights  # keep arrays alive
+        self.n_ctx = n_ctx
+        L = hp["n_layer"]
+        egqa = hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])
+        self.memory_k = np.zeros(L * n_ctx * egqa, dtype=np.uint16)
+        self.memory_v = np.zeros(L * n_ctx * egqa, dtype=np.uint16)
+        self.n_past = 0
+
+        def arr(fmt):
+            a = (C.c_void_p * L)()
+            for i in range(L):
+                a[i] = weights[fmt.format(i)].ctypes.data
+            return a
+
+        self._arrs = {k: arr(f) for k, f in {
+            "attention_norm": "layers.{}.attention_norm.weight", "wq": "layers.{}.attention.wq.weight",
+            "wk": "layers.{}.attention.wk.weight", "wv": "layers.{}.attention.wv.weight",
+            "wo": "layers.{}.attention.wo.weight", "ffn_norm": "layers.{}.ffn_norm.weight",
+            "w1": "layers.{}.feed_forward.w1.weight", "w2": "layers.{}.feed_forward.w2.weight",
+            "w3": "layers.{}.feed_forward.w3.weight"}.items()}
+        m = _LlamaC()
+        for k in ("n_vocab", "n_embd", "n_head", "n_head_kv", "n_layer", "n_rot", "n_ff"):
+            setattr(m, k, hp[k])
+        m.n_ctx = n_ctx
+        m.wtype = hp["wtype"]
+        m.rms_eps = 5e-6
+        m.freq_base = hp.get("freq_base", 10000.0)
+        m.freq_scale = hp.get("freq_scale", 1.0)
+        m.tok_embeddings = weights["tok_embeddings.weight"].ctypes.data
+        m.norm = weights["norm.weight"].ctypes.data
+        m.output = weights["output.weight"].ctypes.data
+        for k, a in self._arrs.items():
+            setattr(m, k, C.cast(a, C.c_void_p))
+        m.memory_k = self.memory_k.ctypes.data
+        m.memory_v = self.memory_v.ctypes.data
+        self._m = m
+
+    def evaluate(self, tokens, mode=0, taps=False):
+        """Feeds `tokens` at the current n_past; returns logits f32 [N, n_vocab] (+ taps dict)."""
+        hp = self.hp
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        N = tokens.size
+        E, H = hp["n_embd"], hp["n_head"]
+        logits = np.zeros((N, hp["n_vocab"]), dtype=np.float32)
+        t = None
+        tap_arrays = None
+        if taps:
+            T = self.n_past + N
+            tap_arrays = {"inpL0": np.zeros((N, E), np.float32), "layer0_attn_norm": np.zeros((N, E), np.float32),
+                          "layer0_q": np.zeros((N, H, E // H), np.float32),
+                          "layer0_kq": np.zeros((H, N, T), np.float32), "layer0_out": np.zeros((N, E), np.float32),
+                          "final_norm": np.zeros((N, E), np.float32)}
+            t = _Taps()
+            for k, a in tap_arrays.items():
+                setattr(t, k, a.ctypes.data)
+        lib().orc_llama_eval(C.byref(self._m), _p(tokens), N, self.n_past, _p(logits), mode,
+                             C.byref(t) if t is not None else None)
+        self.n_past += N
+        return (logits, tap_arrays) if taps else logits
