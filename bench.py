@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""bench.py — decode tokens/s of LLaMA-7B Q4_0 on MI355X through the drop-in C ABI (BASELINE.json metric),
+with the mat-vec kernel's HBM roofline and the restated ggml CPU path timed beside it.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one greedy decode token of one sequence per pipeline slot: InferenceSession::infer_next_token
+(host argmax + Model::evaluate of N=1) exactly as crates/llm-base/src/inference_session.rs:381-424 drives it.
+N=1 workload = BASELINE.json configs[1]: LLaMA-7B Q4_0 single-token decode, 128-token synthetic prompt,
+context 2048, f16 KV, weights resident in HBM before the timed region.
+N>1 = ggml-style layer split: rank r owns layers [r*L/N, (r+1)*L/N); the residual [E] f32
+crosses each boundary by RCCL send/recv; N independent sequences are kept in flight (one per stage), so per-GPU
+work per step is constant ("weak"): value = tokens of all sequences / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "65b", "tiny"])
+    ap.add_argument("--wtype", default="q4_0", choices=["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--cpu-secs", type=float, default=15.0, help="budget of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def build_model(args, layer_range=None):
+    from llm_amd import ggml, llama, synth
+    hp = {"7b": synth.LLAMA_7B, "13b": synth.LLAMA_13B, "65b": synth.LLAMA_65B, "tiny": synth.TINY}[args.model]
+    wtype = {"q4_0": ggml.TYPE_Q4_0, "q4_1": ggml.TYPE_Q4_1, "q5_0": ggml.TYPE_Q5_0, "q5_1": ggml.TYPE_Q5_1,
+             "q8_0": ggml.TYPE_Q8_0}[args.wtype]
+    t0 = time.perf_counter()
+    hp, w = synth.make_llama_fast(hp, wtype)
+    t1 = time.perf_counter()
+    ctx = 2048 if args.model != "tiny" else 256
+    model = llama.Llama(hp, w, context_size=ctx)
+    t2 = time.perf_counter()
+    return hp, w, model, {"gen_s": t1 - t0, "upload_s": t2 - t1}
+
+
+def weight_bytes_per_token(hp, wtype_bytes):
+    E, F, V, L = hp["n_embd"], hp["n_ff"], hp["n_vocab"], hp["n_layer"]
+    Egqa = E // (hp["n_head"] // hp["n_head_kv"])
+    params = L * (2 * E * E + 2 * E * Egqa + 3 * E * F) + V * E  # 7 mat-vecs per layer + lm_head
+    return params // 32 * wtype_bytes, params
+
+
+def cpu_baseline(args, hp, w, budget_s):
+    """Restated ggml CPU path (oracle mode 0, scalar restatement) timed on this host's cores."""
+    from oracle import oracle
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    ncpu = len(os.sched_getaffinity(0))
+    orc = oracle.Llama(hp, w, 256)
+    tok = np.array([1], np.int32)
+    best = None
+    # calibrate the team size on one token each (containers often expose more cpus than they may use)
+    for thr in sorted({1, min(ncpu, 8), ncpu}):
+        oracle.lib().orc_set_num_threads(thr)
+        t = time.perf_counter()
+        orc.evaluate(tok, mode=0)
+        dt = time.perf_counter() - t
+        if best is None or dt < best[1]:
+            best = (thr, dt)
+        if dt * 3 > budget_s:
+            break
+    thr, dt1 = best
+    oracle.lib().orc_set_num_threads(thr)
+    n = int(max(1, min(16, (budget_s - 3 * dt1) / max(dt1, 1e-3))))
+    t = time.perf_counter()
+    for _ in range(n):
+        orc.evaluate(tok, mode=0)
+    el = time.perf_counter() - t
+    return {"value": n / el, "unit": "tokens/s", "cores": thr, "kind": "port",
+            "sample": f"{n} single-token decode steps of the same {args.model} {args.wtype} weights "
+                      f"(oracle mode 0 = scalar ggml semantics, -O3 -mavx2, OpenMP {thr} thread(s), short context)"}
+
+
+def run_single(args):
+    from llm_amd import ggml
+    if not ggml.has_gpu():
+        raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
+    L = ggml.lib()
+    hp, w, model, prep = build_model(args)
+    sess = model.start_session(n_batch=8)
+    prompt = np.random.default_rng(42).integers(0, hp["n_vocab"], args.prompt).astype(np.int32)
+    sess.feed_prompt(prompt)
+    for _ in range(args.warmup):
+        sess.infer_next_token()
+    L.ggml_hip_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sess.infer_next_token()
+    L.ggml_hip_synchronize()
+    elapsed = time.perf_counter() - t0
+    tok_s = args.steps / elapsed
+
+    # roofline leg: per-launch HIP events on the backend stream around every mat-vec launch
+    rs = max(args.roofline_steps, 1)
+    L.ggml_hip_timing_begin()
+    for _ in range(rs):
+        sess.infer_next_token()
+    L.ggml_hip_timing_end()
+    ms, launches, algo_bytes = ggml.timing_query(ggml.KCLASS_MMVQ)
+    oth_ms, oth_n, _ = ggml.timing_query(ggml.KCLASS_OTHER)
+    att_ms, att_n, _ = ggml.timing_query(ggml.KCLASS_ATTN)
+    achieved = (algo_bytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    wb, nparams = weight_bytes_per_token(hp, ggml.BLOCK_BYTES[hp["wtype"]])
+    roofline = {"bound": "hbm", "kernel": "k_mmvq (quantized mat-vec, all 225 launches/token)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(ms * 1e3 / max(launches, 1), 3), "launches_per_token": launches // rs,
+                "algo_bytes_per_token": int(algo_bytes / rs),
+                "weights_bytes_per_token": wb,
+                "event_ms_per_token": {"mmvq": round(ms / rs, 4),
+                                       "attn": round(att_ms / rs, 4),
+                                       "other": round(oth_ms / rs, 4)}}
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, hp, w, args.cpu_secs)
+    out = {"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}", "value": round(tok_s, 2),
+           "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "i8*i4->i32 block dots, f32 accumulate (W4A8 = ggml's Q4_0·Q8_0)",
+           "data": "synthetic",
+           "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode "
+                                  f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",
+                      "n_past_at_start": args.prompt + args.warmup, "parallelism": "1 GPU",
+                      "weights_in_hbm_before_timing": True, "prep": {k: round(v, 2) for k, v in prep.items()}},
+           "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(out), flush=True)
+    sess.free()
+    model.free()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from llm_amd import pipeline
+        pipeline.run_bench(args)
+        return
+    run_single(args)
+
+
+if __name__ == "__main__":
+    main()

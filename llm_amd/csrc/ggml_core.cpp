@@ -221,7 +221,7 @@ struct ggml_context *ggml_init(struct ggml_init_params params) {
     ctx->no_alloc = params.no_alloc;
     ctx->no_alloc_save = params.no_alloc;
     GGML_ASSERT(((uintptr_t)ctx->mem_buffer) % GGML_MEM_ALIGN == 0);
-    ggml_hip_internal_register_arena(ctx->mem_buffer, ctx->mem_size);
+    ggml_hip_internal_register_arena(ctx->mem_buffer, ctx->mem_size, 0);
     return ctx;
 }
 
@@ -238,7 +238,7 @@ size_t ggml_used_mem(const struct ggml_context *ctx) {
 size_t ggml_set_scratch(struct ggml_context *ctx, struct ggml_scratch scratch) {
     const size_t result = ctx->scratch.data ? ctx->scratch.offs : 0;
     ctx->scratch = scratch;
-    if (scratch.data) ggml_hip_internal_register_arena(scratch.data, scratch.size);  // idempotent
+    if (scratch.data) ggml_hip_internal_register_arena(scratch.data, scratch.size, 1);  // idempotent
     return result;
 }
 bool ggml_get_no_alloc(struct ggml_context *ctx) { return ctx->no_alloc; }

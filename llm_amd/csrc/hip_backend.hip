@@ -66,6 +66,7 @@ struct Arena {
     size_t size = 0;
     char *dev = nullptr;  // lazily allocated shadow
     bool live = true;
+    bool is_scratch = false;  // registered through ggml_set_scratch (caller-owned Buffer, never unregistered)
 };
 
 // Record behind ggml_tensor.extra (and behind auto-uploaded persistent leaves).
@@ -99,7 +100,9 @@ struct Backend {
     int device = 0;
     hipStream_t stream = nullptr;
     std::map<uintptr_t, Arena> arenas;          // by base
-    std::map<uintptr_t, DevTensor *> tensors;   // by host data base
+    std::map<uintptr_t, DevTensor *> tensors;   // explicit records (transform_tensor / assign_buffers_no_scratch)
+    std::map<uintptr_t, DevTensor *> auto_tensors;  // persistent leaves uploaded on first use (never offloaded by
+                                                    // the caller); evicted when their host range is recycled
     // per-graph workspace (activation re-quantization, temp SoA): bump allocator over chunks; chunks
     // added mid-graph stay alive until the next graph starts, where they are merged into one.
     struct WsChunk {
@@ -153,13 +156,32 @@ Arena *find_arena(uintptr_t p) {
     if (p >= a.base && p < a.base + a.size && a.live) return &a;
     return nullptr;
 }
-DevTensor *find_tensor(uintptr_t p) {
-    auto it = g.tensors.upper_bound(p);
-    if (it == g.tensors.begin()) return nullptr;
+DevTensor *find_in(std::map<uintptr_t, DevTensor *> &m, uintptr_t p) {
+    auto it = m.upper_bound(p);
+    if (it == m.begin()) return nullptr;
     --it;
     DevTensor *t = it->second;
     if (p >= t->host && p < t->host + std::max<size_t>(t->nbytes, 1)) return t;
     return nullptr;
+}
+// explicit records never overlap each other (enforced at registration), so the nearest base below p decides;
+// auto records are consulted second and are evicted whenever anything else claims their host range.
+DevTensor *find_tensor(uintptr_t p) {
+    if (DevTensor *t = find_in(g.tensors, p)) return t;
+    return find_in(g.auto_tensors, p);
+}
+void destroy_record(DevTensor *e);
+// drops every record of `m` whose host range intersects [b, b+size)
+void evict_overlapping(std::map<uintptr_t, DevTensor *> &m, uintptr_t b, size_t size) {
+    for (auto it = m.begin(); it != m.end();) {
+        DevTensor *e = it->second;
+        if (e->host < b + size && b < e->host + std::max<size_t>(e->nbytes, 1)) {
+            it = m.erase(it);
+            destroy_record(e);
+        } else {
+            ++it;
+        }
+    }
 }
 DevTensor *extra_of(const ggml_tensor *t) {
     DevTensor *e = (DevTensor *)t->extra;
@@ -321,7 +343,7 @@ bool wants_soa(const ggml_tensor *t) {
 }
 
 // Uploads `nbytes` from host `data` as the device copy of `t`. Returns the record (registered in g.tensors).
-DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill) {
+DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill, bool is_auto = false) {
     ensure_init();
     const size_t nbytes = ggml_nbytes(t);
     DevTensor *e = new DevTensor();
@@ -353,26 +375,29 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill)
             HIP_CHECK(hipMemcpyAsync(e->dev, data, nbytes, hipMemcpyHostToDevice, g.stream));
         HIP_CHECK(hipStreamSynchronize(g.stream));
     }
-    // replace any stale record at the same host base
-    auto it = g.tensors.find(e->host);
-    if (it != g.tensors.end()) {
-        DevTensor *old = it->second;
-        HIP_CHECK(hipFree(old->dev));
-        old->magic = 0;
-        delete old;
-        g.tensors.erase(it);
+    e->auto_uploaded = is_auto;
+    // whoever held this host range before is gone (the memory was recycled)
+    evict_overlapping(g.auto_tensors, e->host, std::max<size_t>(nbytes, 1));
+    if (is_auto) {
+        g.auto_tensors[e->host] = e;
+    } else {
+        evict_overlapping(g.tensors, e->host, std::max<size_t>(nbytes, 1));
+        g.tensors[e->host] = e;
     }
-    g.tensors[e->host] = e;
     return e;
 }
 
-void free_dev_tensor(DevTensor *e) {
-    auto it = g.tensors.find(e->host);
-    if (it != g.tensors.end() && it->second == e) g.tensors.erase(it);
+void destroy_record(DevTensor *e) {
     if (g.stream) HIP_CHECK(hipStreamSynchronize(g.stream));
     if (e->dev) HIP_CHECK(hipFree(e->dev));
     e->magic = 0;
     delete e;
+}
+void free_dev_tensor(DevTensor *e) {
+    auto &m = e->auto_uploaded ? g.auto_tensors : g.tensors;
+    auto it = m.find(e->host);
+    if (it != m.end() && it->second == e) m.erase(it);
+    destroy_record(e);
 }
 
 // the SoA view of a quantized mul_mat / get_rows operand; re-lays-out on the fly for raw arena tensors
@@ -757,8 +782,7 @@ void upload_inputs(ggml_cgraph *gr) {
             HIP_CHECK(hipMemcpyAsync(dev_ptr(leaf), leaf->data, nbytes, hipMemcpyHostToDevice, g.stream));
         } else {
             // persistent tensor (weight / KV memory) that was never offloaded by the caller: upload once
-            DevTensor *e = upload_tensor(leaf->data, leaf, false);
-            e->auto_uploaded = true;
+            upload_tensor(leaf->data, leaf, false, /*is_auto=*/true);
         }
     }
 }
@@ -813,6 +837,7 @@ void execute_graph(ggml_cgraph *gr) {
                 // fuse the broadcast multiply by the norm weight that follows (llama lib.rs:183-186)
                 if (fuse && next && next->op == GGML_OP_MUL && next->src[0] == n && uses[i] == 1 && !done[i + 1] &&
                     is_contig_f32(next->src[1]) && ggml_nelements(next->src[1]) == n->ne[0] && next->nb[0] == 4) {
+                    invalidate_qact_if_overwritten(next);
                     op_rms_norm(n, next->src[1], next);
                     done[i + 1] = 1;
                 } else {
@@ -827,6 +852,7 @@ void execute_graph(ggml_cgraph *gr) {
                 if (fuse && n->op_params[0] == GGML_UNARY_OP_SILU && next && next->op == GGML_OP_MUL &&
                     next->src[0] == n && uses[i] == 1 && !done[i + 1] && is_contig_f32(next->src[1]) &&
                     ggml_nelements(next->src[1]) == ggml_nelements(n) && is_contig_f32(next)) {
+                    invalidate_qact_if_overwritten(next);
                     op_unary(n, next->src[1], next);
                     done[i + 1] = 1;
                 } else {
@@ -865,13 +891,14 @@ void execute_graph(ggml_cgraph *gr) {
 // ===================================================================================================
 // exported: internal seam
 // ===================================================================================================
-extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size) {
+extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size, int is_scratch) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     const uintptr_t b = (uintptr_t)host_base;
     if (size == 0) return;
     auto it = g.arenas.find(b);
     if (it != g.arenas.end() && it->second.size == size) {
         if (!it->second.live && it->second.dev) g.dead_shadow_bytes -= it->second.size;
+        if (!it->second.live) evict_overlapping(g.auto_tensors, b, size);
         it->second.live = true;  // same buffer re-initialised (ctx0.recreate()): keep the device shadow
         return;
     }
@@ -889,9 +916,11 @@ extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size) {
             ++jt;
         }
     }
+    evict_overlapping(g.auto_tensors, b, size);
     Arena a;
     a.base = b;
     a.size = size;
+    a.is_scratch = is_scratch != 0;
     g.arenas[b] = a;
 }
 
@@ -902,11 +931,7 @@ extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
     if (it == g.arenas.end()) return;
     Arena &a = it->second;
     // auto-uploaded persistent tensors whose host bytes lived in this arena die with it
-    for (auto jt = g.tensors.begin(); jt != g.tensors.end();) {
-        DevTensor *e = jt->second;
-        ++jt;
-        if (e->auto_uploaded && e->host >= a.base && e->host < a.base + a.size) free_dev_tensor(e);
-    }
+    evict_overlapping(g.auto_tensors, a.base, a.size);
     a.live = false;
     if (a.dev) {
         g.dead_shadow_bytes += a.size;
@@ -959,14 +984,21 @@ void ggml_hip_free_scratch(void) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     if (!g.inited) return;
     HIP_CHECK(hipStreamSynchronize(g.stream));
-    // release shadows of arenas that are no longer live (session buffers) and the workspace
+    // Release the device shadows of dead arenas (freed contexts) and of every scratch buffer.  Scratch
+    // registrations stay (the caller-owned Buffers may still be in use by another session); their
+    // shadows hold only per-evaluation temporaries and are re-created lazily on next use.
     for (auto it = g.arenas.begin(); it != g.arenas.end();) {
-        if (!it->second.live) {
-            if (it->second.dev) HIP_CHECK(hipFree(it->second.dev));
+        Arena &a = it->second;
+        if (!a.live) {
+            if (a.dev) HIP_CHECK(hipFree(a.dev));
             it = g.arenas.erase(it);
-        } else {
-            ++it;
+            continue;
         }
+        if (a.is_scratch && a.dev) {
+            HIP_CHECK(hipFree(a.dev));
+            a.dev = nullptr;
+        }
+        ++it;
     }
     g.dead_shadow_bytes = 0;
 }

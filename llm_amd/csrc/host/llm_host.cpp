@@ -12,6 +12,7 @@
 #include <cmath>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ggml_wrap.hpp"
@@ -458,6 +459,50 @@ int llm_model_n_vocab(const llm_model *m) { return (int)m->llama->hyperparameter
 void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_leafs) {
     if (n_nodes) *n_nodes = s->s->last_n_nodes;
     if (n_leafs) *n_leafs = s->s->last_n_leafs;
+}
+
+
+// Synthetic GGML blocks for full-size benchmarks (no checkpoints are obtainable offline): uniform random
+// quants, f16 scale d = d_scale*(0.5+u), and for the *_1 types a min that centres the block.  Fills
+// `nblocks` blocks of `type` at dst; deterministic in (seed, block index); multi-threaded.
+void llm_synth_blocks(int type, void *dst, int64_t nblocks, uint64_t seed, float d_scale) {
+    const size_t bs = ggml_type_size((ggml_type)type);
+    const bool has_m = type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_1;
+    const float lv = type == GGML_TYPE_Q4_1 ? 7.5f : 15.5f;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 32 ? 32 : nt);
+    auto work = [&](int64_t b0, int64_t b1) {
+        uint8_t *p = (uint8_t *)dst + (size_t)b0 * bs;
+        for (int64_t b = b0; b < b1; b++, p += bs) {
+            uint64_t x = seed * 0x9E3779B97F4A7C15ull + (uint64_t)b * 0xD1B54A32D192ED03ull;
+            auto next = [&x]() {
+                x += 0x9E3779B97F4A7C15ull;
+                uint64_t z = x;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                return z ^ (z >> 31);
+            };
+            for (size_t o = 0; o < bs; o += 8) {
+                const uint64_t r = next();
+                memcpy(p + o, &r, bs - o < 8 ? bs - o : 8);
+            }
+            const float u = (float)(next() >> 40) * (1.0f / 16777216.0f);
+            const float d = d_scale * (0.5f + u);
+            const ggml_fp16_t dh = ggml_fp32_to_fp16(d);
+            memcpy(p, &dh, 2);
+            if (has_m) {
+                const ggml_fp16_t mh = ggml_fp32_to_fp16(-lv * ggml_fp16_to_fp32(dh));
+                memcpy(p + 2, &mh, 2);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    const int64_t per = (nblocks + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const int64_t b0 = (int64_t)t * per, b1 = std::min<int64_t>(nblocks, b0 + per);
+        if (b0 < b1) th.emplace_back(work, b0, b1);
+    }
+    for (auto &t : th) t.join();
 }
 
 }  // extern "C"

@@ -75,6 +75,9 @@ GGML_API int llm_model_n_vocab(const llm_model *m);
 /* graph statistics of the last evaluate (for tests): nodes, leafs */
 GGML_API void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_leafs);
 
+/* synthetic GGML blocks for full-size benchmarks (deterministic in seed and block index) */
+GGML_API void llm_synth_blocks(int type, void *dst, int64_t nblocks, uint64_t seed, float d_scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,8 @@ product's own ggml_quantize_q* (the function the reference's `llm quantize` call
 crates/llm-base/src/quantize.rs:363-379), norm weights 1 + N(0, 0.01²) kept f32 (1-D tensors are never
 quantized, quantize.rs:332-335).  Tensor names / dims follow crates/models/llama/src/lib.rs:52-91:
 2-D weights are [in_features (ne0), out_features (ne1)]."""
+import ctypes
+
 import numpy as np
 
 from . import ggml
@@ -64,16 +66,14 @@ def make_llama_fast(hp, wtype, seed=1234, d_scale=0.0043):
             out[name] = (1.0 + 0.01 * rng.standard_normal(ne0)).astype(np.float32)
             continue
         nblk = ne1 * (ne0 // be)
-        raw = rng.integers(0, 256, size=(nblk, bs), dtype=np.uint8)
         # per-type scale so that dequantized std stays ≈ 0.02: q4 std≈4.6, q5 std≈9.2, q8 std≈74
         sc = {ggml.TYPE_Q4_0: d_scale, ggml.TYPE_Q4_1: d_scale, ggml.TYPE_Q5_0: d_scale / 2,
               ggml.TYPE_Q5_1: d_scale / 2, ggml.TYPE_Q8_0: d_scale / 16}[wtype]
-        d = (sc * (0.5 + rng.random(nblk))).astype(np.float16)
-        raw[:, 0:2] = d.view(np.uint8).reshape(nblk, 2)
-        if wtype in (ggml.TYPE_Q4_1, ggml.TYPE_Q5_1):  # min = -(levels/2)*d: centred blocks
-            lv = 7.5 if wtype == ggml.TYPE_Q4_1 else 15.5
-            m = (-lv * d.astype(np.float32)).astype(np.float16)
-            raw[:, 2:4] = m.view(np.uint8).reshape(nblk, 2)
+        raw = np.empty(nblk * bs, dtype=np.uint8)
+        fill = ggml.lib().llm_synth_blocks
+        fill.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float]
+        fill.restype = None
+        fill(wtype, raw.ctypes.data, nblk, int(rng.integers(0, 2**62)), sc)
         out[name] = raw.reshape(-1)
     h = dict(hp)
     h["wtype"] = wtype

@@ -33,6 +33,9 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
+        # libgomp reads this at load time: idle team members sleep instead of spinning (containers often
+        # expose more cpus than their quota lets them run, where spinning makes 8 threads slower than 1)
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         L = C.CDLL(_SO)
         L.orc_fp16_to_fp32.restype = C.c_float
         L.orc_fp16_to_fp32.argtypes = [C.c_uint16]
@@ -61,6 +64,9 @@ def lib():
         L.orc_fp16_to_fp32_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_llama_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        # bound the OpenMP team: tiny parity cases on a 100+-core host spend their time in barrier spin
+        L.orc_set_num_threads(int(os.environ.get("ORACLE_THREADS", min(os.cpu_count() or 1, 16))))
         _lib = L
     return _lib
 
