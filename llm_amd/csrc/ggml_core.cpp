@@ -760,6 +760,17 @@ inline void put_f16(uint8_t *p, float f) {
 }
 inline int imin(int a, int b) { return a < b ? a : b; }
 
+// upstream's 16-bin histogram for the 5-bit types: walks j = 0,2,..,30 pairing qs[j/2] with the high bits at
+// positions j and j+16 ("cast to 16 bins") — kept as is so `llm quantize` prints what the reference prints
+void hist_q5(uint32_t qh, const uint8_t *qs, int64_t *hist) {
+    for (int j = 0; j < QK; j += 2) {
+        const uint8_t vh0 = (uint8_t)(((qh & (1u << (j + 0))) >> (j + 0)) << 4);
+        const uint8_t vh1 = (uint8_t)((qh & (1u << ((j + 16) & 31))) >> ((j + 12) & 31));  // x86 shift-count wrap of upstream
+        hist[((qs[j / 2] & 0x0F) | vh0) / 2]++;
+        hist[((qs[j / 2] >> 4) | vh1) / 2]++;
+    }
+}
+
 void quant_block(ggml_type type, const float *x, uint8_t *out, int64_t *hist) {
     const scan_t s = scan_block(x);
     switch (type) {
@@ -797,9 +808,9 @@ void quant_block(ggml_type type, const float *x, uint8_t *out, int64_t *hist) {
                 out[6 + j] = (a & 0x0F) | ((b & 0x0F) << 4);
                 qh |= (uint32_t)((a & 0x10u) >> 4) << j;
                 qh |= (uint32_t)((b & 0x10u) >> 4) << (j + QK / 2);
-                if (hist) { hist[a / 2]++; hist[b / 2]++; }
             }
             memcpy(out + 2, &qh, 4);
+            if (hist) hist_q5(qh, out + 6, hist);
         } break;
         case GGML_TYPE_Q5_1: {
             const float d = (s.vmax - s.vmin) / 31;
@@ -813,9 +824,9 @@ void quant_block(ggml_type type, const float *x, uint8_t *out, int64_t *hist) {
                 out[8 + j] = (a & 0x0F) | ((b & 0x0F) << 4);
                 qh |= (uint32_t)((a & 0x10u) >> 4) << j;
                 qh |= (uint32_t)((b & 0x10u) >> 4) << (j + QK / 2);
-                if (hist) { hist[(a & 0x1F) / 2]++; hist[(b & 0x1F) / 2]++; }
             }
             memcpy(out + 4, &qh, 4);
+            if (hist) hist_q5(qh, out + 8, hist);
         } break;
         case GGML_TYPE_Q8_0: {
             const float amax = fabsf(s.amax_signed);

@@ -133,6 +133,7 @@ class InferenceSession {
         }
         last_n_nodes = built_gf.raw()->n_nodes;
         last_n_leafs = built_gf.raw()->n_leafs;
+        last_graph = built_gf.raw();  // lives in ctx0's arena until the next compute()
         if (mem_per_token == 0) mem_per_token = ctx0_.used_mem() / n_embd_;
         n_past += input_tokens.size();
         return GraphOutputs{built_result.result.share(), built_result.embedding_result.share()};
@@ -145,6 +146,7 @@ class InferenceSession {
     std::vector<TokenId> tokens;
     std::vector<float> last_logits;
     int last_n_nodes = 0, last_n_leafs = 0;
+    ggml_cgraph *last_graph = nullptr;
 
    private:
     std::shared_ptr<Context> session_ctx_;
@@ -461,6 +463,25 @@ void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_lea
     if (n_leafs) *n_leafs = s->s->last_n_leafs;
 }
 
+// test hook: device contents of a node of the last evaluated graph, by index (>= 0) or by the k-th node
+// carrying `name` (index < 0).  Returns the number of bytes the node holds, 0 if not found.
+size_t llm_session_read_node(const llm_session *s, int index, const char *name, int occurrence, void *dst,
+                             size_t max_bytes) {
+    ggml_cgraph *g = s->s->last_graph;
+    if (!g) return 0;
+    ggml_tensor *t = nullptr;
+    if (index >= 0) {
+        if (index < g->n_nodes) t = g->nodes[index];
+    } else {
+        int seen = 0;
+        for (int i = 0; i < g->n_nodes && !t; i++)
+            if (strcmp(g->nodes[i]->name, name) == 0 && seen++ == occurrence) t = g->nodes[i];
+    }
+    if (!t || !ggml_is_contiguous(t)) return 0;
+    const size_t n = ggml_nbytes(t);
+    if (dst && n <= max_bytes) ggml_hip_tensor_get(t, dst, 0, n);
+    return n;
+}
 
 // Synthetic GGML blocks for full-size benchmarks (no checkpoints are obtainable offline): uniform random
 // quants, f16 scale d = d_scale*(0.5+u), and for the *_1 types a min that centres the block.  Fills

@@ -75,6 +75,9 @@ GGML_API int llm_model_n_vocab(const llm_model *m);
 /* graph statistics of the last evaluate (for tests): nodes, leafs */
 GGML_API void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_leafs);
 
+/* test hook: reads the device contents of a node of the last evaluated graph (by index, or k-th node named `name`) */
+GGML_API size_t llm_session_read_node(const llm_session *s, int index, const char *name, int occurrence, void *dst,
+                                      size_t max_bytes);
 /* synthetic GGML blocks for full-size benchmarks (deterministic in seed and block index) */
 GGML_API void llm_synth_blocks(int type, void *dst, int64_t nblocks, uint64_t seed, float d_scale);
 

@@ -53,6 +53,8 @@ def _lib():
         L.llm_session_n_past.restype = C.c_int
         L.llm_session_n_past.argtypes = [C.c_void_p]
         L.llm_session_last_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.llm_session_read_node.restype = C.c_size_t
+        L.llm_session_read_node.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
         _bound = True
     return L
 
@@ -136,6 +138,16 @@ class Session:
     def last_logits(self):
         V = self.model.hp["n_vocab"]
         return np.ctypeslib.as_array(_lib().llm_session_last_logits(self.ptr), shape=(V,)).copy()
+
+    def read_node(self, index=-1, name=None, occurrence=0, dtype=np.float32):
+        """Test hook: device contents of a node of the last evaluated graph."""
+        nm = name.encode() if name else None
+        n = _lib().llm_session_read_node(self.ptr, index, nm, occurrence, None, 0)
+        if n == 0:
+            raise KeyError((index, name, occurrence))
+        out = np.zeros(n // np.dtype(dtype).itemsize, dtype=dtype)
+        _lib().llm_session_read_node(self.ptr, index, nm, occurrence, out.ctypes.data, out.nbytes)
+        return out
 
     def graph_stats(self):
         a, b = C.c_int(0), C.c_int(0)

@@ -419,7 +419,8 @@ EXPORT size_t orc_quantize(int type, const float *src, void *dst, int n, int k, 
                     memcpy(&qh, qhp, 4);
                     for (int j = 0; j < QK; j += 2) {
                         const uint8_t vh0 = ((qh & (1u << (j + 0))) >> (j + 0)) << 4;
-                        const uint8_t vh1 = ((qh & (1u << (j + 16))) >> (j + 12));
+                        /* upstream writes (1u << (j + 16)) >> (j + 12) with j up to 30; x86 wraps the count */
+                        const uint8_t vh1 = ((qh & (1u << ((j + 16) & 31))) >> ((j + 12) & 31));
                         /* cast to 16 bins */
                         const uint8_t vi0 = ((qs[j / 2] & 0x0F) | vh0) / 2;
                         const uint8_t vi1 = ((qs[j / 2] >> 4) | vh1) / 2;

@@ -1,0 +1,212 @@
+"""CPU tests of the drop-in boundary (no GPU, no compute calls): libggml_hip.so loads, exports every symbol
+include/ggml_hip.h declares, keeps the struct layouts of the reference's bindgen tests
+(crates/ggml/sys/src/lib.rs:174-238, 261-446, 458-533, 546-651), and builds graphs with the reference's
+semantics (result shapes, strides, views, leaf/node classification, scratch behaviour)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#define GGML_API.*", "", src)
+    return set(re.findall(r"GGML_API[^;(]*?\b(\w+)\s*\(", src))
+
+
+def test_every_declared_symbol_is_exported_and_bound(G):
+    names = _declared("include/ggml_hip.h")
+    assert len(names) > 130
+    lib = C.CDLL(G.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    # the Python binding covers the same set (so tests exercise what the header promises)
+    unbound = sorted(names - set(G.PROTOTYPES))
+    assert not unbound, unbound
+    host = _declared("llm_amd/csrc/host/llm_host.h")
+    assert not [n for n in sorted(host) if not hasattr(lib, n)]
+
+
+def test_struct_layouts_match_bindgen_numbers(G):
+    assert C.sizeof(G.ggml_tensor) == 272
+    assert G.ggml_tensor.ne.offset == 16 and G.ggml_tensor.nb.offset == 48 and G.ggml_tensor.op.offset == 80
+    assert G.ggml_tensor.op_params.offset == 84 and G.ggml_tensor.src.offset == 128
+    assert G.ggml_tensor.data.offset == 200 and G.ggml_tensor.name.offset == 208 and G.ggml_tensor.extra.offset == 256
+    assert C.sizeof(G.ggml_cplan) == 16424 and G.ggml_cplan.n_tasks.offset == 20
+    assert C.sizeof(G.ggml_cgraph) == 164520 and G.ggml_cgraph.leafs.offset == 65544
+    assert G.ggml_cgraph.visited_hash_table.offset == 98312
+    assert C.sizeof(G.ggml_init_params) == 24 and C.sizeof(G.ggml_scratch) == 24
+    assert C.sizeof(G.ggml_compute_params) == 32 and C.sizeof(G.ggml_type_traits_t) == 40
+    L = G.lib()
+    assert L.ggml_graph_overhead() == 32 + 164528  # OBJECT_SIZE + pad16(GRAPH_SIZE)
+    assert L.ggml_tensor_overhead() == 32 + 272 + 16
+
+
+def test_type_table(G):
+    L = G.lib()
+    for t, (bs, be) in {0: (4, 1), 1: (2, 1), 2: (18, 32), 3: (20, 32), 6: (22, 32), 7: (24, 32), 8: (34, 32),
+                        9: (40, 32), 16: (1, 1), 18: (4, 1)}.items():
+        assert L.ggml_type_size(t) == bs and L.ggml_blck_size(t) == be
+    assert abs(L.ggml_type_sizef(2) - 18 / 32) < 1e-7
+    assert L.ggml_is_quantized(2) and not L.ggml_is_quantized(1)
+    assert L.ggml_op_name(21) == b"MUL_MAT" and L.ggml_op_name(51) == b"UNARY" and L.ggml_type_name(6) == b"q5_0"
+    assert L.ggml_internal_get_type_traits(2).vec_dot_type == 8
+    assert L.ggml_internal_get_type_traits(7).vec_dot_type == 9
+
+
+@pytest.mark.parametrize("t", [2, 3, 6, 7, 8])
+def test_product_quantizer_matches_oracle_bytes_and_hist(G, O, t):
+    rng = np.random.default_rng(t)
+    x = (0.02 * rng.standard_normal((32, 256))).astype(np.float32)
+    x[3, 64:96] = 0
+    assert np.array_equal(G.quantize(t, x), O.quantize(t, x))
+    out = np.zeros(G.row_bytes(t, x.size), np.uint8)
+    h1, h2 = np.zeros(16, np.int64), np.zeros(16, np.int64)
+    fn = getattr(G.lib(), "ggml_quantize_" + G.TYPE_NAMES[t])
+    assert fn(x.ctypes.data, out.ctypes.data, x.size, 256, h1.ctypes.data) == out.size
+    O.lib().orc_quantize(t, x.ctypes.data, out.ctypes.data, x.size, 256, h2.ctypes.data)
+    assert np.array_equal(h1, h2) and h1.sum() == x.size
+
+
+def test_fp16_product_matches_numpy(G):
+    x = np.random.default_rng(0).standard_normal(4096).astype(np.float32) * 100
+    out = np.zeros(x.size, np.uint16)
+    G.lib().ggml_fp32_to_fp16_row(x.ctypes.data, out.ctypes.data, x.size)
+    assert np.array_equal(out, x.astype(np.float16).view(np.uint16))
+    back = np.zeros(x.size, np.float32)
+    G.lib().ggml_fp16_to_fp32_row(out.ctypes.data, back.ctypes.data, x.size)
+    assert np.array_equal(back, x.astype(np.float16).astype(np.float32))
+
+
+def test_builders_shapes_strides_and_views(G):
+    with G.Context(1 << 22) as c:
+        a = c.new_tensor(G.TYPE_Q4_0, 256, 64)     # [K=256, M=64]
+        assert a.nb[:2] == (18, 18 * 8) and a.nbytes() == 64 * 8 * 18
+        b = c.new_tensor(G.TYPE_F32, 256, 5)
+        y = c.op_mul_mat(a, b)
+        assert y.ne == (64, 5, 1, 1) and y.t.type == G.TYPE_F32 and y.t.op == 21
+        assert C.addressof(y.t.src[0].contents) == C.addressof(a.t) and C.addressof(y.t.src[1].contents) == C.addressof(b.t)
+        r = c.op_reshape_3d(y, 16, 4, 5)
+        assert r.ne == (16, 4, 5, 1) and r.t.data == y.t.data
+        p = c.op_permute(r, 0, 2, 1, 3)
+        assert p.ne == (16, 5, 4, 1) and p.nb == (4, 16 * 4 * 4, 16 * 4, 16 * 4 * 5 * 4)
+        t = c.op_transpose(b)
+        assert t.ne[:2] == (5, 256) and t.nb[:2] == (1024, 4) and G.lib().ggml_is_transposed(t.ptr)
+        kv = c.new_tensor(G.TYPE_F16, 4096)
+        v1 = c.op_view_1d(kv, 128, 512)
+        assert v1.t.data == kv.t.data + 512 and v1.ne[0] == 128
+        off = C.c_size_t.from_buffer_copy(bytes(v1.t.op_params)[:8]).value
+        assert off == 512  # offset travels in op_params (the accelerator reads it there)
+        v2 = c.op_view_2d(kv, 3, 32, 64 * 2, 10)
+        assert v2.ne[:2] == (3, 32) and v2.nb[:3] == (2, 128, 128 * 32)
+        v3 = c.op_view_3d(kv, 8, 16, 4, 64, 1024, 0)
+        assert v3.nb == (2, 64, 1024, 4096)
+        cp = c.op_cpy(b, c.new_tensor(G.TYPE_F16, 256, 5))
+        assert cp.t.op == 25 and cp.t.type == G.TYPE_F16
+        rn = c.op_rms_norm(b, 5e-6)
+        assert abs(np.frombuffer(bytes(rn.t.op_params)[:4], np.float32)[0] - 5e-6) < 1e-12
+        ro = c.op_rope_custom_inplace(r, 7, 16, 0, 1, 26000.0, 0.5)
+        pr = np.frombuffer(bytes(ro.t.op_params), np.int32)
+        assert list(pr[:4]) == [7, 16, 0, 1] and ro.t.data == r.t.data
+        assert np.frombuffer(bytes(ro.t.op_params)[16:24], np.float32).tolist() == [26000.0, 0.5]
+        si = c.op_silu(b)
+        assert si.t.op == 51 and si.t.op_params[0] == 9  # GGML_OP_UNARY / GGML_UNARY_OP_SILU
+        dm = c.op_diag_mask_inf_inplace(b, 3)
+        assert dm.t.data == b.t.data and dm.t.op_params[0] == 3
+        gr = c.op_get_rows(a, c.new_tensor(G.TYPE_I32, 7))
+        assert gr.ne[:2] == (256, 7)
+
+
+def test_graph_order_leafs_and_scratch(G):
+    with G.Context(1 << 22) as c:
+        scratch = np.zeros(1 << 16, np.uint8)
+        x = c.new_tensor(G.TYPE_F32, 32, 2)
+        w = c.new_tensor(G.TYPE_F32, 32)
+        used0 = G.lib().ggml_used_mem(c.ptr)
+        c.use_scratch(scratch.ctypes.data, scratch.nbytes)
+        n1 = c.op_rms_norm(x, 1e-5)
+        assert scratch.ctypes.data <= n1.t.data < scratch.ctypes.data + scratch.nbytes  # data in the scratch
+        s = c.new_f32(0.25)                                                           # constants are not
+        assert not (scratch.ctypes.data <= s.t.data < scratch.ctypes.data + scratch.nbytes)
+        assert np.frombuffer((C.c_char * 4).from_address(s.t.data), np.float32)[0] == 0.25
+        n2 = c.op_mul(n1, w)
+        n3 = c.op_scale_inplace(n2, s)
+        c.use_scratch(None, 0)
+        g = c.graph().build_forward_expand(n3)
+        assert g.n_nodes == 3 and g.n_leafs == 3
+        assert [g.node(i).t.op for i in range(3)] == [19, 6, 23]
+        assert G.lib().ggml_used_mem(c.ptr) > used0
+        plan = G.lib().ggml_graph_plan(g.ptr, 4)
+        assert plan.n_threads == 4 and plan.work_size == 0
+        # expanding the same result again adds nothing (visited hash table)
+        g.build_forward_expand(n3)
+        assert g.n_nodes == 3
+
+
+def test_llama_layer_graph_has_the_reference_node_count(G):
+    """One layer wired as crates/models/llama/src/lib.rs:174-338 yields 37 nodes."""
+    E, H, F, C_, N, P = 64, 2, 96, 16, 3, 2
+    D = E // H
+    with G.Context(1 << 24) as c:
+        mk, mv = c.new_tensor(G.TYPE_F16, C_ * E), c.new_tensor(G.TYPE_F16, C_ * E)
+        W = {k: c.new_tensor(G.TYPE_Q4_0, *s) for k, s in dict(wq=(E, E), wk=(E, E), wv=(E, E), wo=(E, E), w1=(E, F),
+                                                               w3=(E, F), w2=(F, E)).items()}
+        an, fn = c.new_tensor(G.TYPE_F32, E), c.new_tensor(G.TYPE_F32, E)
+        inp = c.new_tensor(G.TYPE_F32, E, N)
+        g = c.graph()
+        cur = c.op_mul(c.op_rms_norm(inp, 5e-6), an)
+        q = c.op_rope_inplace(c.op_reshape_3d(c.op_mul_mat(W["wq"], cur), D, H, N), P, D, 0, 0)
+        k = c.op_rope_inplace(c.op_reshape_3d(c.op_mul_mat(W["wk"], cur), D, H, N), P, D, 0, 0)
+        v = c.op_transpose(c.op_reshape_2d(c.op_mul_mat(W["wv"], cur), E, N))
+        g.build_forward_expand(c.op_cpy(k, c.op_view_1d(mk, N * E, 2 * E * P)))
+        g.build_forward_expand(c.op_cpy(v, c.op_view_2d(mv, N, E, C_ * 2, P * 2)))
+        Q = c.op_permute(q, 0, 2, 1, 3)
+        K = c.op_permute(c.op_reshape_3d(c.op_view_1d(mk, (P + N) * E, 0), D, H, P + N), 0, 2, 1, 3)
+        kq = c.op_soft_max_inplace(c.op_diag_mask_inf_inplace(c.op_scale_inplace(c.op_mul_mat(K, Q), c.new_f32(0.1)), P))
+        assert kq.ne == (P + N, N, H, 1)
+        V = c.op_view_3d(mv, P + N, D, H, C_ * 2, C_ * 2 * D, 0)
+        kqv = c.op_mul_mat(V, kq)
+        assert kqv.ne == (D, N, H, 1)
+        cur = c.op_cpy(c.op_permute(kqv, 0, 2, 1, 3), c.new_tensor(G.TYPE_F32, E, N))
+        ff_in = c.op_add(c.op_mul_mat(W["wo"], cur), inp)
+        cur = c.op_mul(c.op_rms_norm(ff_in, 5e-6), fn)
+        t3 = c.op_mul_mat(W["w3"], cur)
+        cur = c.op_mul(c.op_silu(c.op_mul_mat(W["w1"], cur)), t3)
+        out = c.op_add(c.op_mul_mat(W["w2"], cur), ff_in)
+        g.build_forward_expand(out)
+        assert g.n_nodes == 37
+        ops = [g.node(i).t.op for i in range(g.n_nodes)]
+        assert ops.count(21) == 9 and ops.count(25) == 3 and ops.count(38) == 2
+        # cpy(k) precedes the K·Q matmul in execution order (the ordering the KV cache relies on)
+        first_cpy = ops.index(25)
+        kq_idx = [i for i in range(g.n_nodes) if g.node(i).t.op == 21 and g.node(i).ne[0] == P + N][0]
+        assert first_cpy < kq_idx
+
+
+def test_out_of_path_ops_abort_not_fallback(G):
+    """alibi / flash_attn / map_* have no device implementation: the library aborts instead of computing on CPU."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from llm_amd import ggml as G\n"
+            "c = G.Context(1 << 20); a = c.new_tensor(G.TYPE_F32, 8, 8); c.op_alibi(a, 0, 2, 8.0)") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert p.returncode != 0 and "no CPU compute fallback" in p.stderr
+
+
+def test_compute_without_gpu_fails_loudly(G):
+    """The product path must not silently run anywhere else: without a HIP device graph compute aborts."""
+    if G.has_gpu():
+        pytest.skip("a GPU is present")
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from llm_amd import ggml as G\n"
+            "import numpy as np\n"
+            "c = G.Context(1 << 20); a = c.tensor_from(np.ones((2, 8), np.float32)); y = c.op_add(a, a)\n"
+            "c.graph().build_forward_expand(y).compute()") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert p.returncode != 0 and "no HIP device" in p.stderr

@@ -36,7 +36,7 @@ def _abs_scale(O, wtype, W_raw, M, K, X):
 
 
 @pytest.mark.parametrize("wtype", QTYPES)
-@pytest.mark.parametrize("shape", [(64, 64), (96, 256), (257, 1024), (33, 4096)])
+@pytest.mark.parametrize("shape", [(64, 64), (96, 256), (257, 1024), (33, 4096), (352, 128), (128, 352), (5, 32)])
 @pytest.mark.parametrize("N", [1, 2, 3, 5, 8, 13])
 def test_mul_mat_q_matches_oracle_exact(G, O, wtype, shape, N):
     M, K = shape
