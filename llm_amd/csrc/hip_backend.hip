@@ -267,6 +267,103 @@ void ws_reset() {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// host <-> device transfers through library-owned pinned staging.  Caller memory (ggml arenas, mmap'd
+// weight files, numpy buffers) is pageable and may be unmapped/recycled at any time; copying through
+// our own hipHostMalloc'd buffers keeps the runtime from pinning (and caching pins of) memory it does
+// not own, and makes the small per-evaluation uploads truly asynchronous.
+// ---------------------------------------------------------------------------------------------------
+struct Staging {
+    static constexpr size_t BIG = (size_t)32 << 20;   // bulk chunk (weights upload, large read-backs)
+    static constexpr size_t SMALL = (size_t)8 << 20;  // per-graph bump region (token ids, constants, logits)
+    char *big[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int next = 0;
+    char *small = nullptr;
+    size_t small_off = 0;
+    struct Pending {
+        void *host_dst;
+        const char *stage;
+        size_t n;
+    };
+    std::vector<Pending> pending;  // D2H copies whose staging → user memcpy happens after the stream sync
+} stg;
+
+void staging_init() {
+    if (stg.small) return;
+    for (int i = 0; i < 2; i++) {
+        HIP_CHECK(hipHostMalloc((void **)&stg.big[i], Staging::BIG, hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&stg.ev[i], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipHostMalloc((void **)&stg.small, Staging::SMALL, hipHostMallocDefault));
+}
+
+// bulk upload; returns when the data has left `src` (the device copy is ordered on g.stream)
+void h2d_bulk(char *dst, const void *src, size_t n) {
+    staging_init();
+    size_t off = 0;
+    while (off < n) {
+        const int b = stg.next;
+        stg.next ^= 1;
+        if (stg.busy[b]) {
+            HIP_CHECK(hipEventSynchronize(stg.ev[b]));
+            stg.busy[b] = false;
+        }
+        const size_t len = std::min(Staging::BIG, n - off);
+        memcpy(stg.big[b], (const char *)src + off, len);
+        HIP_CHECK(hipMemcpyAsync(dst + off, stg.big[b], len, hipMemcpyHostToDevice, g.stream));
+        HIP_CHECK(hipEventRecord(stg.ev[b], g.stream));
+        stg.busy[b] = true;
+        off += len;
+    }
+}
+// small asynchronous upload for the current graph (staging lives until the graph's final sync)
+void h2d_small(char *dst, const void *src, size_t n) {
+    staging_init();
+    const size_t need = (n + 63) & ~(size_t)63;
+    if (stg.small_off + need > Staging::SMALL) {
+        h2d_bulk(dst, src, n);
+        return;
+    }
+    char *s = stg.small + stg.small_off;
+    stg.small_off += need;
+    memcpy(s, src, n);
+    HIP_CHECK(hipMemcpyAsync(dst, s, n, hipMemcpyHostToDevice, g.stream));
+}
+// read-back: queued on the stream now, delivered to user memory by d2h_finish() (which synchronises)
+void d2h_queue(void *host_dst, const char *src, size_t n) {
+    staging_init();
+    const size_t need = (n + 63) & ~(size_t)63;
+    if (stg.small_off + need > Staging::SMALL) {  // large: synchronous chunks through the bulk buffers
+        size_t off = 0;
+        while (off < n) {
+            const size_t len = std::min(Staging::BIG, n - off);
+            for (int i = 0; i < 2; i++)
+                if (stg.busy[i]) {
+                    HIP_CHECK(hipEventSynchronize(stg.ev[i]));
+                    stg.busy[i] = false;
+                }
+            HIP_CHECK(hipMemcpyAsync(stg.big[0], src + off, len, hipMemcpyDeviceToHost, g.stream));
+            HIP_CHECK(hipStreamSynchronize(g.stream));
+            memcpy((char *)host_dst + off, stg.big[0], len);
+            off += len;
+        }
+        return;
+    }
+    char *s = stg.small + stg.small_off;
+    stg.small_off += need;
+    HIP_CHECK(hipMemcpyAsync(s, src, n, hipMemcpyDeviceToHost, g.stream));
+    stg.pending.push_back({host_dst, s, n});
+}
+void d2h_finish() {
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    for (auto &p : stg.pending) memcpy(p.host_dst, p.stage, p.n);
+    stg.pending.clear();
+    stg.small_off = 0;
+    stg.busy[0] = stg.busy[1] = false;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // timing (HIP events on the backend stream, per kernel class)
 // ---------------------------------------------------------------------------------------------------
 struct Timed {
@@ -360,7 +457,7 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill,
         e->dev_bytes = total;
         char *tmp = nullptr;
         HIP_CHECK(hipMalloc((void **)&tmp, nbytes));
-        HIP_CHECK(hipMemcpyAsync(tmp, data, nbytes, hipMemcpyHostToDevice, g.stream));
+        h2d_bulk(tmp, data, nbytes);
         relayout_launch(tmp, qt, M, nb, e->dev);
         HIP_CHECK(hipStreamSynchronize(g.stream));
         HIP_CHECK(hipFree(tmp));
@@ -372,7 +469,7 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill,
         if (zero_fill)
             HIP_CHECK(hipMemsetAsync(e->dev, 0, std::max<size_t>(nbytes, 16), g.stream));
         else
-            HIP_CHECK(hipMemcpyAsync(e->dev, data, nbytes, hipMemcpyHostToDevice, g.stream));
+            h2d_bulk(e->dev, data, nbytes);
         HIP_CHECK(hipStreamSynchronize(g.stream));
     }
     e->auto_uploaded = is_auto;
@@ -779,7 +876,7 @@ void upload_inputs(ggml_cgraph *gr) {
             // inputs written by the host before every compute (token ids, scalar constants, test operands)
             const size_t nbytes = ggml_nbytes(leaf);
             if (nbytes == 0) continue;
-            HIP_CHECK(hipMemcpyAsync(dev_ptr(leaf), leaf->data, nbytes, hipMemcpyHostToDevice, g.stream));
+            h2d_small(dev_ptr(leaf), leaf->data, nbytes);
         } else {
             // persistent tensor (weight / KV memory) that was never offloaded by the caller: upload once
             upload_tensor(leaf->data, leaf, false, /*is_auto=*/true);
@@ -794,11 +891,11 @@ void download_outputs(ggml_cgraph *gr) {
         if (n->backend != GGML_BACKEND_CPU || is_view_op(n->op) || n->op == GGML_OP_CPY) continue;
         if (!ggml_is_contiguous(n) || n->data == nullptr) continue;
         if (extra_of(n) || find_tensor((uintptr_t)n->data)) continue;  // result aliases a device-resident tensor
-        HIP_CHECK(hipMemcpyAsync(n->data, dev_ptr(n), ggml_nbytes(n), hipMemcpyDeviceToHost, g.stream));
+        d2h_queue(n->data, dev_ptr(n), ggml_nbytes(n));
         any = true;
     }
     (void)any;
-    HIP_CHECK(hipStreamSynchronize(g.stream));
+    d2h_finish();
 }
 
 void invalidate_qact_if_overwritten(const ggml_tensor *n) {
@@ -1115,13 +1212,13 @@ void ggml_hip_synchronize(void) {
 void ggml_hip_tensor_get(const struct ggml_tensor *tensor, void *host_dst, size_t offset, size_t nbytes) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     ensure_init();
-    HIP_CHECK(hipMemcpyAsync(host_dst, dev_ptr(tensor) + offset, nbytes, hipMemcpyDeviceToHost, g.stream));
-    HIP_CHECK(hipStreamSynchronize(g.stream));
+    d2h_queue(host_dst, dev_ptr(tensor) + offset, nbytes);
+    d2h_finish();
 }
 void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_t offset, size_t nbytes) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     ensure_init();
-    HIP_CHECK(hipMemcpyAsync(dev_ptr(tensor) + offset, host_src, nbytes, hipMemcpyHostToDevice, g.stream));
+    h2d_bulk(dev_ptr(tensor) + offset, host_src, nbytes);
     HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void *ggml_hip_tensor_device_ptr(const struct ggml_tensor *tensor) {

@@ -440,10 +440,17 @@ EXPORT size_t orc_quantize(int type, const float *src, void *dst, int n, int k, 
 
 /* ---- vec_dot (upstream ggml_vec_dot_q*_q8_*, scalar branch).  The heart of
  * ggml_compute_forward_mul_mat for quantized src0. ------------------------- */
+/* Order in which a row's blocks are added into sumf.  0 = ascending (ggml's scalar code).  1 = descending:
+ * NOT a ggml mode — a yardstick for how much a legal re-association of the f32 block sum (which ggml's own
+ * AVX2 path, 8 lanes + horizontal add, also performs) moves the results of a given model. */
+static int g_rev = 0;
+EXPORT void orc_set_block_order(int reverse) { g_rev = reverse; }
+#define BLOCK_LOOP(i, nb) for (int ii_ = 0, i = g_rev ? (nb)-1 : 0; ii_ < (nb); ii_++, i += g_rev ? -1 : 1)
+
 static float vec_dot_q4_0_q8_0(int n, const block_q4_0 *x, const block_q8_0 *y) {
     const int nb = n / QK;
     float sumf = 0.0f;
-    for (int i = 0; i < nb; i++) {
+    BLOCK_LOOP(i, nb) {
         int sumi = 0;
         for (int j = 0; j < QK / 2; ++j) {
             const int v0 = (x[i].qs[j] & 0x0F) - 8;
@@ -457,7 +464,7 @@ static float vec_dot_q4_0_q8_0(int n, const block_q4_0 *x, const block_q8_0 *y) 
 static float vec_dot_q4_1_q8_1(int n, const block_q4_1 *x, const block_q8_1 *y) {
     const int nb = n / QK;
     float sumf = 0.0f;
-    for (int i = 0; i < nb; i++) {
+    BLOCK_LOOP(i, nb) {
         int sumi = 0;
         for (int j = 0; j < QK / 2; ++j) {
             const int v0 = (x[i].qs[j] & 0x0F);
@@ -471,7 +478,7 @@ static float vec_dot_q4_1_q8_1(int n, const block_q4_1 *x, const block_q8_1 *y) 
 static float vec_dot_q5_0_q8_0(int n, const block_q5_0 *x, const block_q8_0 *y) {
     const int nb = n / QK;
     float sumf = 0.0f;
-    for (int i = 0; i < nb; i++) {
+    BLOCK_LOOP(i, nb) {
         uint32_t qh;
         memcpy(&qh, x[i].qh, sizeof(qh));
         int sumi = 0;
@@ -489,7 +496,7 @@ static float vec_dot_q5_0_q8_0(int n, const block_q5_0 *x, const block_q8_0 *y) 
 static float vec_dot_q5_1_q8_1(int n, const block_q5_1 *x, const block_q8_1 *y) {
     const int nb = n / QK;
     float sumf = 0.0f;
-    for (int i = 0; i < nb; i++) {
+    BLOCK_LOOP(i, nb) {
         uint32_t qh;
         memcpy(&qh, x[i].qh, sizeof(qh));
         int sumi = 0;
@@ -507,7 +514,7 @@ static float vec_dot_q5_1_q8_1(int n, const block_q5_1 *x, const block_q8_1 *y) 
 static float vec_dot_q8_0_q8_0(int n, const block_q8_0 *x, const block_q8_0 *y) {
     const int nb = n / QK;
     float sumf = 0.0f;
-    for (int i = 0; i < nb; i++) {
+    BLOCK_LOOP(i, nb) {
         int sumi = 0;
         for (int j = 0; j < QK; j++) sumi += x[i].qs[j] * y[i].qs[j];
         sumf += sumi * (fp16_to_fp32(x[i].d) * fp16_to_fp32(y[i].d));

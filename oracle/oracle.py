@@ -63,6 +63,7 @@ def lib():
         L.orc_fp32_to_fp16_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_fp16_to_fp32_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_llama_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_set_block_order.argtypes = [C.c_int]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         # bound the OpenMP team: tiny parity cases on a 100+-core host spend their time in barrier spin
@@ -234,8 +235,17 @@ class Llama:
         m.memory_v = self.memory_v.ctypes.data
         self._m = m
 
-    def evaluate(self, tokens, mode=0, taps=False):
-        """Feeds `tokens` at the current n_past; returns logits f32 [N, n_vocab] (+ taps dict)."""
+    def evaluate(self, tokens, mode=0, taps=False, reverse_blocks=False):
+        """Feeds `tokens` at the current n_past; returns logits f32 [N, n_vocab] (+ taps dict).
+        reverse_blocks: add each row's block terms in descending order (a legal re-association of ggml's f32
+        block sum; the fwd-vs-rev distance is the yardstick for a model's own rounding sensitivity)."""
+        lib().orc_set_block_order(1 if reverse_blocks else 0)
+        try:
+            return self._evaluate(tokens, mode, taps)
+        finally:
+            lib().orc_set_block_order(0)
+
+    def _evaluate(self, tokens, mode, taps):
         hp = self.hp
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
         N = tokens.size
