@@ -474,8 +474,12 @@ enum ggml_hip_kclass {
 GGML_API void ggml_hip_timing_begin(void);
 GGML_API void ggml_hip_timing_end(void);
 GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes);
-/* Execution mode knobs (also settable by env GGML_HIP_FUSE / GGML_HIP_GRAPH / GGML_HIP_ACT). */
+/* Execution mode knobs: "fuse" (peephole fusion in the generic executor), "plan" (fused LLaMA decode plan),
+ * "graph" (hipGraph replay of the plan), "mmvq_rows"; also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH. */
 GGML_API void ggml_hip_set_option(const char *key, int value);
+/* Counters for tests: "plan_tokens" (tokens run by the fused decode plan), "graph_replays", "plans",
+ * "generic_graphs".  -1 for an unknown key. */
+GGML_API int64_t ggml_hip_get_stat(const char *key);
 GGML_API const char *ggml_hip_version(void);
 
 #ifdef __cplusplus

@@ -30,6 +30,7 @@
 #include "kernels/common.h"
 #include "kernels/mmvq.h"
 #include "kernels/ops.h"
+#include "kernels/decode.h"
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -115,6 +116,9 @@ struct Backend {
     // options
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
+    int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
+    int opt_graph = 1;      // replay the plan from a captured hipGraph
+    uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0;
     size_t dead_shadow_bytes = 0;
 } g;
 
@@ -141,6 +145,8 @@ void ensure_init() {
     HIP_CHECK(hipSetDevice(g.device));
     HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (const char *v = getenv("GGML_HIP_FUSE")) g.opt_fuse = atoi(v);
+    if (const char *v = getenv("GGML_HIP_PLAN")) g.opt_plan = atoi(v);
+    if (const char *v = getenv("GGML_HIP_GRAPH")) g.opt_graph = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMVQ_R")) g.opt_mmvq_rows = atoi(v);
     g.inited = true;
 }
@@ -484,7 +490,9 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill,
     return e;
 }
 
+void drop_all_plans();
 void destroy_record(DevTensor *e) {
+    drop_all_plans();  // cached decode plans hold device addresses of weight / KV records
     if (g.stream) HIP_CHECK(hipStreamSynchronize(g.stream));
     if (e->dev) HIP_CHECK(hipFree(e->dev));
     e->magic = 0;
@@ -905,10 +913,14 @@ void invalidate_qact_if_overwritten(const ggml_tensor *n) {
     if (b0 < a1 && a0 < b1) g_qact.valid = false;
 }
 
+#include "llama_plan.inc"
+
 void execute_graph(ggml_cgraph *gr) {
     ensure_init();
     ws_reset();
     g_qact.valid = false;
+    if (try_decode_plan(gr)) return;  // single-token LLaMA decode: fused launches + hipGraph replay
+    g.stat_generic_graphs++;
     upload_inputs(gr);
 
     std::map<const ggml_tensor *, int> idx;
@@ -1262,10 +1274,27 @@ void ggml_hip_set_option(const char *key, int value) {
     const std::string k(key);
     if (k == "fuse")
         g.opt_fuse = value;
+    else if (k == "plan")
+        g.opt_plan = value;
+    else if (k == "graph")
+        g.opt_graph = value;
     else if (k == "mmvq_rows")
         g.opt_mmvq_rows = value;
     else
         die("ggml_hip_set_option: unknown key '%s'", key);
+}
+int64_t ggml_hip_get_stat(const char *key) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    const std::string k(key);
+    if (k == "plan_tokens") return (int64_t)g.stat_plan_tokens;       // tokens executed by the fused decode plan
+    if (k == "graph_replays") {
+        int64_t n = 0;
+        for (auto *p : g_plans) n += (int64_t)p->replays;
+        return n;
+    }
+    if (k == "plans") return (int64_t)g_plans.size();
+    if (k == "generic_graphs") return (int64_t)g.stat_generic_graphs;  // graphs run node by node
+    return -1;
 }
 const char *ggml_hip_version(void) { return "libggml_hip 0.1 (gfx950)"; }
 

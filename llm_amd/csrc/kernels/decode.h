@@ -1,0 +1,344 @@
+// decode.h — fused kernels of the single-token (N=1) decode plan: what the LLaMA graph of
+// crates/models/llama/src/lib.rs:174-352 collapses to on MI355X once the ~37 ggml nodes per layer are
+// regrouped around the HBM-bound mat-vecs (launch-bound decode):
+//
+//   k_rmsnorm_quant      rms_norm → ·weight → re-quantize to Q8_0/Q8_1 (the INIT phase of the next mul_mat)
+//   k_mmvq_dec<EPI_QKV>  wq|wk|wv mat-vec → RoPE(Q,K) → Q to f32, K/V to the f16 KV cache (V transposed)
+//   k_attn_decode        K·Q → scale → mask → softmax → V·P → merge heads → re-quantize (input of wo)
+//   k_mmvq_dec<EPI_ADD>  wo / w2 mat-vec + residual add
+//   k_mmvq_dec<EPI_GATE> w1|w3 mat-vec → silu(w1x)·(w3x)
+//
+// Arithmetic is the same as the generic kernels (ops.h / mmvq.h), i.e. ggml's CPU semantics; only the
+// grouping differs.  Every kernel reads the position from device memory (DecParams) so that a captured
+// hipGraph can be replayed for the next token without patching kernel arguments.
+#pragma once
+#include "common.h"
+#include "mmvq.h"
+#include "ops.h"
+
+struct DecParams {
+    int n_past;   // tokens already in the KV cache = position of the token being decoded
+    int token;    // its id (row of tok_embeddings)
+    int pad[2];
+};
+
+// ---------------------------------------------------------------------------------------------------
+// rms_norm (f64 Σx², eps) → multiply by weight → optional f32 copy → Q8 re-quantization, one 1024-thread
+// workgroup for the single activation row.
+// ---------------------------------------------------------------------------------------------------
+template <bool F16_D>
+__global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict__ x, const float *__restrict__ w,
+                                                        float eps, int E, float *y_f32 /*nullable*/, int8_t *lo,
+                                                        int8_t *hi, float *dq, int *sumq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_y = (float *)smem;                 // E floats
+    __shared__ double s_part[16];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < E; i += 1024) {
+        const float v = x[i];
+        s += (double)(v * v);
+    }
+    s = wave_sum_f64(s);
+    if ((tid & 63) == 0) s_part[tid >> 6] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) tot += s_part[i];
+    const float mean = (float)(tot / (double)E);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    for (int i = tid; i < E; i += 1024) {
+        const float v = (x[i] * scale) * w[i];
+        s_y[i] = v;
+        if (y_f32) y_f32[i] = v;
+    }
+    __syncthreads();
+    const int nblk = E / 32, l = tid & 31;
+    for (int b = tid >> 5; b < nblk; b += 32) {
+        const float v = s_y[b * 32 + l];
+        float amax = fabsf(v);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        const float d = amax / 127.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        const int q = (int)roundf(v * id);
+        int sq = q;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        (l < 16 ? lo : hi)[b * 16 + (l & 15)] = (int8_t)q;
+        if (l == 0) {
+            dq[b] = F16_D ? round_f16(d) : d;
+            sumq[b] = sq;
+        }
+    }
+}
+
+// re-quantize a plain f32 row (the FFN gate before w2): 32 lanes per block
+template <bool F16_D>
+__global__ void __launch_bounds__(256) k_quant_row(const float *__restrict__ x, int nblk, int8_t *lo, int8_t *hi,
+                                                   float *dq, int *sumq) {
+    const int b = (blockIdx.x * 256 + threadIdx.x) >> 5, l = threadIdx.x & 31;
+    if (b >= nblk) return;
+    const float v = x[b * 32 + l];
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const int q = (int)roundf(v * id);
+    int sq = q;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    (l < 16 ? lo : hi)[b * 16 + (l & 15)] = (int8_t)q;
+    if (l == 0) {
+        dq[b] = F16_D ? round_f16(d) : d;
+        sumq[b] = sq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode mat-vec with fused epilogues.  One wave = one PAIR of consecutive rows (m0, m0+1) of each
+// weight matrix it serves; 4 waves per workgroup; x staged in LDS exactly like k_mmvq.
+// ---------------------------------------------------------------------------------------------------
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_GATE = 2, EPI_QKV = 3 };
+
+struct DecMmvqArgs {
+    QWeight w[3];        // STORE/ADD: w[0]; GATE: w[0]=w1, w[1]=w3; QKV: wq, wk, wv
+    int wg_begin[3];     // QKV: first workgroup of each segment
+    QAct x;
+    int64_t nb;          // K/32
+    float *dst;          // STORE/ADD/GATE output (f32); QKV: Q output [E] f32
+    const float *res;    // ADD: residual
+    // QKV epilogue
+    const DecParams *prm;
+    __half *mem_k;       // + layer offset: K element (pos p, chan c) at p*Egqa + c
+    __half *mem_v;       // + layer offset: V element (chan c, pos p) at c*C + p
+    int64_t Egqa, C;
+    int D;               // head size (rope row length)
+    float theta_scale, freq_scale;
+};
+
+// rows (m0, m0+1) of NW weight matrices (same K, same activation) in ONE pass over the blocks, so that all
+// 2*NW row streams have their loads in flight together
+template <int QT, int NW>
+__device__ __forceinline__ void dec_rows2(const QWeight *w, int64_t m0, int64_t nb, int lane, const i32x4 *s_lo,
+                                          const i32x4 *s_hi, const float *s_d, const int *s_sum, float (&acc)[NW][2]) {
+    int64_t r[NW][2];
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        acc[i][0] = acc[i][1] = 0.0f;
+        r[i][0] = m0 * nb;
+        r[i][1] = (m0 + 1 < w[i].M ? m0 + 1 : w[i].M - 1) * nb;
+    }
+    for (int64_t b = lane; b < nb; b += 64) {
+        u32x4 q[NW][2], p[NW][2];
+        uint32_t h[NW][2];
+        float dw[NW][2], mw[NW][2];
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int64_t o = r[i][j] + b;
+                q[i][j] = __builtin_nontemporal_load((const u32x4 *)(w[i].qs + o * 16));
+                if constexpr (QT == QT_Q8_0)
+                    p[i][j] = __builtin_nontemporal_load((const u32x4 *)(w[i].qs2 + o * 16));
+                else
+                    p[i][j] = q[i][j];
+                if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1)
+                    h[i][j] = __builtin_nontemporal_load(w[i].qh + o);
+                else
+                    h[i][j] = 0;
+                dw[i][j] = __half2float(w[i].d[o]);
+                if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1)
+                    mw[i][j] = __half2float(w[i].m[o]);
+                else
+                    mw[i][j] = 0.0f;
+            }
+        const i32x4 lo = s_lo[b], hi = s_hi[b];
+        const float xd = s_d[b];
+        const int xs = s_sum[b];
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                acc[i][j] += block_dot<QT>(q[i][j], p[i][j], h[i][j], dw[i][j], mw[i][j], lo, hi, xd, xs);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = wave_sum_f32(acc[i][j]);
+}
+
+template <int QT, int EPI>
+__global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t nb = a.nb;
+    i32x4 *s_lo = (i32x4 *)smem;
+    i32x4 *s_hi = s_lo + nb;
+    float *s_d = (float *)(s_hi + nb);
+    int *s_sum = (int *)(s_d + nb);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int64_t i = tid; i < nb; i += 256) {
+        s_lo[i] = a.x.lo[i];
+        s_hi[i] = a.x.hi[i];
+        s_d[i] = a.x.d[i];
+        s_sum[i] = a.x.sum[i];
+    }
+    __syncthreads();
+
+    int sg = 0;
+    if constexpr (EPI == EPI_QKV) {
+        if ((int)blockIdx.x >= a.wg_begin[1]) sg = 1;
+        if ((int)blockIdx.x >= a.wg_begin[2]) sg = 2;
+    }
+    const int wg = blockIdx.x - (EPI == EPI_QKV ? a.wg_begin[sg] : 0);
+    const int64_t m0 = ((int64_t)wg * 4 + wave) * 2;
+    const QWeight &w = a.w[sg];
+    if (m0 >= w.M) return;
+    const bool has1 = m0 + 1 < w.M;
+    float v0, v1, u0 = 0.0f, u1 = 0.0f;
+    if constexpr (EPI == EPI_GATE) {
+        float acc[2][2];  // rows of w1 and the same rows of w3
+        dec_rows2<QT, 2>(a.w, m0, nb, lane, s_lo, s_hi, s_d, s_sum, acc);
+        v0 = acc[0][0], v1 = acc[0][1], u0 = acc[1][0], u1 = acc[1][1];
+    } else {
+        float acc[1][2];
+        dec_rows2<QT, 1>(&w, m0, nb, lane, s_lo, s_hi, s_d, s_sum, acc);
+        v0 = acc[0][0], v1 = acc[0][1];
+    }
+
+    if constexpr (EPI == EPI_STORE) {
+        if (lane == 0) {
+            a.dst[m0] = v0;
+            if (has1) a.dst[m0 + 1] = v1;
+        }
+    } else if constexpr (EPI == EPI_ADD) {
+        if (lane == 0) {
+            a.dst[m0] = v0 + a.res[m0];
+            if (has1) a.dst[m0 + 1] = v1 + a.res[m0 + 1];
+        }
+    } else if constexpr (EPI == EPI_GATE) {
+        if (lane == 0) {
+            a.dst[m0] = silu_table(v0) * u0;
+            if (has1) a.dst[m0 + 1] = silu_table(v1) * u1;
+        }
+    } else {  // EPI_QKV
+        if (lane != 0) return;
+        const int p = a.prm->n_past;
+        if (sg == 2) {  // V: f16 into the transposed cache (llama lib.rs:234-244)
+            a.mem_v[m0 * a.C + p] = __float2half_rn(v0);
+            if (has1) a.mem_v[(m0 + 1) * a.C + p] = __float2half_rn(v1);
+            return;
+        }
+        // RoPE mode 0 on the adjacent pair (m0, m0+1): theta = freq_scale*p * theta_scale^k, iterated product
+        const int k = (int)(m0 % a.D) >> 1;
+        float theta = a.freq_scale * (float)p;
+        for (int j = 0; j < k; j++) theta *= a.theta_scale;
+        const float c = cosf(theta), s = sinf(theta);
+        const float r0 = v0 * c - v1 * s, r1 = v0 * s + v1 * c;
+        if (sg == 0) {
+            a.dst[m0] = r0;
+            a.dst[m0 + 1] = r1;
+        } else {  // K: f16, contiguous run at position p (llama lib.rs:228-243)
+            a.mem_k[(int64_t)p * a.Egqa + m0] = __float2half_rn(r0);
+            a.mem_k[(int64_t)p * a.Egqa + m0 + 1] = __float2half_rn(r1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode attention for one query token: one workgroup (256 threads) per head.
+//   s_t = Σ_d K[t][d]·f16(q[d])  (f32 accumulate)  for t = 0..P   (P = n_past, the new token included)
+//   p   = softmax(s·scale) with ggml's f16-rounded exp, then rounded to f16 (src1 of the V matmul)
+//   o_d = Σ_t V[d][t]·p_t ; the head's D outputs are re-quantized to Q8 blocks for the wo mat-vec and
+//   also written as f32 (merge-heads layout [E]).
+// K: [C][Egqa] f16 (per layer), V: [Egqa][C] f16 (per layer).  Dynamic LDS: (C + D) floats.
+// ---------------------------------------------------------------------------------------------------
+template <bool F16_D>
+__global__ void __launch_bounds__(256) k_attn_decode(const float *__restrict__ q, const __half *__restrict__ mem_k,
+                                                     const __half *__restrict__ mem_v, const DecParams *prm,
+                                                     float scale, int D, int n_rep /* H / Hkv */, int64_t Egqa,
+                                                     int64_t C, float *out_f32, int8_t *lo, int8_t *hi, float *dq,
+                                                     int *sumq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_s = (float *)smem;  // C scores / probabilities
+    float *s_o = s_s + C;        // D outputs
+    __shared__ float s_red[4];
+    __shared__ double s_redd[4];
+    const int h = blockIdx.x, hk = h / n_rep;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int T = prm->n_past + 1;
+    const float *qh = q + (int64_t)h * D;
+
+    // ---- scores: 16 lanes per position (8 halfs = 16 B each), 16 positions per workgroup pass ----
+    const int g = tid >> 4, gl = tid & 15;  // 16 groups of 16 lanes
+    // D <= 128 and D % 8 == 0 (checked by the plan builder): lane gl owns dims gl*8 .. gl*8+7
+    const int d0 = gl * 8;
+    const bool act = d0 < D;
+    float qf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) qf[j] = act ? round_f16(qh[d0 + j]) : 0.0f;  // ggml rounds src1 (Q) to f16
+    for (int t = g; t < T; t += 16) {
+        float s = 0.0f;
+        if (act) {
+            const __half *kr = mem_k + (int64_t)t * Egqa + (int64_t)hk * D + d0;
+            const uint4 kv = *(const uint4 *)kr;
+            const __half *kh = (const __half *)&kv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += __half2float(kh[j]) * qf[j];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (gl == 0) s_s[t] = s * scale;
+    }
+    __syncthreads();
+    // ---- softmax over T entries (ggml: max, f16-rounded exp of f16-rounded (x-max), f64 sum, scale by 1/sum) ----
+    float mx = -INFINITY;
+    for (int t = tid; t < T; t += 256) mx = fmaxf(mx, s_s[t]);
+    mx = wave_max_f32(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    double sum = 0.0;
+    for (int t = tid; t < T; t += 256) {
+        const float e = round_f16(expf(round_f16(s_s[t] - mx)));
+        s_s[t] = e;
+        sum += (double)e;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) s_redd[wave] = sum;
+    __syncthreads();
+    const float inv = (float)(1.0 / ((s_redd[0] + s_redd[1]) + (s_redd[2] + s_redd[3])));
+    for (int t = tid; t < T; t += 256) s_s[t] = round_f16(s_s[t] * inv);  // probabilities as f16 (src1 of V·P)
+    __syncthreads();
+    // ---- V·P: each wave owns D/4 channels; lanes run along positions ----
+    for (int d = wave; d < D; d += 4) {
+        const __half *vr = mem_v + ((int64_t)hk * D + d) * C;
+        float acc = 0.0f;
+        for (int t = lane; t < T; t += 64) acc += __half2float(vr[t]) * s_s[t];
+        acc = wave_sum_f32(acc);
+        if (lane == 0) s_o[d] = acc;
+    }
+    __syncthreads();
+    // ---- outputs: f32 (merged heads) + Q8 blocks (D/32 blocks per head) ----
+    const int nblk = D / 32, l = tid & 31, b = tid >> 5;
+    if (b < nblk) {
+        const float v = s_o[b * 32 + l];
+        if (out_f32) out_f32[(int64_t)h * D + b * 32 + l] = v;
+        float amax = fabsf(v);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        const float d = amax / 127.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        const int qv = (int)roundf(v * id);
+        int sq = qv;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const int64_t gb = (int64_t)h * nblk + b;
+        (l < 16 ? lo : hi)[gb * 16 + (l & 15)] = (int8_t)qv;
+        if (l == 0) {
+            dq[gb] = F16_D ? round_f16(d) : d;
+            sumq[gb] = sq;
+        }
+    }
+}

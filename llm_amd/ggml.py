@@ -211,6 +211,7 @@ PROTOTYPES.update({
     "ggml_hip_timing_end": (None, []),
     "ggml_hip_timing_query": (None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ggml_hip_set_option": (None, [C.c_char_p, C.c_int]),
+    "ggml_hip_get_stat": (C.c_int64, [C.c_char_p]),
     "ggml_hip_version": (C.c_char_p, []),
 })
 
