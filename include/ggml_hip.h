@@ -477,6 +477,10 @@ GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, d
 /* Execution mode knobs: "fuse" (peephole fusion in the generic executor), "plan" (fused LLaMA decode plan),
  * "graph" (hipGraph replay of the plan), "mmvq_rows"; also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH. */
 GGML_API void ggml_hip_set_option(const char *key, int value);
+/* Replays the launches of one kernel class of the most recent fused decode plan `replays` times from a
+ * dedicated hipGraph between two HIP events on the backend stream (bench.py roofline leg). 0 on success. */
+GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
+                                       double *algo_bytes_per_replay);
 /* Counters for tests: "plan_tokens" (tokens run by the fused decode plan), "graph_replays", "plans",
  * "generic_graphs".  -1 for an unknown key. */
 GGML_API int64_t ggml_hip_get_stat(const char *key);

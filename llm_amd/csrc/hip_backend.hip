@@ -1283,6 +1283,53 @@ void ggml_hip_set_option(const char *key, int value) {
     else
         die("ggml_hip_set_option: unknown key '%s'", key);
 }
+// Roofline leg of bench.py: replays the kernels of ONE class of the most recent decode plan (e.g. the 129
+// mat-vec launches of a LLaMA-7B token) `replays` times from a hipGraph that contains nothing else, bracketed
+// by two HIP events on the backend stream.  Per-launch event pairs would add several µs of marker overhead
+// to kernels that run for 2-15 µs; this measures the launches back to back instead (inter-kernel boundaries
+// included, which rocprof's per-kernel durations exclude).  KV writes of the replay go to the last cache slot.
+int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
+                              double *algo_bytes_per_replay) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (g_plans.empty() || kclass < 0 || kclass >= GGML_HIP_KCLASS_COUNT || replays < 1) return -1;
+    DecodePlan *p = g_plans.back();
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    DecParams saved, park;
+    HIP_CHECK(hipMemcpy(&saved, p->prm, sizeof(saved), hipMemcpyDeviceToHost));
+    park = saved;
+    if (kclass == GGML_HIP_KCLASS_MMVQ) park.n_past = (int)p->m.C - 1;  // K/V stores go to a scratch slot
+    HIP_CHECK(hipMemcpy(p->prm, &park, sizeof(park), hipMemcpyHostToDevice));
+    PlanStats st;
+    hipGraph_t gr = nullptr;
+    hipGraphExec_t ex = nullptr;
+    const bool was_on = g.timing.on;
+    g.timing.on = false;
+    HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+    plan_launch_all(p, 1u << kclass, &st);
+    HIP_CHECK(hipStreamEndCapture(g.stream, &gr));
+    HIP_CHECK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipGraphLaunch(ex, g.stream));  // warm
+    HIP_CHECK(hipEventRecord(a, g.stream));
+    for (int i = 0; i < replays; i++) HIP_CHECK(hipGraphLaunch(ex, g.stream));
+    HIP_CHECK(hipEventRecord(b, g.stream));
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    HIP_CHECK(hipEventDestroy(a));
+    HIP_CHECK(hipEventDestroy(b));
+    HIP_CHECK(hipGraphExecDestroy(ex));
+    HIP_CHECK(hipGraphDestroy(gr));
+    HIP_CHECK(hipMemcpy(p->prm, &saved, sizeof(saved), hipMemcpyHostToDevice));
+    g.timing.on = was_on;
+    if (ms_total) *ms_total = ms;
+    if (launches_per_replay) *launches_per_replay = st.launches[kclass];
+    if (algo_bytes_per_replay) *algo_bytes_per_replay = st.bytes[kclass];
+    return 0;
+}
+
 int64_t ggml_hip_get_stat(const char *key) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     const std::string k(key);

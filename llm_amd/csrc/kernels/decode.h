@@ -278,18 +278,26 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float *__restrict__ q
     float qf[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) qf[j] = act ? round_f16(qh[d0 + j]) : 0.0f;  // ggml rounds src1 (Q) to f16
-    for (int t = g; t < T; t += 16) {
-        float s = 0.0f;
-        if (act) {
-            const __half *kr = mem_k + (int64_t)t * Egqa + (int64_t)hk * D + d0;
-            const uint4 kv = *(const uint4 *)kr;
-            const __half *kh = (const __half *)&kv;
+    // 4 positions per group and pass: the four 16-byte K loads are issued before any of them is consumed
+    for (int t0 = g; t0 < T; t0 += 64) {
+        uint4 kv[4];
 #pragma unroll
-            for (int j = 0; j < 8; j++) s += __half2float(kh[j]) * qf[j];
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + 16 * u;
+            kv[u] = make_uint4(0, 0, 0, 0);
+            if (act && t < T) kv[u] = *(const uint4 *)(mem_k + (int64_t)t * Egqa + (int64_t)hk * D + d0);
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (gl == 0) s_s[t] = s * scale;
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + 16 * u;
+            const __half *kh = (const __half *)&kv[u];
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += __half2float(kh[j]) * qf[j];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (gl == 0 && t < T) s_s[t] = s * scale;
+        }
     }
     __syncthreads();
     // ---- softmax over T entries (ggml: max, f16-rounded exp of f16-rounded (x-max), f64 sum, scale by 1/sum) ----
@@ -311,13 +319,39 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float *__restrict__ q
     const float inv = (float)(1.0 / ((s_redd[0] + s_redd[1]) + (s_redd[2] + s_redd[3])));
     for (int t = tid; t < T; t += 256) s_s[t] = round_f16(s_s[t] * inv);  // probabilities as f16 (src1 of V·P)
     __syncthreads();
-    // ---- V·P: each wave owns D/4 channels; lanes run along positions ----
-    for (int d = wave; d < D; d += 4) {
-        const __half *vr = mem_v + ((int64_t)hk * D + d) * C;
-        float acc = 0.0f;
-        for (int t = lane; t < T; t += 64) acc += __half2float(vr[t]) * s_s[t];
-        acc = wave_sum_f32(acc);
-        if (lane == 0) s_o[d] = acc;
+    // ---- V·P: each wave owns D/4 channels, 8 at a time; a lane covers 8 consecutive positions with one
+    // 16-byte load per channel, so 8 independent loads are in flight per lane ----
+    const int T8 = (T + 7) & ~7;
+    for (int t = T + tid; t < T8; t += 256) s_s[t] = 0.0f;  // padding positions contribute nothing
+    __syncthreads();
+    for (int c0 = 0; c0 < D / 4; c0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc[u] = 0.0f;
+        for (int tb = lane * 8; tb < T8; tb += 512) {
+            uint4 vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                vv[u] = *(const uint4 *)(mem_v + ((int64_t)hk * D + wave + 4 * (c0 + u)) * C + tb);
+            const f32x4 p0 = *(const f32x4 *)(s_s + tb), p1 = *(const f32x4 *)(s_s + tb + 4);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const __half *vh = (const __half *)&vv[u];
+                acc[u] += __half2float(vh[0]) * p0[0];
+                acc[u] += __half2float(vh[1]) * p0[1];
+                acc[u] += __half2float(vh[2]) * p0[2];
+                acc[u] += __half2float(vh[3]) * p0[3];
+                acc[u] += __half2float(vh[4]) * p1[0];
+                acc[u] += __half2float(vh[5]) * p1[1];
+                acc[u] += __half2float(vh[6]) * p1[2];
+                acc[u] += __half2float(vh[7]) * p1[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float r = wave_sum_f32(acc[u]);
+            if (lane == 0) s_o[wave + 4 * (c0 + u)] = r;
+        }
     }
     __syncthreads();
     // ---- outputs: f32 (merged heads) + Q8 blocks (D/32 blocks per head) ----

@@ -212,6 +212,8 @@ PROTOTYPES.update({
     "ggml_hip_timing_query": (None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ggml_hip_set_option": (None, [C.c_char_p, C.c_int]),
     "ggml_hip_get_stat": (C.c_int64, [C.c_char_p]),
+    "ggml_hip_bench_plan_class": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_double)]),
     "ggml_hip_version": (C.c_char_p, []),
 })
 
@@ -425,6 +427,15 @@ class Graph:
         work = self.ctx.new_tensor(TYPE_I8, max(plan.work_size, 0))
         plan.work_data = work.t.data
         return lib().ggml_graph_compute(self.ptr, C.byref(plan))
+
+
+def bench_plan_class(kclass, replays):
+    """(ms_total, launches_per_replay, algo_bytes_per_replay) of one kernel class of the last decode plan."""
+    ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
+    rc = lib().ggml_hip_bench_plan_class(kclass, replays, C.byref(ms), C.byref(n), C.byref(b))
+    if rc != 0:
+        raise RuntimeError("no fused decode plan to benchmark (the decode graph was not recognised)")
+    return ms.value, n.value, b.value
 
 
 def timing_query(kclass):
