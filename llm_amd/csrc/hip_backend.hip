@@ -79,6 +79,7 @@ struct DevTensor {
     size_t dev_bytes = 0;
     bool soa = false;             // quantized SoA layout (see QWeight)
     bool auto_uploaded = false;
+    uintptr_t owner_hdr = 0;      // auto-uploaded only: address of the ggml_tensor header that named this data
     QWeight qw{};
     ggml_type type = GGML_TYPE_F32;
     int64_t ne[4] = {0, 0, 0, 0};
@@ -872,7 +873,8 @@ void upload_inputs(ggml_cgraph *gr) {
         const uintptr_t p = (uintptr_t)leaf->data;
         if (DevTensor *e = find_tensor(p)) {
             // auto-uploaded earlier; make sure it still describes this tensor
-            if (e->auto_uploaded && (e->host != p || e->nbytes != ggml_nbytes(leaf) || e->type != leaf->type)) {
+            if (e->auto_uploaded && (e->host != p || e->nbytes != ggml_nbytes(leaf) || e->type != leaf->type ||
+                                     e->owner_hdr != (uintptr_t)leaf)) {
                 free_dev_tensor(e);
             } else {
                 continue;
@@ -887,7 +889,7 @@ void upload_inputs(ggml_cgraph *gr) {
             h2d_small(dev_ptr(leaf), leaf->data, nbytes);
         } else {
             // persistent tensor (weight / KV memory) that was never offloaded by the caller: upload once
-            upload_tensor(leaf->data, leaf, false, /*is_auto=*/true);
+            upload_tensor(leaf->data, leaf, false, /*is_auto=*/true)->owner_hdr = (uintptr_t)leaf;
         }
     }
 }
@@ -1041,6 +1043,17 @@ extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
     Arena &a = it->second;
     // auto-uploaded persistent tensors whose host bytes lived in this arena die with it
     evict_overlapping(g.auto_tensors, a.base, a.size);
+    // ... and so do those whose tensor HEADER lived here (e.g. mmap'd weights named by a model context): once the
+    // context is freed nothing can refer to them any more, and the host bytes may be recycled with new content
+    for (auto jt = g.auto_tensors.begin(); jt != g.auto_tensors.end();) {
+        DevTensor *e = jt->second;
+        if (e->owner_hdr >= a.base && e->owner_hdr < a.base + a.size) {
+            jt = g.auto_tensors.erase(jt);
+            destroy_record(e);
+        } else {
+            ++jt;
+        }
+    }
     a.live = false;
     if (a.dev) {
         g.dead_shadow_bytes += a.size;
