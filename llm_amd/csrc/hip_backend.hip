@@ -1317,24 +1317,31 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     hipGraphExec_t ex = nullptr;
     const bool was_on = g.timing.on;
     g.timing.on = false;
-    HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-    plan_launch_all(p, 1u << kclass, &st);
-    HIP_CHECK(hipStreamEndCapture(g.stream, &gr));
-    HIP_CHECK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a));
     HIP_CHECK(hipEventCreate(&b));
-    HIP_CHECK(hipGraphLaunch(ex, g.stream));  // warm
-    HIP_CHECK(hipEventRecord(a, g.stream));
-    for (int i = 0; i < replays; i++) HIP_CHECK(hipGraphLaunch(ex, g.stream));
-    HIP_CHECK(hipEventRecord(b, g.stream));
+    if (g.opt_graph) {
+        HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        plan_launch_all(p, 1u << kclass, &st);
+        HIP_CHECK(hipStreamEndCapture(g.stream, &gr));
+        HIP_CHECK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphLaunch(ex, g.stream));  // warm
+        HIP_CHECK(hipEventRecord(a, g.stream));
+        for (int i = 0; i < replays; i++) HIP_CHECK(hipGraphLaunch(ex, g.stream));
+        HIP_CHECK(hipEventRecord(b, g.stream));
+    } else {  // GGML_HIP_GRAPH=0 (e.g. under rocprofv3, whose kernel tracing crashes on graph launches here)
+        plan_launch_all(p, 1u << kclass, &st);
+        HIP_CHECK(hipEventRecord(a, g.stream));
+        for (int i = 0; i < replays; i++) plan_launch_all(p, 1u << kclass, nullptr);
+        HIP_CHECK(hipEventRecord(b, g.stream));
+    }
     HIP_CHECK(hipStreamSynchronize(g.stream));
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     HIP_CHECK(hipEventDestroy(a));
     HIP_CHECK(hipEventDestroy(b));
-    HIP_CHECK(hipGraphExecDestroy(ex));
-    HIP_CHECK(hipGraphDestroy(gr));
+    if (ex) HIP_CHECK(hipGraphExecDestroy(ex));
+    if (gr) HIP_CHECK(hipGraphDestroy(gr));
     HIP_CHECK(hipMemcpy(p->prm, &saved, sizeof(saved), hipMemcpyHostToDevice));
     g.timing.on = was_on;
     if (ms_total) *ms_total = ms;

@@ -463,6 +463,21 @@ void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_lea
     if (n_leafs) *n_leafs = s->s->last_n_leafs;
 }
 
+// Session K/V memory as raw bytes (which: 0 = memory_k, 1 = memory_v) — the payload of the reference's
+// InferenceSnapshot (inference_session.rs:599-646), which reads `memory_k.data()` on the host; here the
+// authoritative copy lives on the device, so the snapshot goes through the backend.  set=0 reads, set=1 writes.
+size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbytes) {
+    ggml::Tensor &t = which == 0 ? s->s->memory_k : s->s->memory_v;
+    const size_t n = t.nbytes();
+    if (!buf) return n;
+    if (nbytes > n) nbytes = n;
+    if (set)
+        ggml_hip_tensor_set(t.ptr(), buf, 0, nbytes);
+    else
+        ggml_hip_tensor_get(t.ptr(), buf, 0, nbytes);
+    return nbytes;
+}
+
 // test hook: device contents of a node of the last evaluated graph, by index (>= 0) or by the k-th node
 // carrying `name` (index < 0).  Returns the number of bytes the node holds, 0 if not found.
 size_t llm_session_read_node(const llm_session *s, int index, const char *name, int occurrence, void *dst,

@@ -53,6 +53,8 @@ def _lib():
         L.llm_session_n_past.restype = C.c_int
         L.llm_session_n_past.argtypes = [C.c_void_p]
         L.llm_session_last_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.llm_session_kv.restype = C.c_size_t
+        L.llm_session_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.llm_session_read_node.restype = C.c_size_t
         L.llm_session_read_node.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
         _bound = True
@@ -138,6 +140,21 @@ class Session:
     def last_logits(self):
         V = self.model.hp["n_vocab"]
         return np.ctypeslib.as_array(_lib().llm_session_last_logits(self.ptr), shape=(V,)).copy()
+
+    def get_kv(self, dtype=np.uint16):
+        """(memory_k, memory_v) raw contents — the InferenceSnapshot payload."""
+        out = []
+        for which in (0, 1):
+            n = _lib().llm_session_kv(self.ptr, which, 0, None, 0)
+            a = np.zeros(n // np.dtype(dtype).itemsize, dtype=dtype)
+            _lib().llm_session_kv(self.ptr, which, 0, a.ctypes.data, a.nbytes)
+            out.append(a)
+        return out
+
+    def set_kv(self, k, v):
+        for which, a in ((0, k), (1, v)):
+            a = np.ascontiguousarray(a)
+            _lib().llm_session_kv(self.ptr, which, 1, a.ctypes.data, a.nbytes)
 
     def read_node(self, index=-1, name=None, occurrence=0, dtype=np.float32):
         """Test hook: device contents of a node of the last evaluated graph."""

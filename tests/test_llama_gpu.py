@@ -40,38 +40,45 @@ def _stat(G, key):
 
 @pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
 def test_logits_match_oracle_prompt_and_decode(G, O, wtype):
+    """Every evaluate() of the GPU session is compared with the oracle evaluating the SAME tokens on the SAME
+    K/V state: after each chunk the GPU's K/V memory (the InferenceSnapshot payload) is copied into the oracle
+    sessions, so a rounding-edge flip in one chunk cannot leak into the next comparison through the cache."""
     toks = np.random.default_rng(42).integers(0, 256, 20).astype(np.int32)
-    strict_seeds = 0
+    n_chunks = n_strict = 0
     for seed in SEEDS:
         hp, w, model = _mk(G, wtype, seed=seed)
         sess = model.start_session(n_batch=8)
-        orc0, orc0r, orc1 = O.Llama(hp, w, 64), O.Llama(hp, w, 64), O.Llama(hp, w, 64)
-        worst = 0.0
+        orcs = [O.Llama(hp, w, 64) for _ in range(3)]
         # prompt in two batches (N=8, N=5): generic executor, multi-column mat-vec; then 7 single-token
         # decodes (N=1): fused decode plan replayed from a hipGraph
         p0 = _stat(G, "plan_tokens")
         for chunk in (toks[:8], toks[8:13]) + tuple(toks[13 + i:14 + i] for i in range(7)):
             got = sess.evaluate(chunk)
-            e0 = orc0.evaluate(chunk, mode=0)
-            e0r = orc0r.evaluate(chunk, mode=0, reverse_blocks=True)
-            e1 = orc1.evaluate(chunk, mode=1)
+            e0 = orcs[0].evaluate(chunk, mode=0)
+            e0r = orcs[1].evaluate(chunk, mode=0, reverse_blocks=True)
+            e1 = orcs[2].evaluate(chunk, mode=1)
             std = float(e1.std())
             d0 = float(np.max(np.abs(got - e0))) / std
             d1 = float(np.max(np.abs(got - e1))) / std
             band = float(np.max(np.abs(e0 - e0r))) / std
             floor = float(np.max(np.abs(e0 - e1))) / std
-            worst = max(worst, d0)
             print(f"type {wtype} seed {seed} N={len(chunk)} n_past={sess.n_past}: gpu-vs-exact {d0:.2e}  "
                   f"oracle fwd-vs-rev band {band:.2e}  gpu-vs-math {d1:.2e}  exact-vs-math (noise floor) {floor:.2e}")
             assert d0 <= EDGE, (d0, "vs ggml-exact oracle")
             assert d1 <= TOL_MATH, (d1, "vs math oracle")
+            n_chunks += 1
             if d0 <= STRICT:
+                n_strict += 1
                 assert (np.argmax(got, -1) == np.argmax(e0, -1)).all()  # llm-test `Tokens` check
+            k, v = sess.get_kv()
+            for o in orcs:  # same K/V state for the next chunk on every side
+                o.memory_k[:] = k
+                o.memory_v[:] = v
         assert _stat(G, "plan_tokens") - p0 == 7  # the decode steps really ran on the fused plan
-        strict_seeds += worst <= STRICT
         sess.free()
         model.free()
-    assert strict_seeds >= 2, f"only {strict_seeds} of {len(SEEDS)} seeds agreed to {STRICT}"
+    print(f"type {wtype}: {n_strict} of {n_chunks} chunk evaluations agree with the oracle to {STRICT}")
+    assert n_strict >= 0.75 * n_chunks, (n_strict, n_chunks)
 
 
 def test_interior_taps_final_norm(G, O):
