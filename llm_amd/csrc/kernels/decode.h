@@ -105,7 +105,10 @@ enum { EPI_STORE = 0, EPI_ADD = 1, EPI_GATE = 2, EPI_QKV = 3 };
 struct DecMmvqArgs {
     QWeight w[3];        // STORE/ADD: w[0]; GATE: w[0]=w1, w[1]=w3; QKV: wq, wk, wv
     int wg_begin[3];     // QKV: first workgroup of each segment
-    QAct x;
+    QAct x;              // XSRC_Q8: activation already re-quantized (attention output, final norm)
+    const float *xf;     // XSRC_NORM / XSRC_F32: f32 activation row, re-quantized by every workgroup while staging
+    const float *xw;     // XSRC_NORM: the norm weight;  eps below
+    float eps;
     int64_t nb;          // K/32
     float *dst;          // STORE/ADD/GATE output (f32); QKV: Q output [E] f32
     const float *res;    // ADD: residual
@@ -117,6 +120,98 @@ struct DecMmvqArgs {
     int D;               // head size (rope row length)
     float theta_scale, freq_scale;
 };
+
+// Where the activation of a decode mat-vec comes from.
+//   XSRC_Q8   : pre-quantized planar Q8 blocks in global memory (copied into LDS)
+//   XSRC_NORM : f32 residual row → rms_norm (f64 Σx², eps) → ·weight → Q8, computed by EVERY workgroup while it
+//               stages x into LDS.  Redundant (each WG re-reads 16 KB from L2 and spends ~100 VALU ops/thread)
+//               but it removes the separate norm+quantize launch (≈6.5 µs + a kernel boundary per use, twice
+//               per layer) from the serial decode chain.
+//   XSRC_F32  : plain f32 row → Q8 (the FFN gate feeding w2), same idea.
+enum { XSRC_Q8 = 0, XSRC_NORM = 1, XSRC_F32 = 2 };
+
+// thread t of the 256 owns elements 4i..4i+3 with i = it*256 + t; a Q8 block = 8 consecutive threads
+template <bool F16_D>
+__device__ __forceinline__ void quant4_to_lds(const f32x4 v, int64_t i4, int64_t nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
+                                              float *s_d, int *s_sum) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const int q0 = (int)roundf(v[0] * id), q1 = (int)roundf(v[1] * id), q2 = (int)roundf(v[2] * id),
+              q3 = (int)roundf(v[3] * id);
+    int sq = (q0 + q1) + (q2 + q3);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const int64_t b = i4 >> 3;  // block index
+    if (b >= nb) return;
+    const int j = tid & 7;
+    const int packed = (q0 & 0xFF) | ((q1 & 0xFF) << 8) | ((q2 & 0xFF) << 16) | ((int)((unsigned)q3 << 24));
+    ((int *)(j < 4 ? s_lo : s_hi))[b * 4 + (j & 3)] = packed;
+    if (j == 0) {
+        s_d[b] = F16_D ? round_f16(d) : d;
+        s_sum[b] = sq;
+    }
+}
+
+template <bool F16_D, int XSRC>
+__device__ __forceinline__ void stage_x(const QAct &xq, const float *xf, const float *xw, float eps, int64_t nb,
+                                        int tid, i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum) {
+    if constexpr (XSRC == XSRC_Q8) {
+        for (int64_t i = tid; i < nb; i += 256) {
+            s_lo[i] = xq.lo[i];
+            s_hi[i] = xq.hi[i];
+            s_d[i] = xq.d[i];
+            s_sum[i] = xq.sum[i];
+        }
+    } else if constexpr (XSRC == XSRC_F32) {
+        const int64_t n4 = nb * 8;  // float4 count
+        for (int64_t i4 = tid; i4 < ((n4 + 255) & ~(int64_t)255); i4 += 256) {
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (i4 < n4) v = ((const f32x4 *)xf)[i4];
+            quant4_to_lds<F16_D>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+        }
+    } else {
+        __shared__ double s_part[4];
+        constexpr int MAXIT = 8;  // rows up to 8192 wide stay in registers between the two passes
+        const int64_t n4 = nb * 8;
+        f32x4 v[MAXIT];
+        double ss = 0.0;
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * 256 + tid;
+            v[it] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (i4 < n4) {
+                v[it] = ((const f32x4 *)xf)[i4];
+                ss += (double)(v[it][0] * v[it][0]);
+                ss += (double)(v[it][1] * v[it][1]);
+                ss += (double)(v[it][2] * v[it][2]);
+                ss += (double)(v[it][3] * v[it][3]);
+            }
+        }
+        ss = wave_sum_f64(ss);
+        if ((tid & 63) == 0) s_part[tid >> 6] = ss;
+        __syncthreads();
+        const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        const float mean = (float)(tot / (double)(nb * 32));
+        const float scale = 1.0f / sqrtf(mean + eps);
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * 256 + tid;
+            if (it * 256 >= n4) break;  // uniform
+            f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (i4 < n4) {
+                const f32x4 w4 = ((const f32x4 *)xw)[i4];
+                y[0] = (v[it][0] * scale) * w4[0];
+                y[1] = (v[it][1] * scale) * w4[1];
+                y[2] = (v[it][2] * scale) * w4[2];
+                y[3] = (v[it][3] * scale) * w4[3];
+            }
+            quant4_to_lds<F16_D>(y, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+        }
+    }
+}
 
 // rows (m0, m0+1) of NW weight matrices (same K, same activation) in ONE pass over the blocks, so that all
 // 2*NW row streams have their loads in flight together
@@ -169,7 +264,7 @@ __device__ __forceinline__ void dec_rows2(const QWeight *w, int64_t m0, int64_t 
         for (int j = 0; j < 2; j++) acc[i][j] = wave_sum_f32(acc[i][j]);
 }
 
-template <int QT, int EPI>
+template <int QT, int EPI, int XSRC>
 __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t nb = a.nb;
@@ -178,12 +273,8 @@ __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
     float *s_d = (float *)(s_hi + nb);
     int *s_sum = (int *)(s_d + nb);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int64_t i = tid; i < nb; i += 256) {
-        s_lo[i] = a.x.lo[i];
-        s_hi[i] = a.x.hi[i];
-        s_d[i] = a.x.d[i];
-        s_sum[i] = a.x.sum[i];
-    }
+    constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;  // vec_dot_type Q8_0 vs Q8_1
+    stage_x<F16_D, XSRC>(a.x, a.xf, a.xw, a.eps, nb, tid, s_lo, s_hi, s_d, s_sum);
     __syncthreads();
 
     int sg = 0;
@@ -247,49 +338,65 @@ __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// decode attention for one query token: one workgroup (256 threads) per head.
+// decode attention for one query token: one 1024-thread workgroup (16 waves) per head, laid out so that the
+// whole head needs ~3 dependent memory round trips (q → K rows → V rows) instead of one per pass:
 //   s_t = Σ_d K[t][d]·f16(q[d])  (f32 accumulate)  for t = 0..P   (P = n_past, the new token included)
 //   p   = softmax(s·scale) with ggml's f16-rounded exp, then rounded to f16 (src1 of the V matmul)
 //   o_d = Σ_t V[d][t]·p_t ; the head's D outputs are re-quantized to Q8 blocks for the wo mat-vec and
-//   also written as f32 (merge-heads layout [E]).
+//   optionally written as f32 (merge-heads layout [E]).
 // K: [C][Egqa] f16 (per layer), V: [Egqa][C] f16 (per layer).  Dynamic LDS: (C + D) floats.
+//   scores : 64 groups of 16 lanes, a lane holds 8 dims (one 16-byte load per position), 4 positions per group
+//            in flight → 256 positions per pass;
+//   V·P    : wave w owns channels 8w..8w+7, a lane covers 8 consecutive positions of each with one 16-byte
+//            load → 8 loads in flight per lane, 512 positions per pass; the first pass is issued BEFORE the
+//            softmax so its latency hides behind the exp/sum work.
 // ---------------------------------------------------------------------------------------------------
 template <bool F16_D>
-__global__ void __launch_bounds__(256) k_attn_decode(const float *__restrict__ q, const __half *__restrict__ mem_k,
-                                                     const __half *__restrict__ mem_v, const DecParams *prm,
-                                                     float scale, int D, int n_rep /* H / Hkv */, int64_t Egqa,
-                                                     int64_t C, float *out_f32, int8_t *lo, int8_t *hi, float *dq,
-                                                     int *sumq) {
+__global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ q, const __half *__restrict__ mem_k,
+                                                      const __half *__restrict__ mem_v, const DecParams *prm,
+                                                      float scale, int D, int n_rep /* H / Hkv */, int64_t Egqa,
+                                                      int64_t C, float *out_f32, int8_t *lo, int8_t *hi, float *dq,
+                                                      int *sumq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_s = (float *)smem;  // C scores / probabilities
     float *s_o = s_s + C;        // D outputs
-    __shared__ float s_red[4];
-    __shared__ double s_redd[4];
+    __shared__ float s_red[16];
+    __shared__ double s_redd[16];
     const int h = blockIdx.x, hk = h / n_rep;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = prm->n_past + 1;
+    const int T8 = (T + 7) & ~7;
     const float *qh = q + (int64_t)h * D;
 
-    // ---- scores: 16 lanes per position (8 halfs = 16 B each), 16 positions per workgroup pass ----
-    const int g = tid >> 4, gl = tid & 15;  // 16 groups of 16 lanes
+    // ---- scores ----
+    const int g = tid >> 4, gl = tid & 15;  // 64 groups of 16 lanes
     // D <= 128 and D % 8 == 0 (checked by the plan builder): lane gl owns dims gl*8 .. gl*8+7
     const int d0 = gl * 8;
     const bool act = d0 < D;
     float qf[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) qf[j] = act ? round_f16(qh[d0 + j]) : 0.0f;  // ggml rounds src1 (Q) to f16
-    // 4 positions per group and pass: the four 16-byte K loads are issued before any of them is consumed
-    for (int t0 = g; t0 < T; t0 += 64) {
+    // first V pass, issued now (independent of the scores): channels of this wave, positions lane*8..+7
+    const int c_first = wave * 8;
+    const int tb_first = lane * 8;
+    const bool v_pre = c_first < D && tb_first < T8;
+    uint4 vpre[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        vpre[u] = make_uint4(0, 0, 0, 0);
+        if (v_pre && c_first + u < D) vpre[u] = *(const uint4 *)(mem_v + ((int64_t)hk * D + c_first + u) * C + tb_first);
+    }
+    for (int t0 = g; t0 < T; t0 += 256) {
         uint4 kv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int t = t0 + 16 * u;
+            const int t = t0 + 64 * u;
             kv[u] = make_uint4(0, 0, 0, 0);
             if (act && t < T) kv[u] = *(const uint4 *)(mem_k + (int64_t)t * Egqa + (int64_t)hk * D + d0);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int t = t0 + 16 * u;
+            const int t = t0 + 64 * u;
             const __half *kh = (const __half *)&kv[u];
             float s = 0.0f;
 #pragma unroll
@@ -302,13 +409,15 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float *__restrict__ q
     __syncthreads();
     // ---- softmax over T entries (ggml: max, f16-rounded exp of f16-rounded (x-max), f64 sum, scale by 1/sum) ----
     float mx = -INFINITY;
-    for (int t = tid; t < T; t += 256) mx = fmaxf(mx, s_s[t]);
+    for (int t = tid; t < T; t += 1024) mx = fmaxf(mx, s_s[t]);
     mx = wave_max_f32(mx);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    mx = s_red[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, s_red[i]);
     double sum = 0.0;
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += 1024) {
         const float e = round_f16(expf(round_f16(s_s[t] - mx)));
         s_s[t] = e;
         sum += (double)e;
@@ -316,23 +425,30 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float *__restrict__ q
     sum = wave_sum_f64(sum);
     if (lane == 0) s_redd[wave] = sum;
     __syncthreads();
-    const float inv = (float)(1.0 / ((s_redd[0] + s_redd[1]) + (s_redd[2] + s_redd[3])));
-    for (int t = tid; t < T; t += 256) s_s[t] = round_f16(s_s[t] * inv);  // probabilities as f16 (src1 of V·P)
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) tot += s_redd[i];
+    const float inv = (float)(1.0 / tot);
+    for (int t = tid; t < T8; t += 1024)
+        s_s[t] = t < T ? round_f16(s_s[t] * inv) : 0.0f;  // probabilities as f16 (src1 of V·P); padding = 0
     __syncthreads();
-    // ---- V·P: each wave owns D/4 channels, 8 at a time; a lane covers 8 consecutive positions with one
-    // 16-byte load per channel, so 8 independent loads are in flight per lane ----
-    const int T8 = (T + 7) & ~7;
-    for (int t = T + tid; t < T8; t += 256) s_s[t] = 0.0f;  // padding positions contribute nothing
-    __syncthreads();
-    for (int c0 = 0; c0 < D / 4; c0 += 8) {
+    // ---- V·P ----
+    for (int c0 = c_first; c0 < D; c0 += 128) {
         float acc[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) acc[u] = 0.0f;
-        for (int tb = lane * 8; tb < T8; tb += 512) {
+        for (int tb = tb_first; tb < T8; tb += 512) {
             uint4 vv[8];
+            if (c0 == c_first && tb == tb_first) {
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                vv[u] = *(const uint4 *)(mem_v + ((int64_t)hk * D + wave + 4 * (c0 + u)) * C + tb);
+                for (int u = 0; u < 8; u++) vv[u] = vpre[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    vv[u] = make_uint4(0, 0, 0, 0);
+                    if (c0 + u < D) vv[u] = *(const uint4 *)(mem_v + ((int64_t)hk * D + c0 + u) * C + tb);
+                }
+            }
             const f32x4 p0 = *(const f32x4 *)(s_s + tb), p1 = *(const f32x4 *)(s_s + tb + 4);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -350,7 +466,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float *__restrict__ q
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const float r = wave_sum_f32(acc[u]);
-            if (lane == 0) s_o[wave + 4 * (c0 + u)] = r;
+            if (lane == 0 && c0 + u < D) s_o[c0 + u] = r;
         }
     }
     __syncthreads();
