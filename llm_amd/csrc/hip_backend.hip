@@ -119,6 +119,7 @@ struct Backend {
     int opt_mmvq_rows = 0;  // 0 = auto
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
     int opt_graph = 1;      // replay the plan from a captured hipGraph
+    int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
     uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0;
     size_t dead_shadow_bytes = 0;
 } g;
@@ -148,6 +149,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_FUSE")) g.opt_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN")) g.opt_plan = atoi(v);
     if (const char *v = getenv("GGML_HIP_GRAPH")) g.opt_graph = atoi(v);
+    if (const char *v = getenv("GGML_HIP_XSRC")) g.opt_xsrc = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMVQ_R")) g.opt_mmvq_rows = atoi(v);
     g.inited = true;
 }
@@ -1291,6 +1293,10 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_plan = value;
     else if (k == "graph")
         g.opt_graph = value;
+    else if (k == "xsrc") {
+        if (g.opt_xsrc != value) drop_all_plans();
+        g.opt_xsrc = value;
+    }
     else if (k == "mmvq_rows")
         g.opt_mmvq_rows = value;
     else

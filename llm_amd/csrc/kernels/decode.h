@@ -348,8 +348,7 @@ __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
 //   scores : 64 groups of 16 lanes, a lane holds 8 dims (one 16-byte load per position), 4 positions per group
 //            in flight → 256 positions per pass;
 //   V·P    : wave w owns channels 8w..8w+7, a lane covers 8 consecutive positions of each with one 16-byte
-//            load → 8 loads in flight per lane, 512 positions per pass; the first pass is issued BEFORE the
-//            softmax so its latency hides behind the exp/sum work.
+//            load → 8 loads in flight per lane, 512 positions per pass.
 // ---------------------------------------------------------------------------------------------------
 template <bool F16_D>
 __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ q, const __half *__restrict__ mem_k,
@@ -376,31 +375,22 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     float qf[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) qf[j] = act ? round_f16(qh[d0 + j]) : 0.0f;  // ggml rounds src1 (Q) to f16
-    // first V pass, issued now (independent of the scores): channels of this wave, positions lane*8..+7
-    const int c_first = wave * 8;
-    const int tb_first = lane * 8;
-    const bool v_pre = c_first < D && tb_first < T8;
-    uint4 vpre[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        vpre[u] = make_uint4(0, 0, 0, 0);
-        if (v_pre && c_first + u < D) vpre[u] = *(const uint4 *)(mem_v + ((int64_t)hk * D + c_first + u) * C + tb_first);
-    }
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int c_first = wave * 8, tb_first = lane * 8;
     for (int t0 = g; t0 < T; t0 += 256) {
-        uint4 kv[4];
+        f16x8 kv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + 64 * u;
-            kv[u] = make_uint4(0, 0, 0, 0);
-            if (act && t < T) kv[u] = *(const uint4 *)(mem_k + (int64_t)t * Egqa + (int64_t)hk * D + d0);
+            kv[u] = zero8;
+            if (act && t < T) kv[u] = *(const f16x8 *)(mem_k + (int64_t)t * Egqa + (int64_t)hk * D + d0);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + 64 * u;
-            const __half *kh = (const __half *)&kv[u];
             float s = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; j++) s += __half2float(kh[j]) * qf[j];
+            for (int j = 0; j < 8; j++) s += (float)kv[u][j] * qf[j];
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (gl == 0 && t < T) s_s[t] = s * scale;
@@ -438,29 +428,23 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; u++) acc[u] = 0.0f;
         for (int tb = tb_first; tb < T8; tb += 512) {
-            uint4 vv[8];
-            if (c0 == c_first && tb == tb_first) {
+            f16x8 vv[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) vv[u] = vpre[u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    vv[u] = make_uint4(0, 0, 0, 0);
-                    if (c0 + u < D) vv[u] = *(const uint4 *)(mem_v + ((int64_t)hk * D + c0 + u) * C + tb);
-                }
+            for (int u = 0; u < 8; u++) {
+                vv[u] = zero8;
+                if (c0 + u < D) vv[u] = *(const f16x8 *)(mem_v + ((int64_t)hk * D + c0 + u) * C + tb);
             }
             const f32x4 p0 = *(const f32x4 *)(s_s + tb), p1 = *(const f32x4 *)(s_s + tb + 4);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const __half *vh = (const __half *)&vv[u];
-                acc[u] += __half2float(vh[0]) * p0[0];
-                acc[u] += __half2float(vh[1]) * p0[1];
-                acc[u] += __half2float(vh[2]) * p0[2];
-                acc[u] += __half2float(vh[3]) * p0[3];
-                acc[u] += __half2float(vh[4]) * p1[0];
-                acc[u] += __half2float(vh[5]) * p1[1];
-                acc[u] += __half2float(vh[6]) * p1[2];
-                acc[u] += __half2float(vh[7]) * p1[3];
+                acc[u] += (float)vv[u][0] * p0[0];
+                acc[u] += (float)vv[u][1] * p0[1];
+                acc[u] += (float)vv[u][2] * p0[2];
+                acc[u] += (float)vv[u][3] * p0[3];
+                acc[u] += (float)vv[u][4] * p1[0];
+                acc[u] += (float)vv[u][5] * p1[1];
+                acc[u] += (float)vv[u][6] * p1[2];
+                acc[u] += (float)vv[u][7] * p1[3];
             }
         }
 #pragma unroll
