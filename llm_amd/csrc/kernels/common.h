@@ -56,20 +56,102 @@ struct QAct {
     const int *sum;
 };
 
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---- cross-lane reductions on the VALU (DPP) instead of the LDS crossbar -----------------------------
+// `__shfl_xor` lowers to ds_bpermute_b32: an LDS-pipe round trip (~100+ cycles) per step, and the steps of a
+// reduction are dependent.  The short kernels of the decode chain are latency chains, so their reductions use
+// DPP row operations (a few cycles each): quad_perm ×2, row_half_mirror, row_mirror reduce a 16-lane row with
+// every lane holding the row's result; rows are combined with v_readlane (wave-uniform results) or one bpermute.
+#define DPP_QUAD_XOR1 0xB1        /* quad_perm [1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E        /* quad_perm [2,3,0,1] */
+#define DPP_ROW_HALF_MIRROR 0x141 /* lane i <-> 7-i inside each 8 lanes */
+#define DPP_ROW_MIRROR 0x140      /* lane i <-> 15-i inside each 16 lanes */
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// reductions over aligned groups of 8 / 16 lanes: every lane of the group ends with the group's result
+__device__ __forceinline__ float g8_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    return fmaxf(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
+}
+__device__ __forceinline__ int g8_sum_i32(int v) {
+    v += dpp_i32<DPP_QUAD_XOR1>(v);
+    v += dpp_i32<DPP_QUAD_XOR2>(v);
+    return v + dpp_i32<DPP_ROW_HALF_MIRROR>(v);
+}
+__device__ __forceinline__ float g16_sum_f32(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
+    return v + dpp_f32<DPP_ROW_MIRROR>(v);
+}
+__device__ __forceinline__ float g16_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
+    return fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+}
+__device__ __forceinline__ int g16_sum_i32(int v) {
+    v += dpp_i32<DPP_QUAD_XOR1>(v);
+    v += dpp_i32<DPP_QUAD_XOR2>(v);
+    v += dpp_i32<DPP_ROW_HALF_MIRROR>(v);
+    return v + dpp_i32<DPP_ROW_MIRROR>(v);
+}
+// groups of 32 lanes: row reduction + one exchange with the neighbouring row
+__device__ __forceinline__ float g32_max_f32(float v) {
+    v = g16_max_f32(v);
+    return fmaxf(v, __shfl_xor(v, 16, 64));
+}
+__device__ __forceinline__ int g32_sum_i32(int v) {
+    v = g16_sum_i32(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+// whole wave (64 lanes): row reduction + the four row results through v_readlane; result is wave-uniform
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v = g16_sum_f32(v);
+    const int i = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
+    v = g16_max_f32(v);
+    const int i = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    double r[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int k = 0; k < 4; k++) {
+        const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, 16 * k), h = (unsigned)__builtin_amdgcn_readlane(hi, 16 * k);
+        r[k] = __builtin_bit_cast(double, ((unsigned long long)h << 32) | l);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 // f32 -> f16 -> f32 round trip (RNE), the rounding ggml applies wherever it stores fp16.

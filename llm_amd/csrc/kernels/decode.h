@@ -57,14 +57,12 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
     for (int b = tid >> 5; b < nblk; b += 32) {
         const float v = s_y[b * 32 + l];
         float amax = fabsf(v);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        amax = g32_max_f32(amax);
         const float d = amax / 127.0f;
         const float id = d != 0.0f ? 1.0f / d : 0.0f;
         const int q = (int)roundf(v * id);
         int sq = q;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        sq = g32_sum_i32(sq);
         (l < 16 ? lo : hi)[b * 16 + (l & 15)] = (int8_t)q;
         if (l == 0) {
             dq[b] = F16_D ? round_f16(d) : d;
@@ -81,14 +79,12 @@ __global__ void __launch_bounds__(256) k_quant_row(const float *__restrict__ x, 
     if (b >= nblk) return;
     const float v = x[b * 32 + l];
     float amax = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    amax = g32_max_f32(amax);
     const float d = amax / 127.0f;
     const float id = d != 0.0f ? 1.0f / d : 0.0f;
     const int q = (int)roundf(v * id);
     int sq = q;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    sq = g32_sum_i32(sq);
     (l < 16 ? lo : hi)[b * 16 + (l & 15)] = (int8_t)q;
     if (l == 0) {
         dq[b] = F16_D ? round_f16(d) : d;
@@ -135,15 +131,13 @@ template <bool F16_D>
 __device__ __forceinline__ void quant4_to_lds(const f32x4 v, int64_t i4, int64_t nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
                                               float *s_d, int *s_sum) {
     float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    amax = g8_max_f32(amax);
     const float d = amax / 127.0f;
     const float id = d != 0.0f ? 1.0f / d : 0.0f;
     const int q0 = (int)roundf(v[0] * id), q1 = (int)roundf(v[1] * id), q2 = (int)roundf(v[2] * id),
               q3 = (int)roundf(v[3] * id);
     int sq = (q0 + q1) + (q2 + q3);
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    sq = g8_sum_i32(sq);
     const int64_t b = i4 >> 3;  // block index
     if (b >= nb) return;
     const int j = tid & 7;
@@ -213,22 +207,13 @@ __device__ __forceinline__ void stage_x(const QAct &xq, const float *xf, const f
     }
 }
 
-// rows (m0, m0+1) of NW weight matrices (same K, same activation) in ONE pass over the blocks, so that all
-// 2*NW row streams have their loads in flight together
+// One K-step (block column b) of rows (m0, m0+1) of NW weight matrices: the raw loads, kept in registers.
 template <int QT, int NW>
-__device__ __forceinline__ void dec_rows2(const QWeight *w, int64_t m0, int64_t nb, int lane, const i32x4 *s_lo,
-                                          const i32x4 *s_hi, const float *s_d, const int *s_sum, float (&acc)[NW][2]) {
-    int64_t r[NW][2];
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        acc[i][0] = acc[i][1] = 0.0f;
-        r[i][0] = m0 * nb;
-        r[i][1] = (m0 + 1 < w[i].M ? m0 + 1 : w[i].M - 1) * nb;
-    }
-    for (int64_t b = lane; b < nb; b += 64) {
-        u32x4 q[NW][2], p[NW][2];
-        uint32_t h[NW][2];
-        float dw[NW][2], mw[NW][2];
+struct DecRegs {
+    u32x4 q[NW][2], p[NW][2];
+    uint32_t h[NW][2];
+    float dw[NW][2], mw[NW][2];
+    __device__ __forceinline__ void load(const QWeight *w, const int64_t (&r)[NW][2], int64_t b) {
 #pragma unroll
         for (int i = 0; i < NW; i++)
 #pragma unroll
@@ -249,6 +234,22 @@ __device__ __forceinline__ void dec_rows2(const QWeight *w, int64_t m0, int64_t 
                 else
                     mw[i][j] = 0.0f;
             }
+    }
+};
+
+// rows (m0, m0+1) of NW weight matrices (same K, same activation) in ONE pass over the blocks, so that all
+// 2*NW row streams have their loads in flight together.  `cur` holds the first K-step, loaded by the caller
+// BEFORE the activation was staged (the weight stream does not depend on x); inside the loop the loads of
+// step b+64 are issued before step b is consumed (register double buffering).
+template <int QT, int NW>
+__device__ __forceinline__ void dec_rows2(const QWeight *w, const int64_t (&r)[NW][2], DecRegs<QT, NW> cur, int64_t nb,
+                                          int lane, const i32x4 *s_lo, const i32x4 *s_hi, const float *s_d,
+                                          const int *s_sum, float (&acc)[NW][2]) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) acc[i][0] = acc[i][1] = 0.0f;
+    for (int64_t b = lane; b < nb; b += 64) {
+        DecRegs<QT, NW> nxt = cur;
+        if (b + 64 < nb) nxt.load(w, r, b + 64);
         const i32x4 lo = s_lo[b], hi = s_hi[b];
         const float xd = s_d[b];
         const int xs = s_sum[b];
@@ -256,7 +257,8 @@ __device__ __forceinline__ void dec_rows2(const QWeight *w, int64_t m0, int64_t 
         for (int i = 0; i < NW; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
-                acc[i][j] += block_dot<QT>(q[i][j], p[i][j], h[i][j], dw[i][j], mw[i][j], lo, hi, xd, xs);
+                acc[i][j] += block_dot<QT>(cur.q[i][j], cur.p[i][j], cur.h[i][j], cur.dw[i][j], cur.mw[i][j], lo, hi, xd, xs);
+        cur = nxt;
     }
 #pragma unroll
     for (int i = 0; i < NW; i++)
@@ -274,9 +276,7 @@ __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
     int *s_sum = (int *)(s_d + nb);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;  // vec_dot_type Q8_0 vs Q8_1
-    stage_x<F16_D, XSRC>(a.x, a.xf, a.xw, a.eps, nb, tid, s_lo, s_hi, s_d, s_sum);
-    __syncthreads();
-
+    constexpr int NW = EPI == EPI_GATE ? 2 : 1;
     int sg = 0;
     if constexpr (EPI == EPI_QKV) {
         if ((int)blockIdx.x >= a.wg_begin[1]) sg = 1;
@@ -284,19 +284,35 @@ __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
     }
     const int wg = blockIdx.x - (EPI == EPI_QKV ? a.wg_begin[sg] : 0);
     const int64_t m0 = ((int64_t)wg * 4 + wave) * 2;
-    const QWeight &w = a.w[sg];
-    if (m0 >= w.M) return;
-    const bool has1 = m0 + 1 < w.M;
-    float v0, v1, u0 = 0.0f, u1 = 0.0f;
-    if constexpr (EPI == EPI_GATE) {
-        float acc[2][2];  // rows of w1 and the same rows of w3
-        dec_rows2<QT, 2>(a.w, m0, nb, lane, s_lo, s_hi, s_d, s_sum, acc);
-        v0 = acc[0][0], v1 = acc[0][1], u0 = acc[1][0], u1 = acc[1][1];
-    } else {
-        float acc[1][2];
-        dec_rows2<QT, 1>(&w, m0, nb, lane, s_lo, s_hi, s_d, s_sum, acc);
-        v0 = acc[0][0], v1 = acc[0][1];
+    const QWeight *w = &a.w[sg];
+    const bool valid = m0 < w->M;
+    // first K-step of the weight stream: issued before x is staged, so HBM latency overlaps the staging
+    int64_t r[NW][2];
+    DecRegs<QT, NW> first;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        r[i][0] = (valid ? m0 : 0) * nb;
+        r[i][1] = (m0 + 1 < w[i].M ? m0 + 1 : w[i].M - 1) * nb;
     }
+    if (valid && lane < nb)
+        first.load(w, r, lane);
+    else
+        first = DecRegs<QT, NW>{};
+
+    stage_x<F16_D, XSRC>(a.x, a.xf, a.xw, a.eps, nb, tid, s_lo, s_hi, s_d, s_sum);
+    __syncthreads();
+    if (!valid) return;
+    const bool has1 = m0 + 1 < w->M;
+    float acc[NW][2];
+    dec_rows2<QT, NW>(w, r, first, nb, lane, s_lo, s_hi, s_d, s_sum, acc);
+    const float v0 = acc[0][0], v1 = acc[0][1];
+    float u0 = 0.0f, u1 = 0.0f;
+    if constexpr (EPI == EPI_GATE) {
+        u0 = acc[1][0];
+        u1 = acc[1][1];
+    }
+    (void)u0;
+    (void)u1;
 
     if constexpr (EPI == EPI_STORE) {
         if (lane == 0) {
@@ -391,8 +407,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
             float s = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; j++) s += (float)kv[u][j] * qf[j];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s = g16_sum_f32(s);
             if (gl == 0 && t < T) s_s[t] = s * scale;
         }
     }
@@ -460,14 +475,12 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
         const float v = s_o[b * 32 + l];
         if (out_f32) out_f32[(int64_t)h * D + b * 32 + l] = v;
         float amax = fabsf(v);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        amax = g32_max_f32(amax);
         const float d = amax / 127.0f;
         const float id = d != 0.0f ? 1.0f / d : 0.0f;
         const int qv = (int)roundf(v * id);
         int sq = qv;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        sq = g32_sum_i32(sq);
         const int64_t gb = (int64_t)h * nblk + b;
         (l < 16 ? lo : hi)[gb * 16 + (l & 15)] = (int8_t)qv;
         if (l == 0) {

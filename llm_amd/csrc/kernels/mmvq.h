@@ -64,14 +64,12 @@ __global__ void __launch_bounds__(256) k_quantize_act(const char *__restrict__ x
     const int64_t row = gblock / nblk, b = gblock % nblk;
     const float v = ((const float *)(x + row * nb_row))[b * 32 + l];
     float amax = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    amax = g32_max_f32(amax);
     const float d = amax / 127.0f;
     const float id = d != 0.0f ? 1.0f / d : 0.0f;
     const int q = (int)roundf(v * id);
     int s = q;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = g32_sum_i32(s);
     int8_t *dst = (l < 16 ? lo : hi) + gblock * 16 + (l & 15);
     *dst = (int8_t)q;
     if (l == 0) {
