@@ -104,12 +104,20 @@ def run_single(args):
     for _ in range(args.warmup):
         sess.infer_next_token()
     L.ggml_hip_synchronize()
+    stat = lambda k: int(L.ggml_hip_get_stat(k.encode()))
+    h0 = {k: stat(k) for k in ("ns_match", "ns_launch", "ns_wait", "ns_compute", "plan_tokens")}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sess.infer_next_token()
     L.ggml_hip_synchronize()
     elapsed = time.perf_counter() - t0
     tok_s = args.steps / elapsed
+    h1 = {k: stat(k) - v for k, v in h0.items()}
+    host_split = {"plan_tokens": h1["plan_tokens"],
+                  "graph_build_and_sampling_ms": round((elapsed * 1e9 - h1["ns_compute"]) / args.steps / 1e6, 4),
+                  "match_ms": round(h1["ns_match"] / args.steps / 1e6, 4),
+                  "enqueue_ms": round(h1["ns_launch"] / args.steps / 1e6, 4),
+                  "device_wait_ms": round(h1["ns_wait"] / args.steps / 1e6, 4)}
 
     # roofline leg (HIP events on the backend's own stream): the token's mat-vec launches alone, replayed from a
     # hipGraph that holds only them, bracketed by two events — every replay streams the full 3.7 GB of weights
@@ -140,7 +148,7 @@ def run_single(args):
            "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode "
                                   f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",
                       "n_past_at_start": args.prompt + args.warmup, "parallelism": "1 GPU",
-                      "weights_in_hbm_before_timing": True, "prep": {k: round(v, 2) for k, v in prep.items()}},
+                      "weights_in_hbm_before_timing": True, "host_split_per_token": host_split, "prep": {k: round(v, 2) for k, v in prep.items()}},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     sess.free()

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -121,6 +122,7 @@ struct Backend {
     int opt_graph = 1;      // replay the plan from a captured hipGraph
     int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
     uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0;
+    uint64_t ns_match = 0, ns_launch = 0, ns_wait = 0, ns_compute = 0;  // host-side time split of plan tokens
     size_t dead_shadow_bytes = 0;
 } g;
 
@@ -1078,7 +1080,9 @@ extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
 
 extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
+    const uint64_t t0 = now_ns();
     execute_graph(cgraph);
+    g.ns_compute += now_ns() - t0;
 }
 
 // ===================================================================================================
@@ -1367,6 +1371,10 @@ int64_t ggml_hip_get_stat(const char *key) {
     }
     if (k == "plans") return (int64_t)g_plans.size();
     if (k == "generic_graphs") return (int64_t)g.stat_generic_graphs;  // graphs run node by node
+    if (k == "ns_match") return (int64_t)g.ns_match;      // host ns spent recognising decode graphs
+    if (k == "ns_launch") return (int64_t)g.ns_launch;    // ... enqueueing (param upload, graph launch, read-back queue)
+    if (k == "ns_wait") return (int64_t)g.ns_wait;        // ... waiting for the device + copying results out
+    if (k == "ns_compute") return (int64_t)g.ns_compute;  // total inside ggml_graph_compute
     return -1;
 }
 const char *ggml_hip_version(void) { return "libggml_hip 0.1 (gfx950)"; }
