@@ -459,6 +459,8 @@ GGML_API void ggml_hip_synchronize(void);
  * Used by tests to inspect interior nodes and by the layer-split driver to hand the residual to RCCL. */
 GGML_API void ggml_hip_tensor_get(const struct ggml_tensor *tensor, void *host_dst, size_t offset, size_t nbytes);
 GGML_API void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_t offset, size_t nbytes);
+/* Raw synchronous copy on the backend stream; kind: 0 = host->device, 1 = device->host, 2 = device->device. */
+GGML_API void ggml_hip_memcpy(void *dst, const void *src, size_t nbytes, int kind);
 /* Device address of a tensor's mirror (for handing buffers to torch.distributed / RCCL). */
 GGML_API void *ggml_hip_tensor_device_ptr(const struct ggml_tensor *tensor);
 /* Per-kernel-class timing with HIP events on the backend's own stream (bench.py roofline leg).

@@ -1252,6 +1252,22 @@ void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_
     h2d_bulk(dev_ptr(tensor) + offset, host_src, nbytes);
     HIP_CHECK(hipStreamSynchronize(g.stream));
 }
+// Raw copies on the backend stream, synchronous (layer-split driver: moving the residual between a stage's
+// hand-off buffer and the communication library's buffers). kind: 0 = host→device, 1 = device→host, 2 = device→device.
+void ggml_hip_memcpy(void *dst, const void *src, size_t nbytes, int kind) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    if (kind == 0) {
+        h2d_bulk((char *)dst, src, nbytes);
+        HIP_CHECK(hipStreamSynchronize(g.stream));
+    } else if (kind == 1) {
+        d2h_queue(dst, (const char *)src, nbytes);
+        d2h_finish();
+    } else {
+        HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, g.stream));
+        HIP_CHECK(hipStreamSynchronize(g.stream));
+    }
+}
 void *ggml_hip_tensor_device_ptr(const struct ggml_tensor *tensor) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     ensure_init();

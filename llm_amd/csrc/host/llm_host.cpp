@@ -139,8 +139,21 @@ class InferenceSession {
         return GraphOutputs{built_result.result.share(), built_result.embedding_result.share()};
     }
 
+    void make_stage_buffers(size_t n_embd, bool in, bool out) {
+        stage_ctx_ = std::make_shared<Context>(Context::new_with_allocate(2 * (n_embd * config.n_batch * 4 + 1024)));
+        if (in) {
+            stage_in = stage_ctx_->new_tensor_1d(GGML_TYPE_F32, n_embd * config.n_batch).set_name("stage_in");
+            stage_in.offload_no_scratch();
+        }
+        if (out) {
+            stage_out = stage_ctx_->new_tensor_1d(GGML_TYPE_F32, n_embd * config.n_batch).set_name("stage_out");
+            stage_out.offload_no_scratch();
+        }
+    }
+
     InferenceSessionConfig config;
     Tensor memory_k, memory_v;
+    Tensor stage_in, stage_out;  // layer-split hand-off buffers (null for a whole-model session)
     size_t n_past = 0;
     size_t mem_per_token = 0;
     std::vector<TokenId> tokens;
@@ -150,6 +163,7 @@ class InferenceSession {
 
    private:
     std::shared_ptr<Context> session_ctx_;
+    std::shared_ptr<Context> stage_ctx_;
     size_t memory_size_ = 0;
     Context ctx0_;
     size_t n_embd_;
@@ -219,12 +233,18 @@ class TensorLoader {
 class Llama {
    public:
     // models/llama/src/lib.rs:43-130
-    Llama(Hyperparameters hp, ModelParameters params, TensorLoader tl) : hyperparameters(hp), params(params) {
-        wte = tl.load("tok_embeddings.weight");
+    Llama(Hyperparameters hp, ModelParameters params_, TensorLoader tl) : hyperparameters(hp), params(params_) {
+        // layer split: this process owns [layer_begin, layer_end); the first stage also owns the
+        // embedding table, the last one the final norm and the lm_head.  Default = the whole model = the reference.
+        if (params.layer_end > hp.n_layer) params.layer_end = hp.n_layer;
+        if (params.layer_begin >= params.layer_end) ggml::panic("empty layer range");
+        if (is_first()) wte = tl.load("tok_embeddings.weight");
         const Backend backend = params.backend(0);
-        norm = tl.load("norm.weight").transfer_to(backend);
-        output = tl.load("output.weight").transfer_to(backend);
-        for (size_t i = 0; i < hp.n_layer; i++) {
+        if (is_last()) {
+            norm = tl.load("norm.weight").transfer_to(backend);
+            output = tl.load("output.weight").transfer_to(backend);
+        }
+        for (size_t i = params.layer_begin; i < params.layer_end; i++) {
             const Backend b = params.backend(i);
             auto name = [&](const char *s) { return "layers." + std::to_string(i) + "." + s; };
             Layer l;
@@ -242,9 +262,16 @@ class Llama {
         context = tl.finish();
     }
 
+    bool is_first() const { return params.layer_begin == 0; }
+    bool is_last() const { return params.layer_end == hyperparameters.n_layer; }
+    size_t n_local_layers() const { return params.layer_end - params.layer_begin; }
+
     InferenceSession *start_session(const InferenceSessionConfig &config) const {  // :133-141
-        return new InferenceSession(config, params, hyperparameters.n_layer, hyperparameters.n_embd,
-                                    hyperparameters.n_vocab);
+        InferenceSession *s = new InferenceSession(config, params, n_local_layers(), hyperparameters.n_embd,
+                                                   hyperparameters.n_vocab);
+        // stage hand-off buffers: persistent device tensors (like memory_k/v) that RCCL sends from / receives into
+        if (!is_first() || !is_last()) s->make_stage_buffers(hyperparameters.n_embd, !is_first(), !is_last());
+        return s;
     }
 
     // models/llama/src/lib.rs:144-368 — line numbers of the Rust builder are cited per step
@@ -259,9 +286,13 @@ class Llama {
         GraphOutputs outputs = session.compute(input_tokens, [&](BuildContext &builder) {
             Context &ctx0 = *builder.ctx0;
             const Tensor &embd = *builder.embd;
-            Tensor input_layer = ctx0.op_get_rows(wte, embd);  // :170
+            (void)n_layer;
+            Tensor input_layer = is_first()
+                                     ? ctx0.op_get_rows(wte, embd)  // :170
+                                     : ctx0.op_reshape_2d(ctx0.op_view_1d(session.stage_in, n_embd * input_len, 0), n_embd,
+                                                          input_len);  // residual received from the previous stage
             ComputationGraph gf = ctx0.create_compute_graph();  // :172
-            for (size_t il = 0; il < n_layer; il++) {
+            for (size_t il = 0; il < n_local_layers(); il++) {
                 ctx0.set_offloading(params.should_offload(il));  // :175
                 Tensor input_self_attention = input_layer.share();
                 Tensor current;
@@ -323,6 +354,11 @@ class Llama {
                 current = ctx0.op_add(current, input_feed_forward);  // :334
                 input_layer = current;  // :337
             }
+            if (!is_last()) {  // hand the residual to the next stage through the persistent buffer
+                ctx0.use_scratch(nullptr);
+                Tensor out = ctx0.op_cpy(input_layer, ctx0.op_view_1d(session.stage_out, n_embd * input_len, 0));
+                return std::make_pair(gf, GraphOutputs{out, out});
+            }
             ctx0.use_scratch(builder.get_scratch(0));  // :340
             input_layer = ctx0.op_rms_norm(input_layer);  // :343
             input_layer = ctx0.op_mul(input_layer, norm);  // :346
@@ -332,6 +368,7 @@ class Llama {
             ctx0.use_scratch(nullptr);  // :354
             return std::make_pair(gf, GraphOutputs{input_layer, embedding_result});
         });
+        if (!is_last()) return;
         // finish evaluation (:364-367)
         common::read_last_token(session, outputs.result, n_vocab, input_len);
         common::extract_logits(output_request, outputs.result, n_vocab, input_len);
@@ -377,6 +414,8 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
     p.has_rope_overrides = mp->has_rope_overrides != 0;
     p.rope_overrides.frequency_scale = mp->rope_frequency_scale;
     p.rope_overrides.frequency_base = (size_t)mp->rope_frequency_base;
+    p.layer_begin = mp->layer_begin > 0 ? (size_t)mp->layer_begin : 0;
+    p.layer_end = mp->layer_end > 0 ? (size_t)mp->layer_end : (size_t)-1;
     if (!p.use_gpu) {
         fprintf(stderr, "llm_llama_new: use_gpu=0 requested, but libggml_hip has no CPU compute path\n");
         abort();
@@ -461,6 +500,14 @@ int llm_model_n_vocab(const llm_model *m) { return (int)m->llama->hyperparameter
 void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_leafs) {
     if (n_nodes) *n_nodes = s->s->last_n_nodes;
     if (n_leafs) *n_leafs = s->s->last_n_leafs;
+}
+
+// Device addresses of the layer-split hand-off buffers of a session (NULL when the stage has none): the residual
+// [n_embd * n_tokens] f32 is received into *in_dev before llm_evaluate and is in *out_dev after it.
+void llm_session_stage_buffers(llm_session *s, void **in_dev, void **out_dev, size_t *nbytes) {
+    if (in_dev) *in_dev = s->s->stage_in.is_null() ? nullptr : ggml_hip_tensor_device_ptr(s->s->stage_in.ptr());
+    if (out_dev) *out_dev = s->s->stage_out.is_null() ? nullptr : ggml_hip_tensor_device_ptr(s->s->stage_out.ptr());
+    if (nbytes) *nbytes = !s->s->stage_in.is_null() ? s->s->stage_in.nbytes() : !s->s->stage_out.is_null() ? s->s->stage_out.nbytes() : 0;
 }
 
 // Session K/V memory as raw bytes (which: 0 = memory_k, 1 = memory_v) — the payload of the reference's

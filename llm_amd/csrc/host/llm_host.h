@@ -75,6 +75,8 @@ GGML_API int llm_model_n_vocab(const llm_model *m);
 /* graph statistics of the last evaluate (for tests): nodes, leafs */
 GGML_API void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_leafs);
 
+/* layer split: device addresses of the residual hand-off buffers of a stage session (NULL if absent) */
+GGML_API void llm_session_stage_buffers(llm_session *s, void **in_dev, void **out_dev, size_t *nbytes);
 /* raw K/V memory of a session (which: 0 = memory_k, 1 = memory_v; set: 0 = read into buf, 1 = write from buf);
  * buf == NULL returns the size.  The InferenceSnapshot payload (inference_session.rs:599-646). */
 GGML_API size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbytes);

@@ -207,6 +207,7 @@ PROTOTYPES.update({
     "ggml_hip_tensor_get": (None, [TP, C.c_void_p, C.c_size_t, C.c_size_t]),
     "ggml_hip_tensor_set": (None, [TP, C.c_void_p, C.c_size_t, C.c_size_t]),
     "ggml_hip_tensor_device_ptr": (C.c_void_p, [TP]),
+    "ggml_hip_memcpy": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "ggml_hip_timing_begin": (None, []),
     "ggml_hip_timing_end": (None, []),
     "ggml_hip_timing_query": (None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

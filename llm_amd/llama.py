@@ -53,6 +53,8 @@ def _lib():
         L.llm_session_n_past.restype = C.c_int
         L.llm_session_n_past.argtypes = [C.c_void_p]
         L.llm_session_last_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.llm_session_stage_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_size_t)]
         L.llm_session_kv.restype = C.c_size_t
         L.llm_session_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.llm_session_read_node.restype = C.c_size_t
@@ -65,12 +67,16 @@ class Llama:
     """models/llama Llama + ModelParameters{use_gpu: true}.  `weights`: {name: ndarray} as produced by
     llm_amd.synth (raw GGML bytes for 2-D tensors) — must outlive the model (mmap semantics)."""
 
-    def __init__(self, hp, weights, context_size=2048, gpu_layers=-1, rope_overrides=None):
-        from .synth import tensor_shapes
+    def __init__(self, hp, weights, context_size=2048, gpu_layers=-1, rope_overrides=None, layer_range=None):
+        from .synth import stage_tensor_names, tensor_shapes
         self.hp = dict(hp)
         self.weights = weights
         L = _lib()
-        shapes = tensor_shapes(hp)
+        lb, le = layer_range if layer_range else (0, hp["n_layer"])
+        self.layer_range = (lb, le)
+        self.is_first, self.is_last = lb == 0, le == hp["n_layer"]
+        keep = stage_tensor_names(hp, lb, le)
+        shapes = {k: v for k, v in tensor_shapes(hp).items() if k in keep}
         descs = (_TD * len(shapes))()
         self._names = []
         for i, (name, (ne0, ne1)) in enumerate(shapes.items()):
@@ -87,7 +93,7 @@ class Llama:
             descs[i].data = arr.ctypes.data
         h = _HP(hp["n_vocab"], hp["n_embd"], hp.get("n_mult", 256), hp["n_head"], hp["n_head_kv"], hp["n_layer"],
                 hp["n_rot"], 2 * 1000 + ggml.FTYPE_OF[hp["wtype"]])
-        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, 0, -1)
+        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, lb, le)
         if rope_overrides:
             mp.has_rope_overrides = 1
             mp.rope_frequency_scale = rope_overrides["frequency_scale"]
@@ -118,6 +124,8 @@ class Session:
         """Model::evaluate: returns all logits [N, n_vocab] (OutputRequest.all_logits) if requested."""
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
         V, E = self.model.hp["n_vocab"], self.model.hp["n_embd"]
+        if not self.model.is_last:
+            want_all_logits = want_embeddings = False
         logits = np.zeros((tokens.size, V), np.float32) if want_all_logits else None
         emb = np.zeros(E, np.float32) if want_embeddings else None
         _lib().llm_evaluate(self.model.ptr, self.ptr, tokens.ctypes.data, tokens.size,
@@ -140,6 +148,12 @@ class Session:
     def last_logits(self):
         V = self.model.hp["n_vocab"]
         return np.ctypeslib.as_array(_lib().llm_session_last_logits(self.ptr), shape=(V,)).copy()
+
+    def stage_buffers(self):
+        """(in_dev_ptr, out_dev_ptr, nbytes) of the layer-split residual hand-off buffers (None if absent)."""
+        a, b, n = C.c_void_p(0), C.c_void_p(0), C.c_size_t(0)
+        _lib().llm_session_stage_buffers(self.ptr, C.byref(a), C.byref(b), C.byref(n))
+        return a.value, b.value, n.value
 
     def get_kv(self, dtype=np.uint16):
         """(memory_k, memory_v) raw contents — the InferenceSnapshot payload."""

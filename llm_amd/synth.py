@@ -34,6 +34,21 @@ def tensor_shapes(hp):
     return s
 
 
+def stage_tensor_names(hp, layer_begin, layer_end):
+    """Tensors a layer-split stage owns: its layers, + tok_embeddings on the first, + norm/output on the last."""
+    names = set()
+    for name in tensor_shapes(hp):
+        if name.startswith("layers."):
+            if layer_begin <= int(name.split(".")[1]) < layer_end:
+                names.add(name)
+        elif name == "tok_embeddings.weight":
+            if layer_begin == 0:
+                names.add(name)
+        elif layer_end == hp["n_layer"]:
+            names.add(name)
+    return names
+
+
 def _layer_of(name):
     return int(name.split(".")[1]) if name.startswith("layers.") else -1
 
@@ -54,13 +69,15 @@ def make_llama(hp, wtype, seed=1234, std=0.02):
     return h, out
 
 
-def make_llama_fast(hp, wtype, seed=1234, d_scale=0.0043):
+def make_llama_fast(hp, wtype, seed=1234, d_scale=0.0043, only=None):
     """Full-size synthetic weights for bench.py: writes random GGML blocks directly (uniform quants, f16
     scales around `d_scale` so that dequantized weights have std ≈ 0.02) instead of quantizing 6.7e9
     gaussians.  Same container format, same bytes-per-weight, valid for every block type."""
     out = {}
     bs, be = ggml.BLOCK_BYTES[wtype], ggml.BLOCK_ELEMS[wtype]
     for name, (ne0, ne1) in tensor_shapes(hp).items():
+        if only is not None and name not in only:
+            continue
         rng = np.random.default_rng([seed, _layer_of(name) + 1, sum(map(ord, name))])
         if ne1 is None:
             out[name] = (1.0 + 0.01 * rng.standard_normal(ne0)).astype(np.float32)

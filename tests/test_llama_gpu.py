@@ -226,3 +226,36 @@ def test_decode_plan_embeddings_and_f32_kv_fallback(G, O):
     assert np.max(np.abs(lg32 - ref)) <= 5e-2 * ref.std()  # f32 KV vs the oracle's f16 KV
     s32.free()
     model.free()
+
+
+@pytest.mark.parametrize("wtype", [2, 7])
+def test_layer_split_stages_match_whole_model(G, O, wtype):
+    """the model split into two stages (layers [0,1) and [1,2)), the residual handed over through the
+    stages' persistent device buffers, reproduces the whole model's tokens and logits (prompt batch + decode)."""
+    from llm_amd import llama, synth
+    from llm_amd.pipeline import GpuStage
+    hp, w = synth.make_llama(synth.TINY, wtype, seed=7)
+    whole = llama.Llama(hp, w, context_size=64)
+    ws = whole.start_session(n_batch=8)
+    st0 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 0, 1)}, (0, 1), 64)
+    st1 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 1, 2)}, (1, 2), 64)
+    assert st0.is_first and not st0.is_last and st1.is_last and not st1.is_first
+    st0.new_sequence(0)
+    st1.new_sequence(0)
+    toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 6).astype(np.int32)
+    chunk = toks
+    for step in range(6):
+        ref = ws.evaluate(chunk)
+        res = st0.evaluate(0, chunk, None)
+        assert res.shape == (len(chunk), hp["n_embd"]) and np.isfinite(res).all()
+        tok = st1.evaluate(0, chunk, res)
+        got = st1.sessions[0].last_logits()
+        d = float(np.max(np.abs(got - ref[-1])) / ref.std())
+        assert d <= EDGE, (step, d)
+        if d <= STRICT:
+            assert tok == int(np.argmax(ref[-1]))
+        chunk = np.array([int(np.argmax(ref[-1]))], np.int32)
+    st0.free()
+    st1.free()
+    ws.free()
+    whole.free()
