@@ -80,6 +80,8 @@ struct DevTensor {
     size_t dev_bytes = 0;
     bool soa = false;             // quantized SoA layout (see QWeight)
     bool auto_uploaded = false;
+    int refs = 1;                 // explicit records: tensors sharing this device copy
+    bool zero_filled = false;     // created by assign_buffers_no_scratch (mutable state: never shared)
     uintptr_t owner_hdr = 0;      // auto-uploaded only: address of the ggml_tensor header that named this data
     QWeight qw{};
     ggml_type type = GGML_TYPE_F32;
@@ -454,7 +456,21 @@ bool wants_soa(const ggml_tensor *t) {
 DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill, bool is_auto = false) {
     ensure_init();
     const size_t nbytes = ggml_nbytes(t);
+    if (!is_auto && !zero_fill) {
+        // The same host bytes offloaded again (two models over one mmap / one weight buffer): share the
+        // device copy instead of evicting it from under the first owner.
+        auto it = g.tensors.find((uintptr_t)data);
+        if (it != g.tensors.end()) {
+            DevTensor *o = it->second;
+            if (o->nbytes == nbytes && o->type == t->type && o->ne[0] == t->ne[0] && o->ne[1] == t->ne[1] &&
+                o->ne[2] == t->ne[2] && o->ne[3] == t->ne[3] && !o->zero_filled) {
+                o->refs++;
+                return o;
+            }
+        }
+    }
     DevTensor *e = new DevTensor();
+    e->zero_filled = zero_fill;
     e->host = (uintptr_t)data;
     e->nbytes = nbytes;
     e->type = t->type;
@@ -504,6 +520,7 @@ void destroy_record(DevTensor *e) {
     delete e;
 }
 void free_dev_tensor(DevTensor *e) {
+    if (--e->refs > 0) return;
     auto &m = e->auto_uploaded ? g.auto_tensors : g.tensors;
     auto it = m.find(e->host);
     if (it != m.end() && it->second == e) m.erase(it);
