@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=20)
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill"],
+                    help="decode = BASELINE configs[1] (the metric); prefill = configs[2], 512-token prompt batch on MFMA")
+    ap.add_argument("--prefill-tokens", type=int, default=512)
     return ap.parse_args()
 
 
@@ -155,12 +158,78 @@ def run_single(args):
     model.free()
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X dense f16 MFMA peak, MI355X_MICROARCH.md "BF16/F16 ~2.5 PF dense"
+
+
+def run_prefill(args):
+    """BASELINE configs[2]: one step = Model::evaluate of a 512-token prompt batch (n_batch = 512) into an empty
+    context; tokens/s = 512 / step time.  Roofline leg: the quantized GEMM launches (k_mmq, f16 MFMA) timed
+    with HIP events on the backend stream in a separate, untimed pass."""
+    from llm_amd import ggml
+    if not ggml.has_gpu():
+        raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
+    L = ggml.lib()
+    hp, w, model, prep = build_model(args)
+    n = args.prefill_tokens
+    sess = model.start_session(n_batch=n)
+    prompt = np.random.default_rng(42).integers(0, hp["n_vocab"], n).astype(np.int32)
+
+    sess.feed_prompt(prompt[:1])  # rewind() must leave one token (RewindError::NotEnoughTokens otherwise)
+
+    def step():
+        sess.feed_prompt(prompt)
+        assert sess.rewind(n) == 0
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    L.ggml_hip_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    L.ggml_hip_synchronize()
+    elapsed = time.perf_counter() - t0
+    L.ggml_hip_timing_begin()
+    step()
+    L.ggml_hip_timing_end()
+    cls = {}
+    for name, k in (("mmq_mfma", ggml.KCLASS_MMQ_MFMA), ("mmvq", ggml.KCLASS_MMVQ), ("attn", ggml.KCLASS_ATTN),
+                    ("other", ggml.KCLASS_OTHER)):
+        ms, launches, work = ggml.timing_query(k)
+        cls[name] = (ms, launches, work)
+    ms, launches, flops = cls["mmq_mfma"]
+    achieved = flops / 1e12 / (ms / 1e3) if ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "k_mmq (quantized GEMM, in-LDS dequant to f16, v_mfma_f32_32x32x16_f16)",
+                "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches_per_step": launches,
+                "algo_flops_per_step": flops,
+                "method": "per-launch HIP events on the backend stream, one extra untimed step",
+                "class_ms_per_step": {k: round(v[0], 3) for k, v in cls.items()},
+                "class_launches_per_step": {k: v[1] for k, v in cls.items()}}
+    out = {"metric": f"prefill tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}",
+           "value": round(n * args.steps / elapsed, 1), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16 MFMA, f32 accumulate (weights dequantized in LDS; activations Q8-requantized then f16)",
+           "data": "synthetic",
+           "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} {n}-token prefill batch "
+                                  f"(BASELINE configs[2]) at n_past=1, ctx 2048, f16 KV", "parallelism": "1 GPU",
+                      "weights_in_hbm_before_timing": True, "prep": {k: round(v, 2) for k, v in prep.items()}},
+           "roofline": roofline, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+    sess.free()
+    model.free()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1:
         from llm_amd import pipeline
         pipeline.run_bench(args)
+        return
+    if args.mode == "prefill":
+        run_prefill(args)
         return
     run_single(args)
 

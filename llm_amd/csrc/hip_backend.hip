@@ -30,6 +30,8 @@
 #include "internal.h"
 #include "kernels/common.h"
 #include "kernels/mmvq.h"
+#include "kernels/mmq.h"
+#include "kernels/gemm_f16.h"
 #include "kernels/ops.h"
 #include "kernels/decode.h"
 
@@ -120,6 +122,7 @@ struct Backend {
     // options
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
+    int opt_mmq_min = 32;   // token count from which mul_mat runs on the MFMA GEMM (0 = never)
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
     int opt_graph = 1;      // replay the plan from a captured hipGraph
     int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
@@ -155,6 +158,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_GRAPH")) g.opt_graph = atoi(v);
     if (const char *v = getenv("GGML_HIP_XSRC")) g.opt_xsrc = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMVQ_R")) g.opt_mmvq_rows = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_MIN")) g.opt_mmq_min = atoi(v);
     g.inited = true;
 }
 
@@ -247,6 +251,14 @@ struct QActBuf {
     QAct act{};
     bool valid = false;
 } g_qact;
+struct XF16Buf {  // the prefill GEMM's activation operand (kernels/mmq.h), cached like g_qact
+    const void *src_data = nullptr;
+    size_t src_bytes = 0;
+    bool f16_d = false;
+    int64_t nb = 0, ncols = 0;
+    const _Float16 *x = nullptr;
+    bool valid = false;
+} g_xf16;
 
 char *ws_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -613,6 +625,69 @@ void launch_mmvq(int qt, const MmvqArgs &a, int ncols, int R, int nwg, size_t ld
     HIP_CHECK(hipGetLastError());
 }
 
+const _Float16 *quantize_activation_f16(const ggml_tensor *src1, bool f16_d) {
+    BK_ASSERT(src1->type == GGML_TYPE_F32 && src1->nb[0] == 4 && src1->ne[2] == 1 && src1->ne[3] == 1);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
+    if (g_xf16.valid && g_xf16.src_data == src1->data && g_xf16.f16_d == f16_d && g_xf16.nb == nb && g_xf16.ncols == N)
+        return g_xf16.x;
+    _Float16 *out = (_Float16 *)ws_alloc((size_t)N * K * 2);
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)(K * N * 6));
+    const int64_t threads = nb * N * 32;
+    if (f16_d)
+        hipLaunchKernelGGL(k_quant_act_f16<true>, grid1(threads), dim3(256), 0, g.stream, dev_ptr(src1),
+                           (int64_t)src1->nb[1], nb, N, out);
+    else
+        hipLaunchKernelGGL(k_quant_act_f16<false>, grid1(threads), dim3(256), 0, g.stream, dev_ptr(src1),
+                           (int64_t)src1->nb[1], nb, N, out);
+    HIP_CHECK(hipGetLastError());
+    g_xf16.valid = true;
+    g_xf16.src_data = src1->data;
+    g_xf16.src_bytes = ggml_nbytes(src1);
+    g_xf16.f16_d = f16_d;
+    g_xf16.nb = nb;
+    g_xf16.ncols = N;
+    g_xf16.x = out;
+    return out;
+}
+
+// Quantized GEMM on the f16 matrix cores (kernels/mmq.h); the `algo_bytes` slot of the MMQ_MFMA timing class
+// carries FLOPs (2*M*N*K), the unit that class is bounded by.
+void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
+    const int qt = qt_of(src0->type);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
+    const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
+    MmqArgs a;
+    a.w = qweight_of(src0);
+    a.x = quantize_activation_f16(src1, f16_d);
+    a.dst = (float *)dev_ptr(dst);
+    a.ldd = (int64_t)dst->nb[1] / 4;
+    a.M = a.w.M;
+    a.N = N;
+    a.nb = nb;
+    const int tiles_m = (int)((a.M + MMQ_TM - 1) / MMQ_TM);
+    a.tiles_n = (int)((N + MMQ_TN - 1) / MMQ_TN);
+    const dim3 grid((unsigned)(tiles_m * a.tiles_n));
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {  // 73.7 KB of dynamic LDS: above the 64 KB a kernel gets without opting in
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+        lds_attr_set = true;
+    }
+    Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)a.M * (double)N * (double)K);
+    switch (qt) {
+        case QT_Q4_0: hipLaunchKernelGGL(k_mmq<QT_Q4_0>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
+        case QT_Q4_1: hipLaunchKernelGGL(k_mmq<QT_Q4_1>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
+        case QT_Q5_0: hipLaunchKernelGGL(k_mmq<QT_Q5_0>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
+        case QT_Q5_1: hipLaunchKernelGGL(k_mmq<QT_Q5_1>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
+        case QT_Q8_0: hipLaunchKernelGGL(k_mmq<QT_Q8_0>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
+        default: die("mmq: bad weight type");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 int pick_rows(int64_t M) {
     if (g.opt_mmvq_rows == 1 || g.opt_mmvq_rows == 2 || g.opt_mmvq_rows == 4) return g.opt_mmvq_rows;
     return M >= 16384 ? 2 : 1;
@@ -628,6 +703,10 @@ void mul_mat_q(int nmat, const ggml_tensor *const *src0s, const ggml_tensor *src
         BK_ASSERT(src0s[i]->type == src0s[0]->type && src0s[i]->ne[0] == K);
         BK_ASSERT(dsts[i]->type == GGML_TYPE_F32 && dsts[i]->nb[0] == 4);
         ws[i] = qweight_of(src0s[i]);
+    }
+    if (g.opt_mmq_min > 0 && N >= g.opt_mmq_min) {  // prompt batch: MFMA GEMM
+        for (int i = 0; i < nmat; i++) mul_mat_q_mfma(src0s[i], src1, dsts[i]);
+        return;
     }
     const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
     const QAct act = quantize_activation(src1, f16_d);
@@ -682,7 +761,26 @@ void op_mul_mat(ggml_tensor *dst) {
     Timed tm(GGML_HIP_KCLASS_ATTN, bytes);
     if (a->type == GGML_TYPE_F16) {
         BK_ASSERT(a->nb[0] == 2);
-        hipLaunchKernelGGL(k_mul_mat_f16, grid, dim3(256), 0, g.stream, va, vb, vd);
+        const bool aligned = ((uintptr_t)va.p % 16 == 0) && a->nb[1] % 16 == 0 && a->nb[2] % 16 == 0 && a->nb[3] % 16 == 0;
+        if (g.opt_mmq_min > 0 && b->ne[1] >= g.opt_mmq_min && aligned && dst->nb[0] == 4) {
+            // prompt batch: both attention products on the f16 matrix cores (kernels/gemm_f16.h)
+            GemmF16Args ga;
+            ga.a = va.p; ga.a_nb1 = a->nb[1]; ga.a_nb2 = a->nb[2]; ga.a_nb3 = a->nb[3];
+            ga.b = vb.p; ga.b_nb1 = b->nb[1]; ga.b_nb2 = b->nb[2]; ga.b_nb3 = b->nb[3];
+            ga.d = vd.p; ga.d_nb1 = dst->nb[1]; ga.d_nb2 = dst->nb[2]; ga.d_nb3 = dst->nb[3];
+            ga.M = a->ne[1]; ga.N = b->ne[1]; ga.K = a->ne[0];
+            ga.ne12 = b->ne[2]; ga.r2 = b->ne[2] / a->ne[2]; ga.r3 = b->ne[3] / a->ne[3];
+            ga.tiles_n = (int)((ga.N + 127) / 128);
+            const int tiles_m = (int)((ga.M + 127) / 128);
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_f16, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_gemm_f16, dim3((unsigned)(tiles_m * ga.tiles_n), (unsigned)(b->ne[2] * b->ne[3])), dim3(256),
+                               MMQ_LDS, g.stream, ga);
+        } else
+            hipLaunchKernelGGL(k_mul_mat_f16, grid, dim3(256), 0, g.stream, va, vb, vd);
     } else if (a->type == GGML_TYPE_F32) {
         BK_ASSERT(a->nb[0] == 4);
         hipLaunchKernelGGL(k_mul_mat_f32, grid, dim3(256), 0, g.stream, va, vb, vd);
@@ -929,11 +1027,19 @@ void download_outputs(ggml_cgraph *gr) {
     d2h_finish();
 }
 
+void invalidate_xf16_if_overwritten_impl(const ggml_tensor *n);
 void invalidate_qact_if_overwritten(const ggml_tensor *n) {
+    invalidate_xf16_if_overwritten_impl(n);
     if (!g_qact.valid || n->data == nullptr) return;
     const uintptr_t a0 = (uintptr_t)g_qact.src_data, a1 = a0 + g_qact.src_bytes;
     const uintptr_t b0 = (uintptr_t)n->data, b1 = b0 + ggml_nbytes(n);
     if (b0 < a1 && a0 < b1) g_qact.valid = false;
+}
+void invalidate_xf16_if_overwritten_impl(const ggml_tensor *n) {
+    if (!g_xf16.valid || n->data == nullptr) return;
+    const uintptr_t a0 = (uintptr_t)g_xf16.src_data, a1 = a0 + g_xf16.src_bytes;
+    const uintptr_t b0 = (uintptr_t)n->data, b1 = b0 + ggml_nbytes(n);
+    if (b0 < a1 && a0 < b1) g_xf16.valid = false;
 }
 
 #include "llama_plan.inc"
@@ -942,6 +1048,7 @@ void execute_graph(ggml_cgraph *gr) {
     ensure_init();
     ws_reset();
     g_qact.valid = false;
+    g_xf16.valid = false;
     if (try_decode_plan(gr)) return;  // single-token LLaMA decode: fused launches + hipGraph replay
     g.stat_generic_graphs++;
     upload_inputs(gr);
@@ -1336,6 +1443,8 @@ void ggml_hip_set_option(const char *key, int value) {
     }
     else if (k == "mmvq_rows")
         g.opt_mmvq_rows = value;
+    else if (!strcmp(key, "mmq_min"))
+        g.opt_mmq_min = value;
     else
         die("ggml_hip_set_option: unknown key '%s'", key);
 }

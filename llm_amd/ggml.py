@@ -443,3 +443,12 @@ def timing_query(kclass):
     ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
     lib().ggml_hip_timing_query(kclass, C.byref(ms), C.byref(n), C.byref(b))
     return ms.value, n.value, b.value
+
+
+def get_stat(key):
+    """Backend counters (plan_tokens, graph_replays, plans, generic_graphs, ns_match, ns_launch, ns_wait, ns_compute)."""
+    return int(lib().ggml_hip_get_stat(key.encode()))
+
+
+def set_option(key, value):
+    lib().ggml_hip_set_option(key.encode(), int(value))

@@ -81,6 +81,36 @@ def test_logits_match_oracle_prompt_and_decode(G, O, wtype):
     assert n_strict >= 0.75 * n_chunks, (n_strict, n_chunks)
 
 
+@pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
+def test_prefill_batch_on_mfma_matches_oracle(G, O, wtype):
+    """A 48-token prompt evaluated as ONE batch (n_batch=64): every quantized mul_mat runs on the f16 MFMA GEMM
+    (kernels/mmq.h).  Besides f32 summation order, that path rounds each dequantized weight and activation to f16
+    (2^-11 unit roundoff), ~100x the f32 noise, so rounding-edge flips of downstream int8 activation quants are
+    the norm rather than the exception in the 128-wide test model.  Stated tolerance (relative to std(logits)):
+    max-abs <= TOL_MATH (6e-2, the reference's own exact-vs-math noise floor), RMS <= 2e-2; the decode steps
+    that follow (fused plan on the K/V the prefill wrote) are held to the same bound."""
+    toks = np.random.default_rng(43).integers(0, 256, 52).astype(np.int32)
+    hp, w, model = _mk(G, wtype, ctx=128, seed=7)
+    sess = model.start_session(n_batch=64)
+    orc = O.Llama(hp, w, 128)
+    G.lib().ggml_hip_timing_begin()
+    got = sess.evaluate(toks[:48])
+    G.lib().ggml_hip_timing_end()
+    _, launches, _ = G.timing_query(G.KCLASS_MMQ_MFMA)
+    assert launches == 7 * hp["n_layer"] + 1, launches  # wq wk wv wo w1 w3 w2 per layer + lm_head
+    ref = orc.evaluate(toks[:48], mode=0)
+    std = float(ref.std())
+    d = np.abs(got - ref) / std
+    print(f"type {wtype} prefill N=48: max {d.max():.2e} rms {np.sqrt((d ** 2).mean()):.2e}")
+    assert d.max() <= TOL_MATH and np.sqrt((d ** 2).mean()) <= 2e-2
+    for i in range(4):
+        g1 = sess.evaluate(toks[48 + i:49 + i])
+        r1 = orc.evaluate(toks[48 + i:49 + i], mode=0)
+        assert float(np.max(np.abs(g1 - r1))) / std <= TOL_MATH
+    sess.free()
+    model.free()
+
+
 def test_interior_taps_final_norm(G, O):
     """OutputRequest.embeddings (final norm output) against the oracle tap, prompt batch (generic path)."""
     hp, w, model = _mk(G, 2, seed=7)
@@ -244,6 +274,7 @@ def test_layer_split_stages_match_whole_model(G, O, wtype):
     st1.new_sequence(0)
     toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 6).astype(np.int32)
     chunk = toks
+    plan0 = G.get_stat("plan_tokens")
     for step in range(6):
         ref = ws.evaluate(chunk)
         res = st0.evaluate(0, chunk, None)
@@ -255,6 +286,8 @@ def test_layer_split_stages_match_whole_model(G, O, wtype):
         if d <= STRICT:
             assert tok == int(np.argmax(ref[-1]))
         chunk = np.array([int(np.argmax(ref[-1]))], np.int32)
+    # the 5 single-token steps ran on the fused decode plan in the whole model AND in both stage sessions
+    assert G.get_stat("plan_tokens") - plan0 == 15
     st0.free()
     st1.free()
     ws.free()

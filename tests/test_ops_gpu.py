@@ -56,6 +56,61 @@ def test_mul_mat_q_matches_oracle_exact(G, O, wtype, shape, N):
 
 
 @pytest.mark.parametrize("wtype", QTYPES)
+@pytest.mark.parametrize("shape", [(128, 64), (200, 96), (256, 4096), (384, 352), (130, 1024)])
+@pytest.mark.parametrize("N", [32, 33, 100, 128, 300])
+def test_mul_mat_q_prefill_mfma_matches_oracle(G, O, wtype, shape, N):
+    """N >= 32 tokens: the f16 MFMA GEMM (kernels/mmq.h).  Same contract as the mat-vec — activations
+    re-quantized to Q8_0/Q8_1 exactly as the reference does — plus one f16 rounding of each dequantized weight
+    and of each dequantized activation (unit roundoff 2^-11 each):
+        |got - exact| <= 2 * 2^-11 * sum_k |w||x|   (worst case; stated bound 1.1e-3 * scale)
+    and, because the roundings are unbiased, the RMS error is far below that (bound 1e-4 * scale)."""
+    M, K = shape
+    rng = np.random.default_rng([wtype, M, K, N, 1])
+    W = (0.02 * rng.standard_normal((M, K))).astype(np.float32)
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    X[:, ::7] *= 4.0
+    W_raw = G.quantize(wtype, W)
+    got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
+    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
+    scale = _abs_scale(O, wtype, W_raw, M, K, X)
+    err = np.abs(got - exact)
+    assert np.all(err <= 1.1e-3 * scale + 1e-7), float(np.max(err / (scale + 1e-12)))
+    assert float(np.sqrt(np.mean((err / (scale + 1e-12)) ** 2))) <= 1e-4
+    # the mat-vec path on the same inputs (mmq_min = 0 disables the GEMM) agrees to the same bound
+    G.set_option("mmq_min", 0)
+    try:
+        mv = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
+    finally:
+        G.set_option("mmq_min", 32)
+    assert np.all(np.abs(mv - exact) <= 2e-5 * scale + 1e-7)
+    assert not np.array_equal(mv, got)  # the two paths really are different kernels
+
+
+def test_mul_mat_q_prefill_mfma_is_used_and_handles_extremes(G, O):
+    """timing class MMQ_MFMA records the launch; zero rows/columns stay exactly zero; a huge activation is
+    clamped to the f16 range instead of producing inf."""
+    M, K, N = 256, 512, 64
+    rng = np.random.default_rng(11)
+    W = (0.02 * rng.standard_normal((M, K))).astype(np.float32)
+    W[5] = 0.0
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    X[3] = 0.0
+    X[4, 9] = 1e6
+    W_raw = G.quantize(2, W)
+    G.lib().ggml_hip_timing_begin()
+    got = _mul_mat_gpu(G, 2, W_raw, M, K, X)
+    G.lib().ggml_hip_timing_end()
+    ms, launches, flops = G.timing_query(G.KCLASS_MMQ_MFMA)
+    assert launches == 1 and flops == 2.0 * M * N * K and ms > 0
+    assert np.all(got[3] == 0.0) and np.all(got[:, 5] == 0.0)
+    assert np.isfinite(got).all()
+    exact = O.mul_mat(2, W_raw, M, K, X, mode=0)
+    ok = np.ones(N, bool)
+    ok[4] = False  # the clamped row differs from the reference by construction
+    assert np.allclose(got[ok], exact[ok], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("wtype", QTYPES)
 def test_mul_mat_q_raw_layout_operand(G, O, wtype):
     """A quantized weight that was never handed to transform_tensor (lives in the compute context) is
     re-laid-out on the fly: same numbers."""
@@ -224,10 +279,13 @@ def test_get_rows(G, O, wtype):
     assert np.array_equal(got, ref)
 
 
-def test_kv_store_and_attention_matmuls(G, O):
+@pytest.mark.parametrize("dims", [(4, 32, 64, 3, 5), (4, 32, 256, 40, 5), (3, 128, 512, 130, 71)])
+def test_kv_store_and_attention_matmuls(G, O, dims):
     """The KV-cache copy (K contiguous f16 run, V scatter-transposed), then K·Q and V·P over the cache,
-    wired exactly as crates/models/llama/src/lib.rs:228-307 for one layer."""
-    H, D, C, N, P = 4, 32, 64, 3, 5
+    wired exactly as crates/models/llama/src/lib.rs:228-307 for one layer.  N = 3: one-wave-per-output kernels;
+    N >= 32 (prompt batch): the batched f16 MFMA GEMM of kernels/gemm_f16.h, incl. ragged M/N tiles and a k tail
+    (T = 45, 201 is not a multiple of 8), with the cache beyond T holding NaN to prove the tail is masked."""
+    H, D, C, N, P = dims
     E = H * D
     T = P + N
     rng = np.random.default_rng(21)
@@ -236,11 +294,11 @@ def test_kv_store_and_attention_matmuls(G, O):
     q = rng.standard_normal((N, H, D)).astype(np.float32)
     k_past = rng.standard_normal((P, E)).astype(np.float16)
     v_past = rng.standard_normal((P, E)).astype(np.float16)
-    memk = np.zeros((C, E), np.float16)
+    memk = np.full((C, E), np.nan, np.float16)
     memk[:P] = k_past
-    memv = np.zeros((E, C), np.float16)
+    memv = np.full((E, C), np.nan, np.float16)
     memv[:, :P] = v_past.T
-    with G.Context(1 << 22) as sctx, G.Context(1 << 24) as ctx:
+    with G.Context(1 << 22) as sctx, G.Context(1 << 26) as ctx:
         mk = sctx.tensor_from(memk.reshape(-1), G.TYPE_F16).set_name("memory_k")
         mv = sctx.tensor_from(memv.reshape(-1), G.TYPE_F16).set_name("memory_v")
         mk.transfer_to_gpu()
@@ -269,13 +327,13 @@ def test_kv_store_and_attention_matmuls(G, O):
     # cache contents: exact f16 RNE conversion at the right places
     memk[P:T] = kc.astype(np.float16)
     memv[:, P:T] = vc.astype(np.float16).T
-    assert np.array_equal(got_memk, memk)
-    assert np.array_equal(got_memv, memv)
+    assert np.array_equal(got_memk, memk, equal_nan=True)
+    assert np.array_equal(got_memv, memv, equal_nan=True)
     # K·Q with f16-rounded Q (ggml converts src1 to f16), f32 accumulate
     Kf = memk[:T].astype(np.float32).reshape(T, H, D)
     Qf = q.astype(np.float16).astype(np.float32)
     ref_kq = np.einsum("thd,nhd->hnt", Kf.astype(np.float64), Qf.astype(np.float64))
-    assert np.allclose(got_kq, ref_kq, rtol=1e-5, atol=1e-5)
+    assert np.allclose(got_kq, ref_kq, rtol=1e-5, atol=1e-4 if D > 32 else 1e-5)
     pr = O.soft_max(got_kq, mode=0)
     Vf = memv[:, :T].astype(np.float64).reshape(H, D, T)
     ref = np.einsum("hdt,hnt->nhd", Vf, pr.astype(np.float16).astype(np.float64)).reshape(N, E)
