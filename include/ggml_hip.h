@@ -477,7 +477,7 @@ GGML_API void ggml_hip_timing_begin(void);
 GGML_API void ggml_hip_timing_end(void);
 GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes);
 /* Execution mode knobs: "fuse" (peephole fusion in the generic executor), "plan" (fused LLaMA decode plan),
- * "graph" (hipGraph replay of the plan), "mmvq_rows"; also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH. */
+ * "graph" (hipGraph replay of the plan), "mmvq_rows", "big", "mmq_min", "timeline"; also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH. */
 GGML_API void ggml_hip_set_option(const char *key, int value);
 /* Replays the launches of one kernel class of the most recent fused decode plan `replays` times from a
  * dedicated hipGraph between two HIP events on the backend stream (bench.py roofline leg). 0 on success. */
@@ -486,6 +486,11 @@ GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total
 /* Counters for tests: "plan_tokens" (tokens run by the fused decode plan), "graph_replays", "plans",
  * "generic_graphs".  -1 for an unknown key. */
 GGML_API int64_t ggml_hip_get_stat(const char *key);
+/* In-kernel timeline of the decode mat-vec launches (ggml_hip_set_option("timeline", 1), eager or graph mode):
+ * records of 8 x int64 {entry, loads issued, x staged, barrier passed, first weights landed, exit (100 MHz
+ * wall clock ticks), steps of wave 0, workgroup id}; 4 sampled workgroups per launch, launch order.
+ * Returns the number of records copied. */
+GGML_API size_t ggml_hip_read_timeline(int64_t *dst, size_t max_records);
 GGML_API const char *ggml_hip_version(void);
 
 #ifdef __cplusplus

@@ -34,6 +34,7 @@
 #include "kernels/gemm_f16.h"
 #include "kernels/ops.h"
 #include "kernels/decode.h"
+#include "kernels/decode_big.h"
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -122,6 +123,10 @@ struct Backend {
     // options
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
+    int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
+    int num_cus = 256;
+    long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
+    size_t timeline_bytes = 0;
     int opt_mmq_min = 32;   // token count from which mul_mat runs on the MFMA GEMM (0 = never)
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
     int opt_graph = 1;      // replay the plan from a captured hipGraph
@@ -159,6 +164,13 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_XSRC")) g.opt_xsrc = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMVQ_R")) g.opt_mmvq_rows = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_MIN")) g.opt_mmq_min = atoi(v);
+    if (const char *v = getenv("GGML_HIP_BIG")) g.opt_big = atoi(v);
+    {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, g.device));
+        g.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char *v = getenv("GGML_HIP_BIG_WGS")) g.num_cus = std::max(1, atoi(v));
+    }
     g.inited = true;
 }
 
@@ -1441,6 +1453,24 @@ void ggml_hip_set_option(const char *key, int value) {
         if (g.opt_xsrc != value) drop_all_plans();
         g.opt_xsrc = value;
     }
+    else if (k == "timeline") {
+        drop_all_plans();
+        if (value && !g.timeline) {
+            ensure_init();
+            g.timeline_bytes = (size_t)1024 * 4 * 8 * 8;
+            HIP_CHECK(hipMalloc((void **)&g.timeline, g.timeline_bytes));
+        }
+        if (!value && g.timeline) {
+            HIP_CHECK(hipStreamSynchronize(g.stream));
+            (void)hipFree(g.timeline);
+            g.timeline = nullptr;
+        }
+        if (g.timeline) HIP_CHECK(hipMemsetAsync(g.timeline, 0, g.timeline_bytes, g.stream));
+    }
+    else if (k == "big") {
+        if (g.opt_big != value) drop_all_plans();
+        g.opt_big = value;
+    }
     else if (k == "mmvq_rows")
         g.opt_mmvq_rows = value;
     else if (!strcmp(key, "mmq_min"))
@@ -1518,6 +1548,14 @@ int64_t ggml_hip_get_stat(const char *key) {
     if (k == "ns_wait") return (int64_t)g.ns_wait;        // ... waiting for the device + copying results out
     if (k == "ns_compute") return (int64_t)g.ns_compute;  // total inside ggml_graph_compute
     return -1;
+}
+size_t ggml_hip_read_timeline(int64_t *dst, size_t max_records) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (!g.timeline) return 0;
+    const size_t n = std::min(max_records, g.timeline_bytes / 64);
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    HIP_CHECK(hipMemcpy(dst, g.timeline, n * 64, hipMemcpyDeviceToHost));
+    return n;
 }
 const char *ggml_hip_version(void) { return "libggml_hip 0.1 (gfx950)"; }
 

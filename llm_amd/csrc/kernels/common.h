@@ -87,6 +87,11 @@ __device__ __forceinline__ float g8_max_f32(float v) {
     v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
     return fmaxf(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
 }
+__device__ __forceinline__ float g8_sum_f32(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    return v + dpp_f32<DPP_ROW_HALF_MIRROR>(v);
+}
 __device__ __forceinline__ int g8_sum_i32(int v) {
     v += dpp_i32<DPP_QUAD_XOR1>(v);
     v += dpp_i32<DPP_QUAD_XOR2>(v);

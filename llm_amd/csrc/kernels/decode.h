@@ -354,24 +354,31 @@ __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// decode attention for one query token: one 1024-thread workgroup (16 waves) per head, laid out so that the
-// whole head needs ~3 dependent memory round trips (q → K rows → V rows) instead of one per pass:
+// decode attention for one query token: one 1024-thread workgroup (16 waves) per head.
 //   s_t = Σ_d K[t][d]·f16(q[d])  (f32 accumulate)  for t = 0..P   (P = n_past, the new token included)
 //   p   = softmax(s·scale) with ggml's f16-rounded exp, then rounded to f16 (src1 of the V matmul)
 //   o_d = Σ_t V[d][t]·p_t ; the head's D outputs are re-quantized to Q8 blocks for the wo mat-vec and
 //   optionally written as f32 (merge-heads layout [E]).
 // K: [C][Egqa] f16 (per layer), V: [Egqa][C] f16 (per layer).  Dynamic LDS: (C + D) floats.
-//   scores : 64 groups of 16 lanes, a lane holds 8 dims (one 16-byte load per position), 4 positions per group
-//            in flight → 256 positions per pass;
-//   V·P    : wave w owns channels 8w..8w+7, a lane covers 8 consecutive positions of each with one 16-byte
-//            load → 8 loads in flight per lane, 512 positions per pass.
+//
+// At short context the kernel is a pure latency chain (a few tens of KB per head), so its shape is dictated by
+// round trips and instruction issue, not bandwidth (in-kernel timeline at 135 positions: position -> K/V loads
+// 5.3 us, V·P with 8 channels per wave and 3/4 of the lanes idle 2.6 us):
+//   * the FIRST 256 positions of K and V, q and the position itself are all requested at kernel entry — the
+//     loads do not wait for n_past (rows past the current position are read and ignored; they exist, the cache is
+//     allocated for C positions), so short contexts cost ONE memory round trip;
+//   * scores : 64 groups of 16 lanes, a lane holds 8 dims (one 16-byte load per position), 4 positions per group
+//              in flight → 256 positions per pass;
+//   * V·P    : wave w owns channels 8w..8w+7, 8 lanes per channel, a lane covers 8 consecutive positions per
+//              64-position pass → all lanes busy from 64 positions on, 8-lane DPP reduction at the end.
 // ---------------------------------------------------------------------------------------------------
 template <bool F16_D>
 __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ q, const __half *__restrict__ mem_k,
                                                       const __half *__restrict__ mem_v, const DecParams *prm,
                                                       float scale, int D, int n_rep /* H / Hkv */, int64_t Egqa,
                                                       int64_t C, float *out_f32, int8_t *lo, int8_t *hi, float *dq,
-                                                      int *sumq) {
+                                                      int *sumq, long long *ts) {
+    const long long t_entry = ts ? (long long)wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_s = (float *)smem;  // C scores / probabilities
     float *s_o = s_s + C;        // D outputs
@@ -379,27 +386,56 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     __shared__ double s_redd[16];
     const int h = blockIdx.x, hk = h / n_rep;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int T = prm->n_past + 1;
-    const int T8 = (T + 7) & ~7;
+    const int n_past = prm->n_past;  // requested first; nothing below waits for it until the masks are needed
     const float *qh = q + (int64_t)h * D;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- scores ----
-    const int g = tid >> 4, gl = tid & 15;  // 64 groups of 16 lanes
-    // D <= 128 and D % 8 == 0 (checked by the plan builder): lane gl owns dims gl*8 .. gl*8+7
-    const int d0 = gl * 8;
+    // ---- speculative first pass (positions 0..255 of K and V) + q
+    const int g = tid >> 4, gl = tid & 15;  // scores: 64 groups of 16 lanes, lane gl owns dims gl*8 .. gl*8+7
+    const int d0 = gl * 8;                  // D <= 128 and D % 8 == 0 (checked by the plan builder)
     const bool act = d0 < D;
+    const __half *kbase = mem_k + (int64_t)hk * D + d0;
+    f16x8 kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int t = g + 64 * u;
+        kv[u] = zero8;
+        if (act && t < C) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+    }
+    const int cv = wave * 8 + (lane >> 3), pj = (lane & 7) * 8;  // V·P: channel, first position inside a 64-pass
+    const bool vact = cv < D;
+    const __half *vbase = mem_v + ((int64_t)hk * D + cv) * C + pj;
+    f16x8 vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        vv[u] = zero8;
+        if (vact && 64 * u + pj + 8 <= C) vv[u] = *(const f16x8 *)(vbase + 64 * u);
+    }
+    f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
+    if (act) {
+        q0 = *(const f32x4 *)(qh + d0);
+        q1 = *(const f32x4 *)(qh + d0 + 4);
+    }
     float qf[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) qf[j] = act ? round_f16(qh[d0 + j]) : 0.0f;  // ggml rounds src1 (Q) to f16
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int c_first = wave * 8, tb_first = lane * 8;
+    for (int j = 0; j < 4; j++) {
+        qf[j] = round_f16(q0[j]);  // ggml rounds src1 (Q) to f16
+        qf[4 + j] = round_f16(q1[j]);
+    }
+    const int T = n_past + 1;
+    const int T8 = (T + 7) & ~7;
+    const long long t_loaded = ts ? (long long)wall_clock64() : 0;
+
+    // ---- scores ----
+#pragma unroll 1
     for (int t0 = g; t0 < T; t0 += 256) {
-        f16x8 kv[4];
+        if (t0 != g) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = t0 + 64 * u;
-            kv[u] = zero8;
-            if (act && t < T) kv[u] = *(const f16x8 *)(mem_k + (int64_t)t * Egqa + (int64_t)hk * D + d0);
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 64 * u;
+                kv[u] = zero8;
+                if (act && t < T) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -412,6 +448,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
         }
     }
     __syncthreads();
+    const long long t_scores = ts ? (long long)wall_clock64() : 0;
     // ---- softmax over T entries (ggml: max, f16-rounded exp of f16-rounded (x-max), f64 sum, scale by 1/sum) ----
     float mx = -INFINITY;
     for (int t = tid; t < T; t += 1024) mx = fmaxf(mx, s_s[t]);
@@ -437,38 +474,40 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     for (int t = tid; t < T8; t += 1024)
         s_s[t] = t < T ? round_f16(s_s[t] * inv) : 0.0f;  // probabilities as f16 (src1 of V·P); padding = 0
     __syncthreads();
+    const long long t_softmax = ts ? (long long)wall_clock64() : 0;
     // ---- V·P ----
-    for (int c0 = c_first; c0 < D; c0 += 128) {
-        float acc[8];
+    {
+        float acc = 0.0f;
+#pragma unroll 1
+        for (int p0 = 0; p0 < T8; p0 += 256) {
+            if (p0 != 0) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc[u] = 0.0f;
-        for (int tb = tb_first; tb < T8; tb += 512) {
-            f16x8 vv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                vv[u] = zero8;
-                if (c0 + u < D) vv[u] = *(const f16x8 *)(mem_v + ((int64_t)hk * D + c0 + u) * C + tb);
+                for (int u = 0; u < 4; u++) {
+                    vv[u] = zero8;
+                    if (vact && p0 + 64 * u + pj < T8) vv[u] = *(const f16x8 *)(vbase + p0 + 64 * u);
+                }
             }
-            const f32x4 p0 = *(const f32x4 *)(s_s + tb), p1 = *(const f32x4 *)(s_s + tb + 4);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                acc[u] += (float)vv[u][0] * p0[0];
-                acc[u] += (float)vv[u][1] * p0[1];
-                acc[u] += (float)vv[u][2] * p0[2];
-                acc[u] += (float)vv[u][3] * p0[3];
-                acc[u] += (float)vv[u][4] * p1[0];
-                acc[u] += (float)vv[u][5] * p1[1];
-                acc[u] += (float)vv[u][6] * p1[2];
-                acc[u] += (float)vv[u][7] * p1[3];
+            for (int u = 0; u < 4; u++) {
+                const int pos = p0 + 64 * u + pj;
+                if (pos < T8) {  // 8-position chunks past the context are never touched (their V is not ours)
+                    const f32x4 pa = *(const f32x4 *)(s_s + pos), pb = *(const f32x4 *)(s_s + pos + 4);
+                    acc += (float)vv[u][0] * pa[0];
+                    acc += (float)vv[u][1] * pa[1];
+                    acc += (float)vv[u][2] * pa[2];
+                    acc += (float)vv[u][3] * pa[3];
+                    acc += (float)vv[u][4] * pb[0];
+                    acc += (float)vv[u][5] * pb[1];
+                    acc += (float)vv[u][6] * pb[2];
+                    acc += (float)vv[u][7] * pb[3];
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const float r = wave_sum_f32(acc[u]);
-            if (lane == 0 && c0 + u < D) s_o[c0 + u] = r;
-        }
+        acc = g8_sum_f32(acc);
+        if ((lane & 7) == 0 && vact) s_o[cv] = acc;
     }
     __syncthreads();
+    const long long t_vp = ts ? (long long)wall_clock64() : 0;
     // ---- outputs: f32 (merged heads) + Q8 blocks (D/32 blocks per head) ----
     const int nblk = D / 32, l = tid & 31, b = tid >> 5;
     if (b < nblk) {
@@ -486,6 +525,14 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
         if (l == 0) {
             dq[gb] = F16_D ? round_f16(d) : d;
             sumq[gb] = sq;
+        }
+    }
+    if (ts && tid == 0) {
+        const int q4 = (int)gridDim.x / 4;
+        if (q4 > 0 && h % q4 == 0 && h / q4 < 4) {
+            long long *o = ts + (h / q4) * 8;
+            o[0] = t_entry; o[1] = t_loaded; o[2] = t_scores; o[3] = t_softmax; o[4] = t_vp;
+            o[5] = (long long)wall_clock64(); o[6] = T; o[7] = h;
         }
     }
 }

@@ -1,0 +1,380 @@
+// decode_big.h — the decode mat-vec as ONE wave of big workgroups: grid = #CUs x 1024 threads, every workgroup owns
+// a contiguous slab of output rows, the weight stream is prefetched PF steps deep into registers BEFORE the
+// activation is touched, and the activation's norm / re-quantization is done by each workgroup while those loads
+// are in flight.  Same arithmetic as k_mmvq_dec (decode.h) / k_mmvq (mmvq.h); same epilogues.
+//
+// Why (measured on MI355X, profiles/r01_run8): with 256-thread workgroups a LLaMA-7B mat-vec needs 512..4000
+// workgroups, each of which re-stages x (4.6 KB from L2, ~1 us of latency before its first dot) and has one
+// K-step of weights in flight; the E x E mat-vec ran at 1.9 TB/s, wq|wk|wv at 3.0 TB/s, and the separate
+// rms_norm+quantize / quantize launches in front of them cost ~6 us each (a 1-workgroup latency chain plus a
+// kernel boundary).  Here:
+//   * 256 workgroups = one per CU, resident at once: no dispatch tail, x staged 256 times instead of 4000;
+//   * 16 waves x PF steps x 16 B x rows-per-step in flight per lane before anything else happens
+//     (>= 128 KB per CU): the whole HBM pipe is busy from the first cycle of the kernel;
+//   * staging x = rms_norm (f64 sum of squares) -> weight -> Q8 blocks in LDS costs each workgroup ~1.5 us of
+//     latency that overlaps the weight prefetch, and removes 3 launches per layer (8 -> 5).
+// A "unit" is what one wave reduces together: a pair of adjacent rows for wq|wk|wv (RoPE rotates the pair),
+// row m of w1 and of w3 for the gate, one row otherwise.  A "step" is one 64-block column of a unit.
+#pragma once
+#include "decode.h"
+
+template <int QT, int NR>
+struct BigStep {
+    u32x4 q[NR];
+    u32x4 p[QT == QT_Q8_0 ? NR : 1];
+    uint32_t h[(QT == QT_Q5_0 || QT == QT_Q5_1) ? NR : 1];
+    __half dw[NR];
+    __half mw[(QT == QT_Q4_1 || QT == QT_Q5_1) ? NR : 1];
+};
+
+template <int QT>
+__device__ __forceinline__ constexpr int big_pf(int NR) {
+    // ring depth: ~64 VGPRs of weight data in flight per lane
+    const int per = NR * (4 + (QT == QT_Q8_0 ? 4 : 0) + ((QT == QT_Q5_0 || QT == QT_Q5_1) ? 1 : 0) + 1 +
+                          ((QT == QT_Q4_1 || QT == QT_Q5_1) ? 1 : 0));
+    return 64 / per >= 8 ? 8 : 64 / per >= 2 ? 64 / per : 2;  // Q4_0: 6 steps of 2 rows, 8 steps of 1 row
+}
+
+struct BigArgs {
+    DecMmvqArgs d;
+    float *y_out;  // XSRC_NORM: optional f32 copy of the normed row (final norm -> OutputRequest.embeddings)
+    long long *ts;  // optional timeline slot (ggml_hip_set_option("timeline", 1)): 8 x int64 per sampled workgroup
+};
+#define BIG_TS_WGS 4  // workgroups 0, G/4, G/2, 3G/4 record
+__device__ __forceinline__ long long big_now() { return (long long)wall_clock64(); }  // 100 MHz, chip-wide
+
+// The activation's global loads, issued as the FIRST memory operations of the kernel: a wave's loads return in
+// order, so anything issued after the weight prefetch would only become usable after the whole prefetch landed
+// (measured: norm staging behind the prefetch made the kernels additive, 16.6 us for wq|wk|wv instead of ~8).
+template <int XSRC>
+struct BigX;
+template <>
+struct BigX<XSRC_Q8> {
+    i32x4 lo, hi;
+    float d;
+    int sum;
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid) {
+        const int64_t i = tid < nb ? tid : 0;  // nb <= 1024 (checked by the launcher)
+        lo = a.d.x.lo[i];
+        hi = a.d.x.hi[i];
+        d = a.d.x.d[i];
+        sum = a.d.x.sum[i];
+    }
+};
+template <>
+struct BigX<XSRC_F32> {
+    static constexpr int MAXIT = 6;  // rows up to 24576 wide
+    f32x4 v[MAXIT];
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid) {
+        const int64_t n4 = nb * 8;
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * 1024 + tid;
+            v[it] = ((const f32x4 *)a.d.xf)[i4 < n4 ? i4 : 0];
+        }
+    }
+};
+template <>
+struct BigX<XSRC_NORM> {
+    // The norm is staged by the first 512 threads only (8 waves, 2 per SIMD): its fixed per-thread cost (f64
+    // reduction and division, sqrt, the block scale divisions) is then paid 512 instead of 1024 times per CU — the
+    // staging is VALU-issue-bound, not latency-bound, once its loads have landed.  Waves 8..15 issue the same
+    // number of (single-address) loads so that every wave's load queue has the same compile-time shape.
+    static constexpr int NT = 512, MAXIT = 4;  // rows up to 8192 wide
+    f32x4 v[MAXIT], w[MAXIT];
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid) {
+        const int64_t n4 = nb * 8;
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * NT + tid;
+            const int64_t ic = (tid < NT && i4 < n4) ? i4 : 0;
+            v[it] = ((const f32x4 *)a.d.xf)[ic];
+            w[it] = ((const f32x4 *)a.d.xw)[ic];
+        }
+    }
+};
+
+// registers -> LDS as padded planar Q8 (nbp = nbl*64 blocks; blocks >= nb are zero so tail steps contribute 0)
+template <bool F16_D, int XSRC>
+__device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int64_t nb, int64_t nbp, int tid,
+                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part) {
+    const DecMmvqArgs &d = a.d;
+    (void)s_part;
+    for (int64_t i = nb + tid; i < nbp; i += 1024) {
+        s_lo[i] = i32x4{0, 0, 0, 0};
+        s_hi[i] = i32x4{0, 0, 0, 0};
+        s_d[i] = 0.0f;
+        s_sum[i] = 0;
+    }
+    const int64_t n4 = nb * 8;
+    if constexpr (XSRC == XSRC_Q8) {
+        if (tid < nb) {
+            s_lo[tid] = xr.lo;
+            s_hi[tid] = xr.hi;
+            s_d[tid] = xr.d;
+            s_sum[tid] = xr.sum;
+        }
+    } else if constexpr (XSRC == XSRC_F32) {
+#pragma unroll
+        for (int it = 0; it < BigX<XSRC_F32>::MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * 1024 + tid;
+            if ((int64_t)it * 1024 >= n4) break;  // uniform
+            const f32x4 v = i4 < n4 ? xr.v[it] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            quant4_to_lds<F16_D>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+        }
+    } else {
+        constexpr int MAXIT = BigX<XSRC_NORM>::MAXIT, NT = BigX<XSRC_NORM>::NT;
+        const bool stager = tid < NT;  // wave-uniform
+        if (stager) {
+            double ss = 0.0;
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                const int64_t i4 = (int64_t)it * NT + tid;
+                if (i4 < n4) {
+                    ss += (double)(xr.v[it][0] * xr.v[it][0]);
+                    ss += (double)(xr.v[it][1] * xr.v[it][1]);
+                    ss += (double)(xr.v[it][2] * xr.v[it][2]);
+                    ss += (double)(xr.v[it][3] * xr.v[it][3]);
+                }
+            }
+            ss = wave_sum_f64(ss);
+            if ((tid & 63) == 0) s_part[tid >> 6] = ss;
+        }
+        __syncthreads();
+        if (stager) {
+            double tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT / 64; i++) tot += s_part[i];
+            const float mean = (float)(tot / (double)(nb * 32));
+            const float scale = 1.0f / sqrtf(mean + d.eps);
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                const int64_t i4 = (int64_t)it * NT + tid;
+                if ((int64_t)it * NT >= n4) break;  // uniform
+                f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (i4 < n4) {
+                    y[0] = (xr.v[it][0] * scale) * xr.w[it][0];
+                    y[1] = (xr.v[it][1] * scale) * xr.w[it][1];
+                    y[2] = (xr.v[it][2] * scale) * xr.w[it][2];
+                    y[3] = (xr.v[it][3] * scale) * xr.w[it][3];
+                    if (a.y_out && blockIdx.x == 0) ((f32x4 *)a.y_out)[i4] = y;
+                }
+                quant4_to_lds<F16_D>(y, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+            }
+        }
+    }
+}
+
+template <int QT, int EPI, int XSRC>
+__global__ void __launch_bounds__(1024) k_mmvq_big(const BigArgs ba) {
+    const DecMmvqArgs &a = ba.d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_part[16];
+    constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
+    constexpr int RU = EPI == EPI_QKV ? 2 : 1, NW = EPI == EPI_GATE ? 2 : 1, NR = RU * NW;
+    constexpr int PF = big_pf<QT>(NR);
+    constexpr int PF0 = PF < 2 ? PF : 2;  // steps requested before x is staged (see step 2)
+    // all index arithmetic is 32-bit (rows <= 2^17, blocks per matrix < 2^27): 64-bit divides and multiplies in
+    // the prologue cost ~1 us of VALU time per launch
+    const int nb = (int)a.nb;
+    const int nbl = (nb + 63) >> 6;
+    const int nbp = nbl * 64;
+    i32x4 *s_lo = (i32x4 *)smem;
+    i32x4 *s_hi = s_lo + nbp;
+    float *s_d = (float *)(s_hi + nbp);
+    int *s_sum = (int *)(s_d + nbp);
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform values must be uniform FOR THE COMPILER too (scalar registers, scalar selects of the matrix
+    // pointers): a kernarg array indexed by a "divergent" segment id is fetched with vector loads, and waiting for
+    // those drains the whole in-order load queue at every step
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const long long t_entry = ba.ts ? big_now() : 0;
+    // ---- 1. the activation's loads go first (see BigX); so does the position (needed by the QKV epilogue only)
+    int n_past = 0;
+    if constexpr (EPI == EPI_QKV) n_past = a.prm->n_past;
+    BigX<XSRC> xr;
+    xr.load(ba, nb, tid);
+
+    // this wave's units: ((i * G + g) * 16 + wave), i < nu — at any moment the G workgroups together stream ONE
+    // contiguous window of G*16 units of the matrix.  Lane i of the wave owns unit i's epilogue.
+    const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0, M2 = EPI == EPI_QKV ? (int)a.w[2].M : 0;
+    const int Utot = (M0 + M1 + M2) / RU;
+    const int u_first = (int)blockIdx.x * 16 + wave, u_stride = (int)gridDim.x * 16;
+    const int nu = u_first < Utot ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
+    const int S = nu * nbl;
+    // EPI_ADD: lane i preloads the residual of unit i (a load issued in the epilogue would drain the queue)
+    float res_pre = 0.0f;
+    if constexpr (EPI == EPI_ADD) {
+        const int m = u_first + u_stride * lane;
+        res_pre = a.res[(lane < nu && m < Utot) ? m : 0];
+    }
+
+    // unit -> (matrix, first row)
+    auto resolve = [&](int i, int &sg, int &m0) {
+        int r = (u_first + u_stride * i) * RU;
+        if (r >= Utot * RU) r = 0;  // dummy prefetch steps of a wave without (enough) units: any valid row
+        sg = 0;
+        m0 = r;
+        if constexpr (EPI == EPI_QKV) {
+            if (r >= M0 + M1) {
+                sg = 2;
+                m0 = r - M0 - M1;
+            } else if (r >= M0) {
+                sg = 1;
+                m0 = r - M0;
+            }
+        }
+    };
+    // The loads of a step are UNCONDITIONAL (addresses clamped; lanes past the row end read block nb-1 and meet
+    // zero x blocks in LDS): the number of memory operations in flight is a compile-time constant at every
+    // wait, so hipcc waits for exactly the step it needs (s_waitcnt vmcnt(N)) instead of draining the queue.
+    auto issue = [&](BigStep<QT, NR> &st, int i, int j, bool dummy) {
+        int sg, m0;
+        resolve(i, sg, m0);
+        const int b = lane + 64 * j;
+        const int bc = dummy ? 0 : (b < nb ? b : nb - 1);  // a dummy step reads one line for the whole wave
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const uint8_t *qs = a.w[0].qs, *qs2 = a.w[0].qs2;
+            const uint32_t *qh = a.w[0].qh;
+            const __half *wd = a.w[0].d, *wm = a.w[0].m;
+            if constexpr (EPI == EPI_GATE) {
+                if (k == 1) {
+                    qs = a.w[1].qs; qs2 = a.w[1].qs2; qh = a.w[1].qh; wd = a.w[1].d; wm = a.w[1].m;
+                }
+            } else if constexpr (EPI == EPI_QKV) {  // scalar selects (sg is wave-uniform)
+                qs = sg == 0 ? a.w[0].qs : sg == 1 ? a.w[1].qs : a.w[2].qs;
+                qs2 = sg == 0 ? a.w[0].qs2 : sg == 1 ? a.w[1].qs2 : a.w[2].qs2;
+                qh = sg == 0 ? a.w[0].qh : sg == 1 ? a.w[1].qh : a.w[2].qh;
+                wd = sg == 0 ? a.w[0].d : sg == 1 ? a.w[1].d : a.w[2].d;
+                wm = sg == 0 ? a.w[0].m : sg == 1 ? a.w[1].m : a.w[2].m;
+            }
+            const uint32_t o = (uint32_t)(m0 + (EPI == EPI_QKV ? k : 0)) * (uint32_t)nb + (uint32_t)bc;
+            st.q[k] = __builtin_nontemporal_load((const u32x4 *)(qs + (size_t)o * 16));
+            if constexpr (QT == QT_Q8_0) st.p[k] = __builtin_nontemporal_load((const u32x4 *)(qs2 + (size_t)o * 16));
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) st.h[k] = __builtin_nontemporal_load(qh + o);
+            st.dw[k] = wd[o];
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) st.mw[k] = wm[o];
+        }
+    };
+
+    // ---- 2. weight prologue, part 1: PF0 steps.  Enough to cover the latency of x, little enough that x is not
+    //         queued behind tens of MB of weight requests in the fabric (measured with the in-kernel timeline:
+    //         with the full ring requested up front x took 3..6 us to arrive)
+    BigStep<QT, NR> ring[PF];
+    int pi = 0, pj = 0;  // producer position (unit, column); steps past the wave's last one are dummies
+    auto advance = [&](int k) {
+        if (k + 1 < S && ++pj == nbl) {
+            pj = 0;
+            pi++;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PF0; k++) {
+        issue(ring[k], pi, pj, k >= S);
+        advance(k);
+    }
+    const long long t_issued = ba.ts ? big_now() : 0;
+
+    // ---- 3. norm / re-quantization of x into LDS
+    big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, s_lo, s_hi, s_d, s_sum, s_part);
+    const long long t_staged = ba.ts ? big_now() : 0;
+    // ---- 2b. the rest of the ring
+#pragma unroll
+    for (int k = PF0; k < PF; k++) {
+        issue(ring[k], pi, pj, k >= S);
+        advance(k);
+    }
+    __syncthreads();
+    const long long t_barrier = ba.ts ? big_now() : 0;
+    long long t_first = 0;
+
+    // ---- 4. dots.  The unrolled body only accumulates; when a unit's last column is done its NR sums are reduced
+    //         across the wave and parked in lane `unit index` (myv), the epilogues run afterwards, one lane each.
+    float acc[NR], myv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) acc[k] = myv[k] = 0.0f;
+    int ci = 0, cj = 0;  // consumer position
+    for (int s = 0; s < S; s += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            if (s + k < S) {  // wave-uniform
+                const int b = lane + 64 * cj;  // < nbp: the padded LDS blocks are zero
+                const i32x4 lo = s_lo[b], hi = s_hi[b];
+                const float xd = s_d[b];
+                const int xs = s_sum[b];
+                const BigStep<QT, NR> &st = ring[k];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    u32x4 p2 = st.q[r];
+                    uint32_t hh = 0;
+                    float mw = 0.0f;
+                    if constexpr (QT == QT_Q8_0) p2 = st.p[r];
+                    if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) hh = st.h[r];
+                    if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mw = __half2float(st.mw[r]);
+                    acc[r] += block_dot<QT>(st.q[r], p2, hh, __half2float(st.dw[r]), mw, lo, hi, xd, xs);
+                }
+                if (ba.ts && s + k == 0) t_first = acc[0] != 12345.678f ? big_now() : 1;  // first step's weights landed
+                if (++cj == nbl) {
+                    cj = 0;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const float v = wave_sum_f32(acc[r]);
+                        myv[r] = lane == ci ? v : myv[r];
+                        acc[r] = 0.0f;
+                    }
+                    ci++;
+                }
+                if (s + k + PF < S) {
+                    issue(ring[k], pi, pj, false);
+                    if (++pj == nbl) {
+                        pj = 0;
+                        pi++;
+                    }
+                }
+            }
+        }
+    }
+    const long long t_dots = ba.ts ? big_now() : 0;
+
+    // ---- 5. epilogues: lane i finishes unit i
+    if (lane < nu) {
+        int sg, m0;
+        resolve(lane, sg, m0);
+        if constexpr (EPI == EPI_STORE) {
+            a.dst[m0] = myv[0];
+        } else if constexpr (EPI == EPI_ADD) {
+            a.dst[m0] = myv[0] + res_pre;
+        } else if constexpr (EPI == EPI_GATE) {
+            a.dst[m0] = silu_table(myv[0]) * myv[1];
+        } else {  // EPI_QKV, see k_mmvq_dec
+            const int p = n_past;
+            if (sg == 2) {
+                a.mem_v[(int64_t)m0 * a.C + p] = __float2half_rn(myv[0]);
+                a.mem_v[(int64_t)(m0 + 1) * a.C + p] = __float2half_rn(myv[1]);
+            } else {
+                const int kk = (m0 % a.D) >> 1;
+                float theta = a.freq_scale * (float)p;
+                for (int t = 0; t < kk; t++) theta *= a.theta_scale;
+                const float c = cosf(theta), sn = sinf(theta);
+                const float r0 = myv[0] * c - myv[1] * sn, r1 = myv[0] * sn + myv[1] * c;
+                if (sg == 0) {
+                    a.dst[m0] = r0;
+                    a.dst[m0 + 1] = r1;
+                } else {
+                    a.mem_k[(int64_t)p * a.Egqa + m0] = __float2half_rn(r0);
+                    a.mem_k[(int64_t)p * a.Egqa + m0 + 1] = __float2half_rn(r1);
+                }
+            }
+        }
+    }
+    if (ba.ts && wave == 0 && lane == 0) {
+        const int q = (int)gridDim.x / BIG_TS_WGS;
+        if (q > 0 && blockIdx.x % q == 0 && (int)blockIdx.x / q < BIG_TS_WGS) {
+            long long *o = ba.ts + ((int)blockIdx.x / q) * 8;
+            o[0] = t_entry; o[1] = t_issued; o[2] = t_staged; o[3] = t_barrier; o[4] = t_first; o[5] = big_now();
+            o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = blockIdx.x;
+        }
+    }
+}

@@ -213,6 +213,7 @@ PROTOTYPES.update({
     "ggml_hip_timing_query": (None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ggml_hip_set_option": (None, [C.c_char_p, C.c_int]),
     "ggml_hip_get_stat": (C.c_int64, [C.c_char_p]),
+    "ggml_hip_read_timeline": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ggml_hip_bench_plan_class": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_double)]),
     "ggml_hip_version": (C.c_char_p, []),
@@ -452,3 +453,11 @@ def get_stat(key):
 
 def set_option(key, value):
     lib().ggml_hip_set_option(key.encode(), int(value))
+
+
+def read_timeline(max_records=4096):
+    """int64 [n, 8] records of the decode mat-vec timeline (see ggml_hip_read_timeline)."""
+    import numpy as np
+    buf = np.zeros((max_records, 8), np.int64)
+    n = lib().ggml_hip_read_timeline(buf.ctypes.data, max_records)
+    return buf[:n]

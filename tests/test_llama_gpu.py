@@ -111,6 +111,31 @@ def test_prefill_batch_on_mfma_matches_oracle(G, O, wtype):
     model.free()
 
 
+def test_decode_attention_beyond_first_pass(G, O):
+    """k_attn_decode requests the first 256 positions speculatively and loops for the rest: decode at positions
+    300..303 (second pass of K and of V) against the oracle on the same K/V state."""
+    toks = np.random.default_rng(44).integers(0, 256, 304).astype(np.int32)
+    hp, w, model = _mk(G, 2, ctx=512, seed=11)
+    sess = model.start_session(n_batch=64)
+    orc = O.Llama(hp, w, 512)
+    sess.feed_prompt(toks[:300])
+    orc.evaluate(toks[:300], mode=0)
+    p0 = _stat(G, "plan_tokens")
+    worst = 0.0
+    for i in range(4):
+        k, v = sess.get_kv()
+        orc.memory_k[:] = k
+        orc.memory_v[:] = v
+        got = sess.evaluate(toks[300 + i:301 + i])
+        ref = orc.evaluate(toks[300 + i:301 + i], mode=0)
+        worst = max(worst, float(np.max(np.abs(got - ref))) / float(ref.std()))
+    assert _stat(G, "plan_tokens") - p0 == 4
+    print(f"decode at n_past 300..303: worst gpu-vs-exact {worst:.2e}")
+    assert worst <= EDGE
+    sess.free()
+    model.free()
+
+
 def test_interior_taps_final_norm(G, O):
     """OutputRequest.embeddings (final norm output) against the oracle tap, prompt batch (generic path)."""
     hp, w, model = _mk(G, 2, seed=7)
@@ -203,9 +228,11 @@ def test_decode_plan_and_hipgraph_replay_match_generic_executor(G, O, wtype):
     hp, w, model = _mk(G, wtype, seed=7)
     toks = np.random.default_rng(5).integers(0, hp["n_vocab"], 14).astype(np.int32)
     outs = {}
-    for mode, (plan, graph) in {"generic": (0, 0), "plan-eager": (1, 0), "plan-graph": (1, 1)}.items():
+    modes = {"generic": (0, 0, 1), "plan-eager": (1, 0, 1), "plan-graph": (1, 1, 1), "plan-small-wg": (1, 1, 0)}
+    for mode, (plan, graph, big) in modes.items():
         G.lib().ggml_hip_set_option(b"plan", plan)
         G.lib().ggml_hip_set_option(b"graph", graph)
+        G.lib().ggml_hip_set_option(b"big", big)  # 1: k_mmvq_big (decode_big.h), 0: k_mmvq_dec + separate norm/quant
         p0, r0, g0 = _stat(G, "plan_tokens"), _stat(G, "graph_replays"), _stat(G, "generic_graphs")
         s = model.start_session(n_batch=8)
         s.feed_prompt(toks[:6])
@@ -216,11 +243,15 @@ def test_decode_plan_and_hipgraph_replay_match_generic_executor(G, O, wtype):
             assert dp == 0 and dg == 9
         else:
             assert dp == 8 and dg == 1, (dp, dg)   # the N=6 prompt batch is the only generic graph
-            assert (dr == 8) == (mode == "plan-graph"), dr
+            assert (dr == 8) == (mode != "plan-eager"), dr
     G.lib().ggml_hip_set_option(b"plan", 1)
     G.lib().ggml_hip_set_option(b"graph", 1)
+    G.lib().ggml_hip_set_option(b"big", 1)
     std = outs["generic"].std()
     assert np.array_equal(outs["plan-eager"], outs["plan-graph"])      # same kernels, replayed
+    d_small = np.max(np.abs(outs["plan-small-wg"] - outs["plan-graph"])) / std
+    print(f"type {wtype}: big-vs-small workgroup decode kernels {d_small:.2e}")
+    assert d_small <= EDGE
     orc = O.Llama(hp, w, 64)
     orc.evaluate(toks[:6], mode=0)
     ref = np.stack([orc.evaluate(toks[6 + i:7 + i], mode=0)[0] for i in range(8)])
