@@ -480,7 +480,9 @@ GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, d
  * "graph" (hipGraph replay of the plan), "mmvq_rows", "big", "mmq_min", "timeline"; also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH. */
 GGML_API void ggml_hip_set_option(const char *key, int value);
 /* Replays the launches of one kernel class of the most recent fused decode plan `replays` times from a
- * dedicated hipGraph between two HIP events on the backend stream (bench.py roofline leg). 0 on success. */
+ * dedicated hipGraph between two HIP events on the backend stream (bench.py roofline leg). 0 on success.
+ * kclass may also be GGML_HIP_KKIND_BASE + {0 wq|wk|wv, 1 wo, 2 w1|w3, 3 w2, 4 lm_head}: that mat-vec alone. */
+#define GGML_HIP_KKIND_BASE 16
 GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
                                        double *algo_bytes_per_replay);
 /* Counters for tests: "plan_tokens" (tokens run by the fused decode plan), "graph_replays", "plans",

@@ -1486,6 +1486,11 @@ void ggml_hip_set_option(const char *key, int value) {
 int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
                               double *algo_bytes_per_replay) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
+    unsigned kind_mask = ~0u;
+    if (kclass >= GGML_HIP_KKIND_BASE && kclass < GGML_HIP_KKIND_BASE + 5) {  // one kind of mat-vec launch alone
+        kind_mask = 1u << (kclass - GGML_HIP_KKIND_BASE);
+        kclass = GGML_HIP_KCLASS_MMVQ;
+    }
     if (g_plans.empty() || kclass < 0 || kclass >= GGML_HIP_KCLASS_COUNT || replays < 1) return -1;
     DecodePlan *p = g_plans.back();
     HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -1504,7 +1509,7 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     HIP_CHECK(hipEventCreate(&b));
     if (g.opt_graph) {
         HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-        plan_launch_all(p, 1u << kclass, &st);
+        plan_launch_all(p, 1u << kclass, &st, kind_mask);
         HIP_CHECK(hipStreamEndCapture(g.stream, &gr));
         HIP_CHECK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
         HIP_CHECK(hipGraphLaunch(ex, g.stream));  // warm
@@ -1512,9 +1517,9 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
         for (int i = 0; i < replays; i++) HIP_CHECK(hipGraphLaunch(ex, g.stream));
         HIP_CHECK(hipEventRecord(b, g.stream));
     } else {  // GGML_HIP_GRAPH=0 (e.g. under rocprofv3, whose kernel tracing crashes on graph launches here)
-        plan_launch_all(p, 1u << kclass, &st);
+        plan_launch_all(p, 1u << kclass, &st, kind_mask);
         HIP_CHECK(hipEventRecord(a, g.stream));
-        for (int i = 0; i < replays; i++) plan_launch_all(p, 1u << kclass, nullptr);
+        for (int i = 0; i < replays; i++) plan_launch_all(p, 1u << kclass, nullptr, kind_mask);
         HIP_CHECK(hipEventRecord(b, g.stream));
     }
     HIP_CHECK(hipStreamSynchronize(g.stream));

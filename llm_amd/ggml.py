@@ -20,6 +20,7 @@ BACKEND_CPU, BACKEND_GPU, BACKEND_GPU_SPLIT = 0, 10, 20
 OP_NONE, OP_MUL_MAT = 0, 21
 MAX_NODES, MAX_SRC, MAX_NAME, HASHTABLE = 4096, 6, 48, 8273
 KCLASS_MMVQ, KCLASS_MMQ_MFMA, KCLASS_ATTN, KCLASS_OTHER = 0, 1, 2, 3
+KKIND_BASE = 16  # + {0 wq|wk|wv, 1 wo, 2 w1|w3, 3 w2, 4 lm_head}: one kind of decode mat-vec (bench_plan_class)
 
 TYPE_NAMES = {TYPE_F32: "f32", TYPE_F16: "f16", TYPE_Q4_0: "q4_0", TYPE_Q4_1: "q4_1", TYPE_Q5_0: "q5_0",
               TYPE_Q5_1: "q5_1", TYPE_Q8_0: "q8_0", TYPE_I32: "i32"}
