@@ -127,6 +127,8 @@ struct Backend {
     int num_cus = 256;
     long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
     size_t timeline_bytes = 0;
+    int opt_mmq_splitk = 1;
+    int opt_mmq_xcdn = 0;   // pin XCDs to token tiles (measured slower than the tile-id walk: 393 vs 446 TFLOP/s)
     int opt_mmq_min = 32;   // token count from which mul_mat runs on the MFMA GEMM (0 = never)
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
     int opt_graph = 1;      // replay the plan from a captured hipGraph
@@ -165,6 +167,8 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_MMVQ_R")) g.opt_mmvq_rows = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_MIN")) g.opt_mmq_min = atoi(v);
     if (const char *v = getenv("GGML_HIP_BIG")) g.opt_big = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_SPLITK")) g.opt_mmq_splitk = atoi(v);
     {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, g.device));
@@ -678,7 +682,14 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
     a.nb = nb;
     const int tiles_m = (int)((a.M + MMQ_TM - 1) / MMQ_TM);
     a.tiles_n = (int)((N + MMQ_TN - 1) / MMQ_TN);
-    const dim3 grid((unsigned)(tiles_m * a.tiles_n));
+    // too few tiles to fill the chip (E x E at 512 tokens: 128 tiles for 256 CUs): split K in two, combined with
+    // commutative (2-addend) f32 atomic adds into a zeroed dst
+    const int nstage = (int)((nb + 1) / 2);
+    const int splits = (g.opt_mmq_splitk && tiles_m * a.tiles_n * 4 <= g.num_cus * 3 && nstage >= 16 &&
+                        dst->nb[0] == 4 && ggml_is_contiguous(dst)) ? 2 : 1;
+    if (splits > 1) HIP_CHECK(hipMemsetAsync(a.dst, 0, (size_t)a.M * N * 4, g.stream));
+    a.xcd_by_n = g.opt_mmq_xcdn && (a.tiles_n == 1 || a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && tiles_m % (8 / a.tiles_n) == 0;
+    const dim3 grid((unsigned)(tiles_m * a.tiles_n), (unsigned)splits);
     static bool lds_attr_set = false;
     if (!lds_attr_set) {  // 73.7 KB of dynamic LDS: above the 64 KB a kernel gets without opting in
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
@@ -1475,6 +1486,8 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_mmvq_rows = value;
     else if (!strcmp(key, "mmq_min"))
         g.opt_mmq_min = value;
+    else if (!strcmp(key, "mmq_splitk"))
+        g.opt_mmq_splitk = value;
     else
         die("ggml_hip_set_option: unknown key '%s'", key);
 }

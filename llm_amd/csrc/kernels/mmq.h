@@ -120,6 +120,23 @@ __device__ __forceinline__ void mmq_dequant(const u32x4 q, const u32x4 q2, const
     }
 }
 
+// one 32-bit output (two f16) of the block dequantization: word k (0..3), slot t (0..3) — see mmq_dequant
+template <int QT>
+__device__ __forceinline__ uint32_t mmq_dequant_slice(const u32x4 q, const u32x4 q2, const uint32_t qh, int k, int t,
+                                                      f16x2 dd, f16x2 mm) {
+    uint32_t src;  // bytes = codes of elements 4k..4k+3 (t < 2) or 16+4k..16+4k+3 (t >= 2)
+    if constexpr (QT == QT_Q4_0 || QT == QT_Q4_1) {
+        src = (t < 2 ? q[k] : (q[k] >> 4)) & 0x0F0F0F0Fu;
+    } else if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) {
+        const uint32_t h4 = (qh >> ((t < 2 ? 0 : 16) + 4 * k)) & 0xFu;
+        src = ((t < 2 ? q[k] : (q[k] >> 4)) & 0x0F0F0F0Fu) | (((h4 * 0x00204081u) & 0x01010101u) << 4);
+    } else {
+        src = (t < 2 ? q[k] : q2[k]) ^ 0x80808080u;
+    }
+    const uint32_t magic = (((t & 1) ? (src >> 8) : src) & 0x00FF00FFu) | 0x64006400u;
+    return mmq_cvt<QT>(magic, dd, mm);
+}
+
 // One k-stage (64 k) of the 128 x 128 workgroup tile on the matrix cores, shared by the quantized GEMM and the
 // f16 batched GEMM (gemm_f16.h).  Wt / Xt: LDS tiles [128 rows][MMQ_ROWB bytes] of f16, k contiguous.
 // acc[j][i]: rows = Xt rows wn*64 + j*32.. (MFMA A operand), columns = Wt rows wm*64 + i*32.. (B operand).
@@ -153,48 +170,72 @@ struct MmqArgs {
     int64_t ldd;
     int64_t M, N, nb;
     int tiles_n;
+    int xcd_by_n;  // 1: XCD x works on token tile x % tiles_n only (its slice of the activations stays in that L2)
 };
 
-// registers holding one stage of global data in flight
+// registers holding one stage of global data in flight: the weight block (5..10 VGPRs) and the 4 activation chunks
+// (16 VGPRs); two ring slots each (stages s+1 and s+2)
 template <int QT>
-struct MmqStage {
+struct MmqW {
     u32x4 q, q2;
     uint32_t qh;
     _Float16 d, m;
+};
+struct MmqX {
     u32x4 xa[4];
 };
 
+// Branch-free so that the whole k-stage is ONE basic block: addresses are clamped to the last valid block, and a
+// block past the end of K gets d = m = 0 (its dequantized weights are exactly 0, which also cancels the — finite —
+// activations loaded for it).
 template <int QT>
-__device__ __forceinline__ void mmq_load(MmqStage<QT> &s, const MmqArgs &a, int64_t wrow, int64_t kb /*first block*/,
-                                         int wj, const _Float16 *xrow[4], int xc, bool kvalid) {
-    // weights: this thread's block (row wrow, block kb + wj)
-    const int64_t blk = wrow * a.nb + kb + wj;
-    if (kvalid) {
-        s.q = __builtin_nontemporal_load((const u32x4 *)(a.w.qs) + blk);
-        if constexpr (QT == QT_Q8_0) s.q2 = __builtin_nontemporal_load((const u32x4 *)(a.w.qs2) + blk);
-        if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) s.qh = a.w.qh[blk];
-        s.d = ((const _Float16 *)a.w.d)[blk];
-        if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) s.m = ((const _Float16 *)a.w.m)[blk];
-    }
-    // activations: 4 chunks of 16 B; chunk column xc (0..7) of rows xrow[i]
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int64_t kel = kb * 32 + xc * 8;
-        if (kel < a.nb * 32)
-            s.xa[i] = *(const u32x4 *)(xrow[i] + kel);
-        else
-            s.xa[i] = u32x4{0, 0, 0, 0};
+__device__ __forceinline__ void mmq_load_w(MmqW<QT> &s, const MmqArgs &a, int64_t wrow, int64_t kb /*first block*/, int wj) {
+    const bool kvalid = kb + wj < a.nb;
+    const int64_t blk = wrow * a.nb + (kvalid ? kb + wj : a.nb - 1);
+    s.q = __builtin_nontemporal_load((const u32x4 *)(a.w.qs) + blk);
+    if constexpr (QT == QT_Q8_0) s.q2 = __builtin_nontemporal_load((const u32x4 *)(a.w.qs2) + blk);
+    if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) s.qh = a.w.qh[blk];
+    const _Float16 d = ((const _Float16 *)a.w.d)[blk];
+    s.d = kvalid ? d : (_Float16)0.0f;
+    if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) {
+        const _Float16 m = ((const _Float16 *)a.w.m)[blk];
+        s.m = kvalid ? m : (_Float16)0.0f;
     }
 }
+__device__ __forceinline__ void mmq_load_x(MmqX &s, const MmqArgs &a, int64_t kb, const _Float16 *xrow[4], int xc) {
+    int64_t kel = kb * 32 + xc * 8;  // chunk column xc (0..7) of rows xrow[i]
+    kel = kel < a.nb * 32 ? kel : a.nb * 32 - 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s.xa[i] = *(const u32x4 *)(xrow[i] + kel);
+}
 
+// Software pipeline, one barrier per 64-wide k stage:
+//     iteration s:   barrier | global loads of stage s+2 -> registers
+//                            | MFMA on LDS[s & 1]   (matrix pipe)
+//                            | dequantize stage s+1 -> LDS[(s+1) & 1]   (VALU + LDS-write pipe, independent of the MFMAs)
+// so the dequant + ds_write of the next stage (~300 VALU + ~400 LDS-write cycles) hide under the 512 MFMA cycles of the
+// current one instead of preceding them (first version: write -> barrier -> MFMA, 12 % of the f16 peak).
+// gridDim.y = number of K splits (1 or 2): with 2 the partial tiles are combined with f32 atomic adds into a zeroed
+// dst — two addends commute, so the result does not depend on arrival order.
 template <int QT>
 __global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
 
-    const int t = xcd_tile_id(blockIdx.x, gridDim.x);
-    const int tm = t / a.tiles_n, tn = t % a.tiles_n;
+    // workgroup -> tile.  The activation operand is the bigger stream (a workgroup reads 128 tokens x K f16 = 1 MB
+    // at K = 4096 against 0.3 MB of weights), so each XCD is pinned to ONE token tile: its 1 MB slice stays in that
+    // XCD's 4 MB L2 and is re-read from there by every weight slab; the weights stream through once per XCD.
+    int tm, tn;
+    if (a.xcd_by_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = 8 / a.tiles_n;
+        tn = xcd % a.tiles_n;
+        tm = idx * per + xcd / a.tiles_n;
+    } else {
+        const int t = xcd_tile_id(blockIdx.x, gridDim.x);
+        tm = t / a.tiles_n;
+        tn = t % a.tiles_n;
+    }
     const int64_t m0 = (int64_t)tm * MMQ_TM, n0 = (int64_t)tn * MMQ_TN;
 
     // staging assignment
@@ -213,35 +254,97 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[j][i][r] = 0.0f;
 
-    const int nstage = (int)((a.nb + 1) >> 1);
-    MmqStage<QT> st;
-    st.q2 = u32x4{0, 0, 0, 0};
-    st.qh = 0;
-    st.m = (_Float16)0.0f;
-    mmq_load<QT>(st, a, wrow, 0, wj, xrow, xc, wj < a.nb);
+    // this workgroup's stages [s_begin, s_end) of the K loop
+    const int nstage_all = (int)((a.nb + 1) >> 1);
+    const int per = (nstage_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s_begin = (int)blockIdx.y * per, s_end = min(nstage_all, s_begin + per);
+    const int nstage = s_end - s_begin;
 
-    for (int s = 0; s < nstage; s++) {
-        char *W = lds + (s & 1) * 2 * MMQ_TILEB, *X = W + MMQ_TILEB;
-        {  // registers -> LDS (dequantizing the weights)
-            u32x4 o[4];
-            if ((int64_t)s * 2 + wj < a.nb) {
-                mmq_dequant<QT>(st.q, st.q2, st.qh, st.d, st.m, o);
-            } else {
-                o[0] = o[1] = o[2] = o[3] = u32x4{0, 0, 0, 0};
-            }
-            u32x4 *wp = (u32x4 *)(W + wr * MMQ_ROWB + wj * 64);
+    MmqW<QT> wr_[2];  // weight ring: stage s+1 (being dequantized), s+2 (in flight)
+    MmqX xr_[2];      // activation ring: stage s+1, s+2
 #pragma unroll
-            for (int k = 0; k < 4; k++) wp[k] = o[k];
-#pragma unroll
-            for (int i = 0; i < 4; i++) *(u32x4 *)(X + ((tid >> 3) + 32 * i) * MMQ_ROWB + xc * 16) = st.xa[i];
-        }
-        __syncthreads();
-        if (s + 1 < nstage) mmq_load<QT>(st, a, wrow, (int64_t)(s + 1) * 2, wj, xrow, xc, (int64_t)(s + 1) * 2 + wj < a.nb);
-        mma_stage_128x128(W, X, lane, wm, wn, acc);
+    for (int u = 0; u < 2; u++) {
+        wr_[u].q2 = u32x4{0, 0, 0, 0};
+        wr_[u].qh = 0;
+        wr_[u].m = (_Float16)0.0f;
     }
+    auto kb_of = [&](int s) { return (int64_t)(s_begin + min(s, nstage - 1)) * 2; };  // clamped: see mmq_load_w
+    const int frag_off = (lane & 31) * MMQ_ROWB + (lane >> 5) * 16;
+    const int xoff = (tid >> 3) * MMQ_ROWB + xc * 16, woff = wr * MMQ_ROWB + wj * 64;
+
+    // One k-stage, hand-interleaved: after EACH of the 16 MFMAs (32 cycles on the matrix pipe, ~8 issue slots)
+    // comes one slice of the other work — a fragment read for the next k-step, one 32-bit slice of the dequant of
+    // stage s+1 (5 VALU ops), a ds_write when a 16-byte word is complete — and a scheduling barrier that keeps
+    // hipcc from clustering the MFMAs (it does, and then the VALU/LDS work runs with the matrix pipe idle).
+    // Ring slots are compile-time: the caller unrolls by 2.  st/sx hold stage s+1; lw/lx receive stage s+3.
+    auto stage = [&](int s, const MmqW<QT> &st, const MmqX &sx, MmqW<QT> &lw, MmqX &lx) {
+        const char *W = lds + (s & 1) * 2 * MMQ_TILEB, *X = W + MMQ_TILEB;
+        char *Wn = lds + ((s + 1) & 1) * 2 * MMQ_TILEB, *Xn = Wn + MMQ_TILEB;
+        __syncthreads();
+        const MmqW<QT> stc = st;  // slot st is re-filled below (lw may alias it)
+        const MmqX sxc = sx;
+        mmq_load_w<QT>(lw, a, wrow, kb_of(s + 3), wj);
+        mmq_load_x(lx, a, kb_of(s + 3), xrow, xc);
+        const f16x2 dd = {stc.d, stc.d}, mm = {stc.m, stc.m};
+        f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) fa[0][j] = *(const f16x8 *)(X + (wn * 64 + j * 32) * MMQ_ROWB + frag_off);
+#pragma unroll
+        for (int i = 0; i < 2; i++) fb[0][i] = *(const f16x8 *)(W + (wm * 64 + i * 32) * MMQ_ROWB + frag_off);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            u32x4 o;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = t >> 1, i = t & 1, cb = ks & 1, nb2 = cb ^ 1;
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cb][j], fb[cb][i], acc[j][i], 0, 0, 0);
+                if (ks < 3) {  // fragments of k-step ks+1
+                    if (t < 2)
+                        fa[nb2][t] = *(const f16x8 *)(X + (wn * 64 + t * 32) * MMQ_ROWB + frag_off + (ks + 1) * 32);
+                    else
+                        fb[nb2][t - 2] = *(const f16x8 *)(W + (wm * 64 + (t - 2) * 32) * MMQ_ROWB + frag_off + (ks + 1) * 32);
+                }
+                o[t] = mmq_dequant_slice<QT>(stc.q, stc.q2, stc.qh, ks, t, dd, mm);
+                if (t == 1) *(u32x4 *)(Xn + xoff + 32 * ks * MMQ_ROWB) = sxc.xa[ks];
+                if (t == 3) *(u32x4 *)(Wn + woff + ks * 16) = o;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if (nstage > 0) {
+        // stage 0 straight into LDS buffer 0; stages 1..2 into the rings
+        MmqW<QT> w0 = wr_[0];
+        MmqX x0;
+        mmq_load_w<QT>(w0, a, wrow, kb_of(0), wj);
+        mmq_load_x(x0, a, kb_of(0), xrow, xc);
+#pragma unroll
+        for (int u = 0; u < 2; u++) mmq_load_w<QT>(wr_[u], a, wrow, kb_of(1 + u), wj);  // slot u <-> stage u+1
+#pragma unroll
+        for (int u = 0; u < 2; u++) mmq_load_x(xr_[u], a, kb_of(1 + u), xrow, xc);
+        u32x4 o[4];
+        mmq_dequant<QT>(w0.q, w0.q2, w0.qh, w0.d, w0.m, o);
+#pragma unroll
+        for (int k = 0; k < 4; k++) *(u32x4 *)(lds + woff + k * 16) = o[k];
+#pragma unroll
+        for (int i = 0; i < 4; i++) *(u32x4 *)(lds + MMQ_TILEB + xoff + 32 * i * MMQ_ROWB) = x0.xa[i];
+    }
+    // iteration s consumes ring slot s % 2 (it holds stage s+1) and re-fills it with stage s+3.  The steady-state
+    // loop body is branch-free.  (A deeper ring — 4 weight stages — was measured and bought nothing: hipcc's
+    // s_waitcnt insertion waits for vmcnt <= 5 at the top of every stage whatever the ring depth, so the effective
+    // prefetch distance stays ~1 stage and the kernel remains latency-bound; WAIT_ANY = 43 % of wave cycles in
+    // profiles/r01_run23_prefill_mmq_pmc.txt.  The way out is LDS-DMA staging with hand-placed counted waits.)
+    int s = 0;
+    for (; s + 2 <= nstage; s += 2) {
+        stage(s, wr_[0], xr_[0], wr_[0], xr_[0]);
+        stage(s + 1, wr_[1], xr_[1], wr_[1], xr_[1]);
+    }
+    if (s < nstage) stage(s, wr_[0], xr_[0], wr_[0], xr_[0]);
 
     // C layout of the 32x32 MFMA: column (B index = weight row) = lane & 31,
     // row (A index = token) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool split = gridDim.y > 1;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -250,7 +353,12 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int64_t n = n0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < a.M && n < a.N) a.dst[n * a.ldd + m] = acc[j][i][r];
+                if (m < a.M && n < a.N) {
+                    if (split)
+                        unsafeAtomicAdd(a.dst + n * a.ldd + m, acc[j][i][r]);
+                    else
+                        a.dst[n * a.ldd + m] = acc[j][i][r];
+                }
             }
         }
 }

@@ -1,12 +1,6 @@
-set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/t_all.log 2>&1; echo "all rc=$?"
-tail -4 gpurun_out/t_all.log
-timeout 600 python bench.py > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "bench rc=$?"
-cat gpurun_out/bench_decode.json; tail -5 gpurun_out/bench_decode.err
-rm -rf gpurun_out/prof_dec
-GGML_HIP_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_dec -o bench -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_dec.log 2>&1; echo "prof rc=$?"
-grep '"metric"' gpurun_out/prof_dec.log > gpurun_out/prof_dec_bench_line.json
-python tests/tools/kstats.py gpurun_out/prof_dec > gpurun_out/prof_dec_stats.txt; head -12 gpurun_out/prof_dec_stats.txt
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_llama_gpu.py -x -q -m gpu -k "prefill or attention" 2>&1 | tail -2
+for x in 0 1; do
+echo "XCDN=$x"; GGML_HIP_MMQ_XCDN=$x timeout 600 python bench.py --mode prefill --steps 5 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['achieved'], d['roofline']['class_ms_per_step'])"
+done
