@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_llama_gpu.py -x -q -m gpu -k "prefill or attention" 2>&1 | tail -2
-for x in 0 1; do
-echo "XCDN=$x"; GGML_HIP_MMQ_XCDN=$x timeout 600 python bench.py --mode prefill --steps 5 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['achieved'], d['roofline']['class_ms_per_step'])"
-done
+export LLM_PIPELINE_BACKEND=gloo
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 16 --warmup 4 --model 7b > gpurun_out/bench2.json 2> gpurun_out/bench2.err; echo "rc=$?"
+cat gpurun_out/bench2.json; tail -5 gpurun_out/bench2.err
