@@ -266,3 +266,64 @@ class Llama:
                              C.byref(t) if t is not None else None)
         self.n_past += N
         return (logits, tap_arrays) if taps else logits
+
+
+class Gpt2:
+    """CPU restatement of the GPT-2 graph of crates/models/gpt2/src/lib.rs:156-329 (BASELINE configs[0], "plumbing"):
+    numpy orchestration over the C primitives above (norm, quantized mul_mat, gelu, scale+mask+softmax), one Python
+    loop over layers.  `w` holds ggml-layout arrays: quantized 2-D weights as raw block bytes (type `wtype`) with
+    [out rows of `in` elements], 1-D f32 gains/biases, `model/wpe` f32 [n_ctx, n_embd].  K and V are cached as f16,
+    token-major (GPT-2 does not transpose V in the cache, lib.rs:198-210)."""
+
+    def __init__(self, hp, w, n_ctx=None):
+        self.hp, self.w = hp, w
+        self.C = n_ctx or hp["n_ctx"]
+        E, L = hp["n_embd"], hp["n_layer"]
+        self.memory_k = np.zeros((L, self.C, E), np.float16)
+        self.memory_v = np.zeros((L, self.C, E), np.float16)
+        self.n_past = 0
+
+    def _mm(self, name, rows, cols, x, mode):
+        return mul_mat(self.hp["wtype"], self.w[name], rows, cols, x, mode)
+
+    def _ln(self, x, g, b):
+        return norm(x) * self.w[g] + self.w[b]
+
+    def evaluate(self, tokens, mode=0):
+        hp, w = self.hp, self.w
+        E, H, L, V, t = hp["n_embd"], hp["n_head"], hp["n_layer"], hp["n_vocab"], hp["wtype"]
+        D, N, P = E // H, len(tokens), self.n_past
+        T = P + N
+        rb = row_bytes(t, E)
+        wte = w["model/wte"]
+        x = np.stack([dequantize(t, wte[int(tok) * rb:(int(tok) + 1) * rb], E) for tok in tokens])
+        x = x + w["model/wpe"][P:T]  # :166-169
+        f16r = (lambda a: a.astype(np.float16).astype(np.float32)) if mode == 0 else (lambda a: a)
+        for il in range(L):
+            pre = f"model/h{il}/"
+            cur = self._ln(x, pre + "ln_1/g", pre + "ln_1/b")  # :178-183
+            qkv = self._mm(pre + "attn/c_attn/w", 3 * E, E, cur, mode) + w[pre + "attn/c_attn/b"]  # :186-187
+            q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+            self.memory_k[il, P:T] = k.astype(np.float16)  # :197-210
+            self.memory_v[il, P:T] = v.astype(np.float16)
+            Kf = self.memory_k[il, :T].astype(np.float32).reshape(T, H, D)
+            Vf = self.memory_v[il, :T].astype(np.float32).reshape(T, H, D)
+            Qf = f16r(q).reshape(N, H, D)  # src1 of an F16 mul_mat is rounded to f16
+            kq = np.einsum("thd,nhd->hnt", Kf.astype(np.float64), Qf.astype(np.float64)).astype(np.float32)  # :234
+            pr = scale_mask_softmax(kq, np.float32(1.0) / np.sqrt(np.float32(D)), P, mode)  # :235-241
+            kqv = np.einsum("thd,hnt->nhd", Vf.astype(np.float64), f16r(pr).astype(np.float64)).astype(np.float32)
+            cur = kqv.reshape(N, E)  # :266-272
+            cur = self._mm(pre + "attn/c_proj/w", E, E, cur, mode) + w[pre + "attn/c_proj/b"]  # :275-276
+            ff_in = cur + x  # :279
+            cur = self._ln(ff_in, pre + "ln_2/g", pre + "ln_2/b")  # :287-291
+            cur = self._mm(pre + "mlp/c_fc/w", 4 * E, E, cur, mode) + w[pre + "mlp/c_fc/b"]  # :294-295
+            cur = gelu(cur, mode)  # :298
+            cur = self._mm(pre + "mlp/c_proj/w", E, 4 * E, cur, mode) + w[pre + "mlp/c_proj/b"]  # :301-302
+            x = cur + ff_in  # :305
+        x = self._ln(x, "model/ln_f/g", "model/ln_f/b")  # :311-312
+        self.n_past = T
+        head = w.get("model/lm_head", wte)  # :319
+        return self._mm_raw(head, V, E, x, mode)
+
+    def _mm_raw(self, raw, rows, cols, x, mode):
+        return mul_mat(self.hp["wtype"], raw, rows, cols, x, mode)
