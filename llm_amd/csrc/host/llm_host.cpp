@@ -9,7 +9,13 @@
 // of include/ggml_hip.h.
 #include "llm_host.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cmath>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <thread>
@@ -387,8 +393,10 @@ class Llama {
 // ---------------------------------------------------------------------------------------------------
 // C entry points
 // ---------------------------------------------------------------------------------------------------
+struct llm_ggml_file;
 struct llm_model {
     llm::Llama *llama;
+    llm_ggml_file *file = nullptr;  // mmap'd container the weights point into (llm_llama_load)
 };
 struct llm_session {
     llm::InferenceSession *s;
@@ -428,7 +436,191 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
 void llm_model_free(llm_model *m) {
     if (!m) return;
     delete m->llama;
+    if (m->file) llm_ggml_file_close(m->file);
     delete m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GGML / GGMF / GGJT container reader (crates/ggml/src/format/loader.rs:160-281), tensor data left in the mapping
+// ---------------------------------------------------------------------------------------------------------------
+struct llm_ggml_file {
+    int fd = -1;
+    const uint8_t *base = nullptr;
+    size_t size = 0;
+    int container = 0, version = 0;
+    llm_llama_hparams hp{};
+    struct Tok {
+        const char *p;
+        uint32_t len;
+        float score;
+    };
+    std::vector<Tok> vocab;
+    struct Ten {
+        std::string name;
+        int32_t type, n_dims;
+        int64_t ne[2];
+        size_t offset;
+    };
+    std::vector<Ten> tensors;
+};
+
+namespace {
+struct Cursor {
+    const uint8_t *p, *end;
+    bool ok = true;
+    uint32_t u32() {
+        uint32_t v = 0;
+        if ((size_t)(end - p) < 4) {
+            ok = false;
+            return v;
+        }
+        memcpy(&v, p, 4);
+        p += 4;
+        return v;
+    }
+    int32_t i32() { return (int32_t)u32(); }
+    float f32() {
+        const uint32_t u = u32();
+        float v;
+        memcpy(&v, &u, 4);
+        return v;
+    }
+    const uint8_t *bytes(size_t n) {
+        if ((size_t)(end - p) < n) {
+            ok = false;
+            return nullptr;
+        }
+        const uint8_t *r = p;
+        p += n;
+        return r;
+    }
+};
+size_t ggml_file_type_size(int32_t t) {  // bytes per block; blck via ggml_blck_size
+    return ggml_type_size((ggml_type)t);
+}
+}  // namespace
+
+llm_ggml_file *llm_ggml_file_open(const char *path) {
+    auto fail = [&](llm_ggml_file *f, const char *why) -> llm_ggml_file * {
+        fprintf(stderr, "llm_ggml_file_open(%s): %s\n", path, why);
+        if (f) llm_ggml_file_close(f);
+        return nullptr;
+    };
+    llm_ggml_file *f = new llm_ggml_file();
+    f->fd = open(path, O_RDONLY);
+    if (f->fd < 0) return fail(f, "cannot open file");
+    struct stat st;
+    if (fstat(f->fd, &st) != 0 || st.st_size < 8) return fail(f, "cannot stat file / file too small");
+    f->size = (size_t)st.st_size;
+    void *m = mmap(nullptr, f->size, PROT_READ, MAP_SHARED, f->fd, 0);
+    if (m == MAP_FAILED) return fail(f, "mmap failed");
+    f->base = (const uint8_t *)m;
+    Cursor c{f->base, f->base + f->size};
+    // ContainerType::read (crates/ggml/src/lib.rs:58-84)
+    const uint32_t magic = c.u32();
+    if (magic == 0x67676d6cu) {  // 'ggml': unversioned
+        f->container = 0;
+    } else if (magic == 0x67676d66u || magic == 0x67676a74u || magic == 0x67676c61u) {
+        f->container = magic == 0x67676d66u ? 1 : magic == 0x67676a74u ? 2 : 3;
+        f->version = (int)c.u32();
+    } else {
+        return fail(f, "LoadError::InvalidMagic");
+    }
+    const bool ok_version = f->container == 0 || (f->container == 1 && f->version == 1) ||
+                            (f->container == 2 && f->version >= 1 && f->version <= 3) ||
+                            (f->container == 3 && f->version == 1);
+    if (!ok_version) return fail(f, "LoadError::InvalidFormatVersion");
+    // LLaMA hyperparameters (models/llama/src/lib.rs:425-447)
+    f->hp.n_vocab = c.i32();
+    f->hp.n_embd = c.i32();
+    f->hp.n_mult = c.i32();
+    f->hp.n_head = c.i32();
+    f->hp.n_layer = c.i32();
+    f->hp.n_rot = c.i32();
+    f->hp.file_type = c.i32();
+    f->hp.n_head_kv = f->hp.n_head;
+    if (!c.ok || f->hp.n_vocab < 0 || f->hp.n_embd <= 0 || f->hp.n_head <= 0 || f->hp.n_layer <= 0)
+        return fail(f, "LoadError: bad hyperparameters");
+    for (int i = 0; i < f->hp.n_vocab; i++) {  // loader.rs:187-203
+        const uint32_t len = c.u32();
+        const uint8_t *tok = c.bytes(len);
+        float score = 0.0f;
+        if (f->container == 1 || f->container == 2) score = c.f32();
+        if (!c.ok) return fail(f, "LoadError: truncated vocabulary");
+        f->vocab.push_back({(const char *)tok, len, score});
+    }
+    const bool align = f->container >= 2;  // loader.rs:206-212
+    while (c.p < c.end) {                  // load_weights, loader.rs:219-281
+        llm_ggml_file::Ten t;
+        t.n_dims = c.i32();
+        const int32_t name_len = c.i32();
+        const uint32_t ftype = c.u32();
+        if (!c.ok || t.n_dims < 1 || t.n_dims > 2 || name_len < 0) return fail(f, "LoadError::InvariantBroken (n_dims <= 2)");
+        t.ne[0] = t.ne[1] = 1;
+        int64_t n_elements = 1;
+        for (int i = 0; i < t.n_dims; i++) {
+            t.ne[i] = c.i32();
+            if (t.ne[i] <= 0) return fail(f, "LoadError: bad tensor dimension");
+            n_elements *= t.ne[i];
+        }
+        const uint8_t *nm = c.bytes((size_t)name_len);
+        if (!c.ok) return fail(f, "LoadError: truncated tensor header");
+        t.name.assign((const char *)nm, (size_t)name_len);
+        if (ftype >= GGML_TYPE_COUNT || ggml_blck_size((ggml_type)ftype) == 0 || ggml_file_type_size((int32_t)ftype) == 0)
+            return fail(f, "LoadError::UnsupportedElementType");
+        t.type = (int32_t)ftype;
+        if ((t.type == GGML_TYPE_Q4_0 || t.type == GGML_TYPE_Q4_1) && t.ne[0] % 64 != 0)
+            return fail(f, "LoadError::InvariantBroken (dims[0] % 64 == 0)");
+        size_t off = (size_t)(c.p - f->base);
+        if (align) off = (off + 31) & ~(size_t)31;
+        const size_t n_bytes = ggml_file_type_size(t.type) * (size_t)n_elements / (size_t)ggml_blck_size((ggml_type)t.type);
+        if (off + n_bytes > f->size) return fail(f, "LoadError: tensor data past the end of the file");
+        t.offset = off;
+        f->tensors.push_back(t);
+        c.p = f->base + off + n_bytes;
+    }
+    return f;
+}
+void llm_ggml_file_close(llm_ggml_file *f) {
+    if (!f) return;
+    if (f->base) munmap((void *)f->base, f->size);
+    if (f->fd >= 0) close(f->fd);
+    delete f;
+}
+void llm_ggml_file_info(const llm_ggml_file *f, int *container, int *version, llm_llama_hparams *hp, int *n_tensors,
+                        int *n_vocab_entries) {
+    if (container) *container = f->container;
+    if (version) *version = f->version;
+    if (hp) *hp = f->hp;
+    if (n_tensors) *n_tensors = (int)f->tensors.size();
+    if (n_vocab_entries) *n_vocab_entries = (int)f->vocab.size();
+}
+int llm_ggml_file_tensor(const llm_ggml_file *f, int i, llm_tensor_desc *d) {
+    if (i < 0 || i >= (int)f->tensors.size()) return -1;
+    const auto &t = f->tensors[(size_t)i];
+    d->name = t.name.c_str();
+    d->type = t.type;
+    d->n_dims = t.n_dims;
+    d->ne[0] = t.ne[0];
+    d->ne[1] = t.ne[1];
+    d->data = (void *)(f->base + t.offset);
+    return 0;
+}
+int llm_ggml_file_vocab(const llm_ggml_file *f, int i, char *buf, int cap, float *score) {
+    if (i < 0 || i >= (int)f->vocab.size()) return -1;
+    const auto &t = f->vocab[(size_t)i];
+    if (buf && cap > 0) memcpy(buf, t.p, std::min<size_t>((size_t)cap, t.len));
+    if (score) *score = t.score;
+    return (int)t.len;
+}
+llm_model *llm_llama_load(const char *path, const llm_model_params *params) {
+    llm_ggml_file *f = llm_ggml_file_open(path);
+    if (!f) return nullptr;
+    std::vector<llm_tensor_desc> descs(f->tensors.size());
+    for (size_t i = 0; i < descs.size(); i++) llm_ggml_file_tensor(f, (int)i, &descs[i]);
+    llm_model *m = llm_llama_new(&f->hp, params, descs.data(), (int)descs.size());
+    m->file = f;
+    return m;
 }
 llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
     llm::InferenceSessionConfig c;

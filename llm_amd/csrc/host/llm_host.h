@@ -57,6 +57,24 @@ typedef struct llm_session llm_session;
 GGML_API llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *params,
                                   const llm_tensor_desc *tensors, int n_tensors);
 GGML_API void llm_model_free(llm_model *m);
+
+/* GGML / GGMF v1 / GGJT v1-3 container reader with an mmap'd tensor section:
+ * crates/ggml/src/format/loader.rs:160-281 (container walk, 32-byte alignment of GGJT tensor data, the
+ * dims[0] % 64 rule for Q4_0/Q4_1) + crates/llm-base/src/loader.rs:419-567, 702-755 (mmap loader) +
+ * crates/models/llama/src/lib.rs:425-447 (LLaMA hyperparameters) + loader.rs:32-50 (ftype = format +
+ * 1000 * quantization_version).  Returns NULL after printing the LoadError-style reason to stderr. */
+typedef struct llm_ggml_file llm_ggml_file;
+GGML_API llm_ggml_file *llm_ggml_file_open(const char *path);
+GGML_API void llm_ggml_file_close(llm_ggml_file *f);
+/* container: 0 ggml, 1 ggmf, 2 ggjt, 3 ggla; hp may be NULL */
+GGML_API void llm_ggml_file_info(const llm_ggml_file *f, int *container, int *version, llm_llama_hparams *hp,
+                                 int *n_tensors, int *n_vocab_entries);
+/* i-th tensor in file order; desc->name / desc->data point into the mapping (valid until close) */
+GGML_API int llm_ggml_file_tensor(const llm_ggml_file *f, int i, llm_tensor_desc *desc);
+/* i-th vocabulary entry: returns the token's byte length, copies at most cap bytes, *score nullable */
+GGML_API int llm_ggml_file_vocab(const llm_ggml_file *f, int i, char *buf, int cap, float *score);
+/* llm::load for LLaMA: open + Llama::new over the mapping (kept alive by the model); hyperparameters from the file */
+GGML_API llm_model *llm_llama_load(const char *path, const llm_model_params *params);
 GGML_API llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg);
 GGML_API void llm_session_free(llm_session *s);
 /* Model::evaluate (models/llama/src/lib.rs:144-368): feeds n tokens at the session's n_past.

@@ -39,6 +39,17 @@ def _lib():
         L.llm_llama_new.restype = C.c_void_p
         L.llm_llama_new.argtypes = [C.POINTER(_HP), C.POINTER(_MP), C.POINTER(_TD), C.c_int]
         L.llm_model_free.argtypes = [C.c_void_p]
+        L.llm_ggml_file_open.restype = C.c_void_p
+        L.llm_ggml_file_open.argtypes = [C.c_char_p]
+        L.llm_ggml_file_close.argtypes = [C.c_void_p]
+        L.llm_ggml_file_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_HP),
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.llm_ggml_file_tensor.restype = C.c_int
+        L.llm_ggml_file_tensor.argtypes = [C.c_void_p, C.c_int, C.POINTER(_TD)]
+        L.llm_ggml_file_vocab.restype = C.c_int
+        L.llm_ggml_file_vocab.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float)]
+        L.llm_llama_load.restype = C.c_void_p
+        L.llm_llama_load.argtypes = [C.c_char_p, C.POINTER(_MP)]
         L.llm_start_session.restype = C.c_void_p
         L.llm_start_session.argtypes = [C.c_void_p, C.POINTER(_SC)]
         L.llm_session_free.argtypes = [C.c_void_p]
@@ -61,6 +72,33 @@ def _lib():
         L.llm_session_read_node.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
         _bound = True
     return L
+
+
+def inspect_file(path):
+    """Parses a GGML-family container with the C++ reader (no device needed): None if it is rejected, else
+    {container, version, hp, vocab: [(bytes, score)], tensors: [{name, type, n_dims, ne, offset_mod32, head}]}."""
+    L = _lib()
+    f = L.llm_ggml_file_open(str(path).encode())
+    if not f:
+        return None
+    try:
+        c, v, nt, nv, hp = C.c_int(), C.c_int(), C.c_int(), C.c_int(), _HP()
+        L.llm_ggml_file_info(f, C.byref(c), C.byref(v), C.byref(hp), C.byref(nt), C.byref(nv))
+        vocab = []
+        for i in range(nv.value):
+            buf, sc = C.create_string_buffer(256), C.c_float()
+            n = L.llm_ggml_file_vocab(f, i, buf, 256, C.byref(sc))
+            vocab.append((buf.raw[:min(n, 256)], sc.value))
+        tensors = []
+        for i in range(nt.value):
+            d = _TD()
+            L.llm_ggml_file_tensor(f, i, C.byref(d))
+            head = bytes((C.c_uint8 * 16).from_address(d.data))
+            tensors.append(dict(name=d.name.decode(), type=d.type, n_dims=d.n_dims, ne=(d.ne[0], d.ne[1]),
+                                offset_mod32=d.data % 32, head=head))
+        return dict(container=c.value, version=v.value, hp=hp, vocab=vocab, tensors=tensors)
+    finally:
+        L.llm_ggml_file_close(f)
 
 
 class Llama:
@@ -100,6 +138,30 @@ class Llama:
             mp.rope_frequency_base = rope_overrides["frequency_base"]
         self.context_size = context_size
         self.ptr = L.llm_llama_new(C.byref(h), C.byref(mp), descs, len(shapes))
+
+    @classmethod
+    def load(cls, path, context_size=2048, gpu_layers=-1):
+        """llm::load::<Llama>(path, …, ModelParameters{prefer_mmap: true, use_gpu: true}): the C++ container reader
+        (llm_ggml_file_open) maps the GGML/GGMF/GGJT file and the tensors point into the mapping."""
+        L = _lib()
+        info = inspect_file(path)
+        if info is None:
+            raise ValueError(f"{path}: not a loadable GGML-family container")
+        self = cls.__new__(cls)
+        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, 0, -1)
+        self.ptr = L.llm_llama_load(str(path).encode(), C.byref(mp))
+        if not self.ptr:
+            raise ValueError(f"{path}: load failed")
+        h = info["hp"]
+        wtype = next(t["type"] for t in info["tensors"] if t["n_dims"] == 2)
+        n_ff = next(t["ne"][1] for t in info["tensors"] if t["name"].endswith("feed_forward.w1.weight"))
+        self.hp = dict(n_vocab=h.n_vocab, n_embd=h.n_embd, n_mult=h.n_mult, n_head=h.n_head, n_head_kv=h.n_head_kv,
+                       n_layer=h.n_layer, n_rot=h.n_rot, n_ff=n_ff, wtype=wtype)
+        self.weights = None
+        self.layer_range = (0, h.n_layer)
+        self.is_first = self.is_last = True
+        self.context_size = context_size
+        return self
 
     def start_session(self, n_batch=8, kv_type=ggml.TYPE_F16):
         return Session(self, n_batch, kv_type)

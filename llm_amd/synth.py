@@ -95,3 +95,37 @@ def make_llama_fast(hp, wtype, seed=1234, d_scale=0.0043, only=None):
     h = dict(hp)
     h["wtype"] = wtype
     return h, out
+
+
+def write_ggjt(path, hp, w, container="ggjt", version=3, vocab=None):
+    """Writes a LLaMA model file the way crates/ggml/src/format/saver.rs:86-160 does: magic (+ version), the
+    hyperparameters of models/llama/src/lib.rs:449-458, the vocabulary (u32 len, bytes, f32 score — no score in the
+    legacy 'ggml' container), then per tensor (i32 n_dims, i32 name_len, u32 type, i32 dims[], name, padding to a
+    32-byte boundary for ggjt, data).  `w`: the dict of make_llama*(): raw GGML bytes for 2-D weights, f32 for 1-D."""
+    import struct
+    from . import ggml
+    magic = {"ggml": 0x67676d6c, "ggmf": 0x67676d66, "ggjt": 0x67676a74}[container]
+    shapes = tensor_shapes(hp)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", magic))
+        if container != "ggml":
+            f.write(struct.pack("<I", version))
+        ftype = 2 * 1000 + ggml.FTYPE_OF[hp["wtype"]]  # crates/llm-base/src/loader.rs:32-36
+        f.write(struct.pack("<7i", hp["n_vocab"], hp["n_embd"], hp.get("n_mult", 256), hp["n_head"], hp["n_layer"],
+                            hp["n_rot"], ftype))
+        for i in range(hp["n_vocab"]):
+            tok, score = vocab[i] if vocab else (f"<{i}>".encode(), -float(i))
+            f.write(struct.pack("<I", len(tok)) + tok)
+            if container != "ggml":
+                f.write(struct.pack("<f", score))
+        for name, (ne0, ne1) in shapes.items():
+            nb = name.encode()
+            typ = ggml.TYPE_F32 if ne1 is None else hp["wtype"]
+            dims = (ne0,) if ne1 is None else (ne0, ne1)
+            f.write(struct.pack("<iiI", len(dims), len(nb), typ))
+            f.write(struct.pack(f"<{len(dims)}i", *dims))
+            f.write(nb)
+            if container == "ggjt":
+                pos = f.tell()
+                f.write(b"\0" * (((pos + 31) & ~31) - pos))
+            f.write(np.ascontiguousarray(w[name]).tobytes())

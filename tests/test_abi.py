@@ -210,3 +210,48 @@ def test_compute_without_gpu_fails_loudly(G):
             "c.graph().build_forward_expand(y).compute()") % ROOT
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert p.returncode != 0 and "no HIP device" in p.stderr
+
+
+def test_ggjt_container_reader_roundtrip_and_rejections(tmp_path):
+    """the C++ GGML/GGMF/GGJT reader (llm_ggml_file_open) against files written the way
+    crates/ggml/src/format/saver.rs does — hyperparameters, vocabulary with scores, tensor directory in file order,
+    32-byte alignment of GGJT tensor data, the tensor bytes themselves — and the reference's load errors
+    (InvalidMagic, InvalidFormatVersion, dims[0] % 64 for Q4_0, truncated data).  No device involved."""
+    import struct
+    from llm_amd import ggml as G, llama, synth
+    hp, w = synth.make_llama(dict(synth.TINY, n_ff=384), G.TYPE_Q4_0, seed=3)  # every ne0 a multiple of 64
+    for container, version in (("ggjt", 3), ("ggjt", 1), ("ggmf", 1), ("ggml", 0)):
+        p = tmp_path / f"m_{container}{version}.bin"
+        synth.write_ggjt(p, hp, w, container=container, version=version)
+        info = llama.inspect_file(p)
+        assert info is not None, (container, version)
+        assert info["container"] == {"ggml": 0, "ggmf": 1, "ggjt": 2}[container] and info["version"] == version
+        h = info["hp"]
+        assert (h.n_vocab, h.n_embd, h.n_head, h.n_head_kv, h.n_layer, h.n_rot) == (
+            hp["n_vocab"], hp["n_embd"], hp["n_head"], hp["n_head"], hp["n_layer"], hp["n_rot"])
+        assert h.file_type == 2000 + 2  # qnt version 2, MostlyQ4_0
+        assert len(info["vocab"]) == hp["n_vocab"] and info["vocab"][7][0] == b"<7>"
+        assert info["vocab"][7][1] == (0.0 if container == "ggml" else -7.0)
+        shapes = synth.tensor_shapes(hp)
+        assert [t["name"] for t in info["tensors"]] == list(shapes)
+        for t in info["tensors"]:
+            ne0, ne1 = shapes[t["name"]]
+            assert t["ne"] == (ne0, 1 if ne1 is None else ne1) and t["n_dims"] == (1 if ne1 is None else 2)
+            assert t["type"] == (G.TYPE_F32 if ne1 is None else G.TYPE_Q4_0)
+            assert t["head"] == np.ascontiguousarray(w[t["name"]]).tobytes()[:16]
+            if container == "ggjt":
+                assert t["offset_mod32"] == 0
+    good = (tmp_path / "m_ggjt3.bin").read_bytes()
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"GGUF" + good[4:])
+    assert llama.inspect_file(bad) is None  # InvalidMagic
+    bad.write_bytes(good[:4] + struct.pack("<I", 4) + good[8:])
+    assert llama.inspect_file(bad) is None  # InvalidFormatVersion (ggjt v4)
+    bad.write_bytes(good[:-100])
+    assert llama.inspect_file(bad) is None  # tensor data past the end of the file
+    hp2 = dict(hp, n_embd=96, n_rot=24)  # 96 % 64 != 0: the Q4_0 sanity check of loader.rs:248-255
+    w2 = {k: (np.zeros(synth.tensor_shapes(hp2)[k][0], np.float32) if v.dtype == np.float32 else
+              np.zeros(G.row_bytes(G.TYPE_Q4_0, synth.tensor_shapes(hp2)[k][0]) * synth.tensor_shapes(hp2)[k][1], np.uint8))
+          for k, v in w.items()}
+    synth.write_ggjt(bad, hp2, w2)
+    assert llama.inspect_file(bad) is None

@@ -136,6 +136,30 @@ def test_decode_attention_beyond_first_pass(G, O):
     model.free()
 
 
+@pytest.mark.parametrize("wtype", [2, 7])
+def test_model_loaded_from_ggjt_file_equals_in_memory_model(G, O, wtype, tmp_path):
+    """llm_llama_load maps a GGJT v3 file written like the reference's saver and builds the model over
+    the mapping; logits (prompt batch + fused-plan decode) are bit-identical to the model built from the same bytes
+    in memory, and match the oracle."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(dict(synth.TINY, n_ff=384), wtype, seed=21)
+    path = tmp_path / "tiny.bin"
+    synth.write_ggjt(path, hp, w)
+    toks = np.random.default_rng(2).integers(0, hp["n_vocab"], 9).astype(np.int32)
+    outs = []
+    for model in (llama.Llama(hp, w, context_size=64), llama.Llama.load(path, context_size=64)):
+        assert model.hp["n_ff"] == 384 and model.hp["wtype"] == wtype
+        s = model.start_session(n_batch=8)
+        a = s.evaluate(toks[:6])
+        b = np.stack([s.evaluate(toks[6 + i:7 + i])[0] for i in range(3)])
+        outs.append((a, b))
+        s.free()
+        model.free()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ref = O.Llama(hp, w, 64).evaluate(toks[:6], mode=0)
+    assert float(np.max(np.abs(outs[1][0] - ref))) / float(ref.std()) <= EDGE
+
+
 def test_interior_taps_final_norm(G, O):
     """OutputRequest.embeddings (final norm output) against the oracle tap, prompt batch (generic path)."""
     hp, w, model = _mk(G, 2, seed=7)

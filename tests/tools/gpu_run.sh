@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpt2_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_llama_gpu.py -x -q -m gpu -k "ggjt" 2>&1 | tail -5
