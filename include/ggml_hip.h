@@ -488,6 +488,12 @@ GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total
 /* Counters for tests: "plan_tokens" (tokens run by the fused decode plan), "graph_replays", "plans",
  * "generic_graphs".  -1 for an unknown key. */
 GGML_API int64_t ggml_hip_get_stat(const char *key);
+/* ggml_graph_compute split in two so that a caller can overlap host work (building the next token's graph) with
+ * the device: begin() enqueues the graph and returns 1 if it is still running on the device (fused decode plan),
+ * 0 if it already completed (any other graph runs synchronously); end() waits and completes the copy of the
+ * host-visible results (CPU-backend nodes).  No result may be read, and no other graph computed, in between. */
+GGML_API int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph);
+GGML_API void ggml_hip_graph_compute_end(void);
 /* In-kernel timeline of the decode mat-vec launches (ggml_hip_set_option("timeline", 1), eager or graph mode):
  * records of 8 x int64 {entry, loads issued, x staged, barrier passed, first weights landed, exit (100 MHz
  * wall clock ticks), steps of wave 0, workgroup id}; 4 sampled workgroups per launch, launch order.

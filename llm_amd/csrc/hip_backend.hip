@@ -134,6 +134,7 @@ struct Backend {
     int opt_graph = 1;      // replay the plan from a captured hipGraph
     int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
     uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0;
+    bool pending_wait = false;  // a decode plan was launched by graph_compute_begin and not yet waited for
     uint64_t ns_match = 0, ns_launch = 0, ns_wait = 0, ns_compute = 0;  // host-side time split of plan tokens
     size_t dead_shadow_bytes = 0;
 } g;
@@ -1067,8 +1068,17 @@ void invalidate_xf16_if_overwritten_impl(const ggml_tensor *n) {
 
 #include "llama_plan.inc"
 
+void finish_pending() {
+    if (!g.pending_wait) return;
+    const uint64_t t = now_ns();
+    d2h_finish();
+    g.ns_wait += now_ns() - t;
+    g.pending_wait = false;
+}
+
 void execute_graph(ggml_cgraph *gr) {
     ensure_init();
+    finish_pending();
     ws_reset();
     g_qact.valid = false;
     g_xf16.valid = false;
@@ -1229,6 +1239,33 @@ extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     const uint64_t t0 = now_ns();
     execute_graph(cgraph);
+    g.ns_compute += now_ns() - t0;
+}
+// Split form of ggml_graph_compute for callers that have host work to overlap with the device (the session
+// mirror builds the next token's graph meanwhile): begin() enqueues the graph and returns 1 if it is still running
+// (fused decode plan), 0 if it was executed synchronously (any other graph); end() waits and finishes the
+// read-back of the host-visible results.  Nothing else may read results before end().
+extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    const uint64_t t0 = now_ns();
+    ensure_init();
+    finish_pending();
+    ws_reset();
+    g_qact.valid = false;
+    g_xf16.valid = false;
+    int async = 0;
+    if (try_decode_plan(cgraph, true)) {
+        async = 1;
+    } else {
+        execute_graph(cgraph);
+    }
+    g.ns_compute += now_ns() - t0;
+    return async;
+}
+extern "C" void ggml_hip_graph_compute_end(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    const uint64_t t0 = now_ns();
+    finish_pending();
     g.ns_compute += now_ns() - t0;
 }
 

@@ -382,6 +382,13 @@ class GraphExecutionPlan {
         inner_.work_data = (uint8_t *)work.data();                            // assign_work_buffer
         ggml_graph_compute(inner_graph_, &inner_);
     }
+    // split form (hip backend extension): returns true if the graph is still running on the device
+    bool execute_begin(const Context &context) {
+        Tensor work = context.new_tensor_1d(GGML_TYPE_I8, inner_.work_size);
+        inner_.work_data = (uint8_t *)work.data();
+        return ggml_hip_graph_compute_begin(inner_graph_) != 0;
+    }
+    static void execute_end() { ggml_hip_graph_compute_end(); }
 
    private:
     ggml_cplan inner_;

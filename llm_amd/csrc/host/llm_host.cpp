@@ -114,7 +114,9 @@ class InferenceSession {
         scratch_[1] = std::make_shared<Buffer>(SCRATCH_SIZE);
         const size_t buf_size_mb = n_layer >= 80 ? 1536 : n_layer >= 60 ? 1280 : 1024;
         const size_t buf_size = buf_size_mb * 1024 * 1024 + ggml_graph_overhead();
-        ctx0_ = Context::new_with_buffer(std::make_shared<Buffer>(buf_size));
+        ctx0_[0] = Context::new_with_buffer(std::make_shared<Buffer>(buf_size));
+        ctx0_[1] = Context::new_with_buffer(std::make_shared<Buffer>(buf_size));
+        if (const char *v = getenv("LLM_HOST_SPECULATE")) speculate = atoi(v) != 0;
         last_logits.assign(n_vocab, 0.0f);
     }
     ~InferenceSession() {
@@ -122,27 +124,46 @@ class InferenceSession {
         ggml::accelerator::free_scratch();
     }
 
-    // inference_session.rs:220-295
-    GraphOutputs compute(const std::vector<TokenId> &input_tokens,
-                         const std::function<std::pair<ComputationGraph, GraphOutputs>(BuildContext &)> &builder) {
-        ctx0_.recreate();
-        Tensor embd = ctx0_.new_tensor_1d(GGML_TYPE_I32, input_tokens.size()).set_name("embd");
-        BuildContext bc{&ctx0_, &embd, &memory_k, &memory_v, scratch_};
-        auto built = builder(bc);
-        ComputationGraph &built_gf = built.first;
-        GraphOutputs &built_result = built.second;
-        embd.write_data(input_tokens.data(), input_tokens.size() * sizeof(TokenId));  // Write input tokens
-        built_gf.build_forward_expand(built_result.result);                          // Compute the graph
-        {
-            GraphExecutionPlan plan(built_gf, config.n_threads);
-            plan.execute(ctx0_);
+    using Builder = std::function<std::pair<ComputationGraph, GraphOutputs>(BuildContext &)>;
+
+    // inference_session.rs:220-295.  `next_builder` (optional) is a host-side latency optimisation that does not
+    // change what is computed: while the device runs a single-token graph, the graph of the NEXT single-token call
+    // (same session, n_past + 1) is built into the other of two ctx0 arenas; the following compute() adopts it if
+    // the session is where the speculation assumed (otherwise it is discarded and the graph is built as usual).
+    // The reference rebuilds the graph inside every evaluate; this hides that cost behind the device.
+    GraphOutputs compute(const std::vector<TokenId> &input_tokens, const Builder &builder,
+                         const std::function<Builder(size_t /*session_len*/)> &next_builder = nullptr,
+                         const void *model_key = nullptr, size_t context_size = 0) {
+        const bool single = input_tokens.size() == 1;
+        Built built;
+        if (single && pre_.valid && pre_.n_past == n_past && pre_.model_key == model_key) {
+            cur_ = pre_.slot;  // adopt the speculatively built graph
+            built = std::move(pre_.b);
+        } else {
+            cur_ ^= 1;
+            built = build_into(cur_, input_tokens.size(), builder);
         }
-        last_n_nodes = built_gf.raw()->n_nodes;
-        last_n_leafs = built_gf.raw()->n_leafs;
-        last_graph = built_gf.raw();  // lives in ctx0's arena until the next compute()
-        if (mem_per_token == 0) mem_per_token = ctx0_.used_mem() / n_embd_;
+        pre_.valid = false;
+        Context &ctx0 = ctx0_[cur_];
+        built.embd.write_data(input_tokens.data(), input_tokens.size() * sizeof(TokenId));  // Write input tokens
+        {
+            GraphExecutionPlan plan(built.gf, config.n_threads);
+            const bool running = single && speculate ? plan.execute_begin(ctx0) : (plan.execute(ctx0), false);
+            if (running && next_builder && n_past + 2 <= context_size) {
+                pre_.b = build_into(cur_ ^ 1, 1, next_builder(n_past + 1));
+                pre_.slot = cur_ ^ 1;
+                pre_.n_past = n_past + 1;
+                pre_.model_key = model_key;
+                pre_.valid = true;
+            }
+            if (single && speculate) GraphExecutionPlan::execute_end();
+        }
+        last_n_nodes = built.gf.raw()->n_nodes;
+        last_n_leafs = built.gf.raw()->n_leafs;
+        last_graph = built.gf.raw();  // lives in its ctx0 arena until that arena is recreated
+        if (mem_per_token == 0) mem_per_token = ctx0.used_mem() / n_embd_;
         n_past += input_tokens.size();
-        return GraphOutputs{built_result.result.share(), built_result.embedding_result.share()};
+        return GraphOutputs{built.out.result.share(), built.out.embedding_result.share()};
     }
 
     void make_stage_buffers(size_t n_embd, bool in, bool out) {
@@ -171,9 +192,37 @@ class InferenceSession {
     std::shared_ptr<Context> session_ctx_;
     std::shared_ptr<Context> stage_ctx_;
     size_t memory_size_ = 0;
-    Context ctx0_;
+    struct Built {
+        ComputationGraph gf{nullptr};
+        GraphOutputs out;
+        Tensor embd;
+    };
+    Built build_into(int slot, size_t n_tokens, const Builder &builder) {
+        Context &ctx0 = ctx0_[slot];
+        ctx0.recreate();
+        Built b;
+        b.embd = ctx0.new_tensor_1d(GGML_TYPE_I32, n_tokens).set_name("embd");
+        BuildContext bc{&ctx0, &b.embd, &memory_k, &memory_v, scratch_};
+        auto built = builder(bc);
+        b.gf = built.first;
+        b.out = built.second;
+        b.gf.build_forward_expand(b.out.result);  // Compute the graph
+        return b;
+    }
+    struct Prebuilt {
+        bool valid = false;
+        size_t n_past = 0;
+        const void *model_key = nullptr;
+        int slot = 0;
+        Built b;
+    } pre_;
+    Context ctx0_[2];
+    int cur_ = 0;
     size_t n_embd_;
     std::shared_ptr<Buffer> scratch_[2];
+
+   public:
+    bool speculate = true;  // build the next single-token graph while the device runs (LLM_HOST_SPECULATE=0 disables)
 };
 
 // crates/llm-base/src/model/common.rs:6-59
@@ -280,16 +329,17 @@ class Llama {
         return s;
     }
 
-    // models/llama/src/lib.rs:144-368 — line numbers of the Rust builder are cited per step
-    void evaluate(InferenceSession &session, const std::vector<TokenId> &input_tokens, OutputRequest &output_request) {
-        const size_t input_len = input_tokens.size();
-        const size_t session_len = session.n_past;
-        const size_t ctx_size = params.context_size;
-        const size_t n_vocab = hyperparameters.n_vocab, n_embd = hyperparameters.n_embd, n_head = hyperparameters.n_head,
-                     n_head_kv = hyperparameters.n_head_kv, n_layer = hyperparameters.n_layer, n_rot = hyperparameters.n_rot;
-        const size_t n_embd_gqa = n_embd / (n_head / n_head_kv);
+    // The graph builder of Llama::evaluate (models/llama/src/lib.rs:166-362) for `input_len` tokens at position
+    // `session_len`, as a value so that the session can also build the graph of the next call ahead of time.
+    InferenceSession::Builder make_builder(InferenceSession *session_ptr, size_t input_len, size_t session_len) {
+        return [this, session_ptr, input_len, session_len](BuildContext &builder) {
+            InferenceSession &session = *session_ptr;
+            const size_t ctx_size = params.context_size;
+            const size_t n_embd = hyperparameters.n_embd, n_head = hyperparameters.n_head,
+                         n_head_kv = hyperparameters.n_head_kv, n_layer = hyperparameters.n_layer,
+                         n_rot = hyperparameters.n_rot;
+            const size_t n_embd_gqa = n_embd / (n_head / n_head_kv);
 
-        GraphOutputs outputs = session.compute(input_tokens, [&](BuildContext &builder) {
             Context &ctx0 = *builder.ctx0;
             const Tensor &embd = *builder.embd;
             (void)n_layer;
@@ -373,7 +423,20 @@ class Llama {
             input_layer = ctx0.op_mul_mat(output, input_layer);  // :352 lm_head
             ctx0.use_scratch(nullptr);  // :354
             return std::make_pair(gf, GraphOutputs{input_layer, embedding_result});
-        });
+        };
+    }
+
+    // models/llama/src/lib.rs:144-368 — line numbers of the Rust builder are cited per step
+    void evaluate(InferenceSession &session, const std::vector<TokenId> &input_tokens, OutputRequest &output_request) {
+        const size_t input_len = input_tokens.size();
+        const size_t session_len = session.n_past;
+        const size_t ctx_size = params.context_size;
+        const size_t n_vocab = hyperparameters.n_vocab, n_embd = hyperparameters.n_embd;
+
+        InferenceSession *sp = &session;
+        GraphOutputs outputs = session.compute(
+            input_tokens, make_builder(sp, input_len, session_len),
+            [this, sp](size_t next_len) { return make_builder(sp, 1, next_len); }, this, ctx_size);
         if (!is_last()) return;
         // finish evaluation (:364-367)
         common::read_last_token(session, outputs.result, n_vocab, input_len);

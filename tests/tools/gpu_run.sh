@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_llama_gpu.py -x -q -m gpu -k "ggjt" 2>&1 | tail -5
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+timeout 600 python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['host_split_per_token'])"
+LLM_HOST_SPECULATE=0 timeout 600 python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['host_split_per_token'])"
