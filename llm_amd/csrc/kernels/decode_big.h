@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_big(const BigArgs ba) {
     const DecMmvqArgs &a = ba.d;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_part[16];
+    __shared__ float s_rope[EPI == EPI_QKV ? 256 : 2];  // cos/sin of the RoPE angle of every pair of a head (D <= 256)
     constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
     constexpr int RU = EPI == EPI_QKV ? 2 : 1, NW = EPI == EPI_GATE ? 2 : 1, NR = RU * NW;
     constexpr int PF = big_pf<QT>(NR);
@@ -277,7 +278,17 @@ __global__ void __launch_bounds__(1024) k_mmvq_big(const BigArgs ba) {
     }
     const long long t_issued = ba.ts ? big_now() : 0;
 
-    // ---- 3. norm / re-quantization of x into LDS
+    // ---- 3. norm / re-quantization of x into LDS; meanwhile the last wave (not a stager) tabulates the RoPE
+    //         rotation of this position: theta_k = freq_scale*p * theta_scale^k as ggml's iterated f32 product
+    if constexpr (EPI == EPI_QKV) {
+        if (tid >= 1024 - 128 && tid - (1024 - 128) < (a.D >> 1)) {
+            const int kk = tid - (1024 - 128);
+            float theta = a.freq_scale * (float)n_past;
+            for (int t = 0; t < kk; t++) theta *= a.theta_scale;
+            s_rope[2 * kk] = cosf(theta);
+            s_rope[2 * kk + 1] = sinf(theta);
+        }
+    }
     big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, s_lo, s_hi, s_d, s_sum, s_part);
     const long long t_staged = ba.ts ? big_now() : 0;
     // ---- 2b. the rest of the ring
@@ -355,9 +366,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_big(const BigArgs ba) {
                 a.mem_v[(int64_t)(m0 + 1) * a.C + p] = __float2half_rn(myv[1]);
             } else {
                 const int kk = (m0 % a.D) >> 1;
-                float theta = a.freq_scale * (float)p;
-                for (int t = 0; t < kk; t++) theta *= a.theta_scale;
-                const float c = cosf(theta), sn = sinf(theta);
+                const float c = s_rope[2 * kk], sn = s_rope[2 * kk + 1];
                 const float r0 = myv[0] * c - myv[1] * sn, r1 = myv[0] * sn + myv[1] * c;
                 if (sg == 0) {
                     a.dst[m0] = r0;
