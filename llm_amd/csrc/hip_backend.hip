@@ -852,7 +852,17 @@ void op_bin(ggml_tensor *dst, int op) {
     } else {
         BK_ASSERT(a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_F32);
         const TView va = view_of(a), vb = view_of(b), vd = view_of(dst);
-        if (op == BIN_ADD)
+        const bool same = is_contig_f32(a) && is_contig_f32(b) && is_contig_f32(dst) && ggml_nelements(a) == n &&
+                          ggml_nelements(b) == n && n % 4 == 0 &&
+                          (((uintptr_t)va.p | (uintptr_t)vb.p | (uintptr_t)vd.p) & 15) == 0;
+        if (same) {
+            if (op == BIN_ADD)
+                hipLaunchKernelGGL(k_bin4<BIN_ADD>, grid1(n / 4), dim3(256), 0, g.stream, (const f32x4 *)va.p,
+                                   (const f32x4 *)vb.p, (f32x4 *)vd.p, n / 4);
+            else
+                hipLaunchKernelGGL(k_bin4<BIN_MUL>, grid1(n / 4), dim3(256), 0, g.stream, (const f32x4 *)va.p,
+                                   (const f32x4 *)vb.p, (f32x4 *)vd.p, n / 4);
+        } else if (op == BIN_ADD)
             hipLaunchKernelGGL(k_bin<BIN_ADD>, grid1(n), dim3(256), 0, g.stream, va, vb, vd, n);
         else
             hipLaunchKernelGGL(k_bin<BIN_MUL>, grid1(n), dim3(256), 0, g.stream, va, vb, vd, n);
@@ -871,8 +881,12 @@ void op_unary(ggml_tensor *dst, const ggml_tensor *mul_b /* nullable: fused silu
     if (uop == GGML_UNARY_OP_SILU) {
         if (mul_b) {
             BK_ASSERT(is_contig_f32(mul_b) && ggml_nelements(mul_b) == n);
-            hipLaunchKernelGGL((k_unary<UN_SILU, true>), grid1(n), dim3(256), 0, g.stream, pa,
-                               (const float *)dev_ptr(mul_b), pd, n);
+            const float *pb = (const float *)dev_ptr(mul_b);
+            if (n % 4 == 0 && (((uintptr_t)pa | (uintptr_t)pb | (uintptr_t)pd) & 15) == 0)
+                hipLaunchKernelGGL((k_unary4<UN_SILU, true>), grid1(n / 4), dim3(256), 0, g.stream, (const f32x4 *)pa,
+                                   (const f32x4 *)pb, (f32x4 *)pd, n / 4);
+            else
+                hipLaunchKernelGGL((k_unary<UN_SILU, true>), grid1(n), dim3(256), 0, g.stream, pa, pb, pd, n);
         } else {
             hipLaunchKernelGGL((k_unary<UN_SILU, false>), grid1(n), dim3(256), 0, g.stream, pa, (const float *)nullptr,
                                pd, n);
@@ -1097,6 +1111,23 @@ void execute_graph(ggml_cgraph *gr) {
             }
     std::vector<char> done(gr->n_nodes, 0);
     const bool fuse = g.opt_fuse != 0;
+    // silu(a) whose only consumer is a later mul(silu(a), b) — the FFN gate; the reference's build order puts the
+    // w3 mat-mul between the two (nodes: w1·x, silu, w3·x, mul), so the pair is not adjacent: the silu is deferred
+    // and executed fused when its mul comes up (nothing in between writes a's buffer: it is a live operand).
+    std::vector<int> deferred_silu(gr->n_nodes, -1);  // index of the mul that will run it
+    if (fuse) {
+        for (int j = 0; j < gr->n_nodes; j++) {
+            ggml_tensor *mu = gr->nodes[j];
+            if (mu->op != GGML_OP_MUL || !mu->src[0] || mu->src[0]->op != GGML_OP_UNARY) continue;
+            const int i = node_index(gr, mu->src[0], idx);
+            ggml_tensor *un = mu->src[0];
+            if (i < 0 || i >= j || uses[i] != 1 || un->op_params[0] != GGML_UNARY_OP_SILU) continue;
+            if (!is_contig_f32(un->src[0]) || !is_contig_f32(mu->src[1]) || !is_contig_f32(mu) ||
+                ggml_nelements(mu->src[1]) != ggml_nelements(un) || ggml_nelements(mu) != ggml_nelements(un))
+                continue;
+            deferred_silu[i] = j;
+        }
+    }
 
     for (int i = 0; i < gr->n_nodes; i++) {
         ggml_tensor *n = gr->nodes[i];
@@ -1118,9 +1149,16 @@ void execute_graph(ggml_cgraph *gr) {
             } break;
             case GGML_OP_NORM: op_norm(n); break;
             case GGML_OP_ADD: op_bin(n, BIN_ADD); break;
-            case GGML_OP_MUL: op_bin(n, BIN_MUL); break;
+            case GGML_OP_MUL: {
+                const int si = n->src[0] && n->src[0]->op == GGML_OP_UNARY ? node_index(gr, n->src[0], idx) : -1;
+                if (si >= 0 && deferred_silu[si] == i)
+                    op_unary(n->src[0], n->src[1], n);  // silu(a) * b in one pass
+                else
+                    op_bin(n, BIN_MUL);
+            } break;
             case GGML_OP_REPEAT: op_bin(n, BIN_REPEAT); break;
             case GGML_OP_UNARY: {
+                if (deferred_silu[i] >= 0) break;  // runs fused with its mul
                 if (fuse && n->op_params[0] == GGML_UNARY_OP_SILU && next && next->op == GGML_OP_MUL &&
                     next->src[0] == n && uses[i] == 1 && !done[i + 1] && is_contig_f32(next->src[1]) &&
                     ggml_nelements(next->src[1]) == ggml_nelements(n) && is_contig_f32(next)) {

@@ -85,6 +85,20 @@ __global__ void __launch_bounds__(256) k_bin(const TView a, const TView b, const
     *dp = OP == BIN_ADD ? av + bv : av * bv;
 }
 
+// same-shape contiguous operands (the residual adds and the gate multiply of a prompt batch: 8..22 MB per
+// operand): float4 per thread, no index arithmetic
+template <int OP>
+__global__ void __launch_bounds__(256) k_bin4(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, f32x4 *d,
+                                              int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 x = a[i], y = b[i];
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = OP == BIN_ADD ? x[k] + y[k] : x[k] * y[k];
+    d[i] = r;
+}
+
 // ---- unary ops through ggml's f16 lookup tables (ggml_silu / ggml_gelu) -----------------------------
 // table_silu_f16[h] = f16(silu_f32(f32(h))), looked up at h = f16(x): silu(x) := f16(xf/(1+expf(-xf))).
 enum { UN_SILU = 0, UN_GELU = 1 };
@@ -106,6 +120,24 @@ __global__ void __launch_bounds__(256) k_unary(const float *a, const float *b, f
     float v = OP == UN_SILU ? silu_table(a[i]) : gelu_table(a[i]);
     if (MUL_B) v = v * b[i];
     d[i] = v;
+}
+
+template <int OP, bool MUL_B>
+__global__ void __launch_bounds__(256) k_unary4(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, f32x4 *d,
+                                                int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 x = a[i];
+    f32x4 y = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (MUL_B) y = b[i];
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float v = OP == UN_SILU ? silu_table(x[k]) : gelu_table(x[k]);
+        if (MUL_B) v = v * y[k];
+        r[k] = v;
+    }
+    d[i] = r;
 }
 
 // ---- scale by a device-resident scalar (ggml_scale) --------------------------------------------------
