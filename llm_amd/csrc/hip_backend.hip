@@ -32,6 +32,7 @@
 #include "kernels/common.h"
 #include "kernels/mmvq.h"
 #include "kernels/mmq.h"
+#include "kernels/mmq_dma.h"
 #include "kernels/gemm_f16.h"
 #include "kernels/ops.h"
 #include "kernels/decode.h"
@@ -129,6 +130,7 @@ struct Backend {
     long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
     size_t timeline_bytes = 0;
     int opt_mmq_splitk = 1;
+    int opt_mmq_dma = 1;    // prompt GEMM with LDS-DMA staging (kernels/mmq_dma.h) when K/32 is even
     int opt_mmq_xcdn = 0;   // pin XCDs to token tiles (measured slower than the tile-id walk: 393 vs 446 TFLOP/s)
     int opt_mmq_min = 32;   // token count from which mul_mat runs on the MFMA GEMM (0 = never)
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
@@ -170,6 +172,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_MMQ_MIN")) g.opt_mmq_min = atoi(v);
     if (const char *v = getenv("GGML_HIP_BIG")) g.opt_big = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_SPLITK")) g.opt_mmq_splitk = atoi(v);
     {
         hipDeviceProp_t prop;
@@ -731,6 +734,27 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
         lds_attr_set = true;
     }
     Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)a.M * (double)N * (double)K);
+    if (g.opt_mmq_dma && nb % 2 == 0) {
+        static bool dma_attr_set = false;
+        if (!dma_attr_set) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            dma_attr_set = true;
+        }
+        switch (qt) {
+            case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma<QT_Q4_0>, grid, dim3(256), DMA_LDS, g.stream, a); break;
+            case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma<QT_Q4_1>, grid, dim3(256), DMA_LDS, g.stream, a); break;
+            case QT_Q5_0: hipLaunchKernelGGL(k_mmq_dma<QT_Q5_0>, grid, dim3(256), DMA_LDS, g.stream, a); break;
+            case QT_Q5_1: hipLaunchKernelGGL(k_mmq_dma<QT_Q5_1>, grid, dim3(256), DMA_LDS, g.stream, a); break;
+            case QT_Q8_0: hipLaunchKernelGGL(k_mmq_dma<QT_Q8_0>, grid, dim3(256), DMA_LDS, g.stream, a); break;
+            default: die("mmq: bad weight type");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     switch (qt) {
         case QT_Q4_0: hipLaunchKernelGGL(k_mmq<QT_Q4_0>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
         case QT_Q4_1: hipLaunchKernelGGL(k_mmq<QT_Q4_1>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
@@ -1593,6 +1617,8 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_mmq_min = value;
     else if (!strcmp(key, "mmq_splitk"))
         g.opt_mmq_splitk = value;
+    else if (!strcmp(key, "mmq_dma"))
+        g.opt_mmq_dma = value;
     else
         die("ggml_hip_set_option: unknown key '%s'", key);
 }

@@ -213,6 +213,9 @@ def run_bench(args):
     os.environ["GGML_HIP_DEVICE"] = str(local_rank)  # one process drives one GPU (read at backend init)
     backend = os.environ.get("LLM_PIPELINE_BACKEND", "nccl")
     device = None
+    if backend == "nccl" and torch.cuda.device_count() <= local_rank:
+        backend = "gloo"  # fewer visible GPUs than ranks (e.g. a 1-GPU box running the 2-rank functional check)
+        os.environ["GGML_HIP_DEVICE"] = str(local_rank % max(torch.cuda.device_count(), 1))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
