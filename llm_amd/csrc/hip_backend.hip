@@ -722,7 +722,7 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
     const int splits = (g.opt_mmq_splitk && tiles_m * a.tiles_n * 4 <= g.num_cus * 3 && nstage >= 16 &&
                         dst->nb[0] == 4 && ggml_is_contiguous(dst)) ? 2 : 1;
     if (splits > 1) HIP_CHECK(hipMemsetAsync(a.dst, 0, (size_t)a.M * N * 4, g.stream));
-    a.xcd_by_n = g.opt_mmq_xcdn && (a.tiles_n == 1 || a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && tiles_m % (8 / a.tiles_n) == 0;
+    a.xcd_by_n = g.opt_mmq_xcdn == 2 ? 1 : g.opt_mmq_xcdn && (a.tiles_n == 1 || a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && tiles_m % (8 / a.tiles_n) == 0;
     const dim3 grid((unsigned)(tiles_m * a.tiles_n), (unsigned)splits);
     static bool lds_attr_set = false;
     if (!lds_attr_set) {  // 73.7 KB of dynamic LDS: above the 64 KB a kernel gets without opting in

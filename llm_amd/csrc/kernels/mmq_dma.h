@@ -48,8 +48,16 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
     const int wm = wave & 1, wn = wave >> 1;
     constexpr int G = dma_group<QT>();
 
-    const int t = xcd_tile_id(blockIdx.x, gridDim.x);
-    const int tm = t / a.tiles_n, tn = t % a.tiles_n;
+    int tm, tn;
+    if (a.xcd_by_n) {  // token-tile-major walk: the whole chip works on ONE 128-token slice of X at a time
+        const int tiles_m = (int)gridDim.x / a.tiles_n;
+        tn = (int)blockIdx.x / tiles_m;
+        tm = (int)blockIdx.x % tiles_m;
+    } else {
+        const int t = xcd_tile_id(blockIdx.x, gridDim.x);
+        tm = t / a.tiles_n;
+        tn = t % a.tiles_n;
+    }
     const int64_t m0 = (int64_t)tm * MMQ_TM, n0 = (int64_t)tn * MMQ_TN;
 
     // this workgroup's stages [s_begin, s_end) of the K loop (K/32 is even: checked by the launcher)

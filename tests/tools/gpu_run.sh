@@ -1,9 +1,13 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rm -rf /tmp/prof_pre /tmp/pmc1
-timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_pre -o bench -- python bench.py --mode prefill --steps 3 --warmup 1 > gpurun_out/prof_pre.log 2>&1
-python tests/tools/shape_stats.py /tmp/prof_pre '%k_mmq%'
-python tests/tools/kstats.py /tmp/prof_pre > gpurun_out/prof_pre_stats.txt; head -14 gpurun_out/prof_pre_stats.txt
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace -d /tmp/pmc1 -o bench -- python bench.py --mode prefill --steps 1 --warmup 1 > gpurun_out/pmc1.log 2>&1
-python tests/tools/pmc_kernel.py /tmp/pmc1 '%k_mmq%' | tee gpurun_out/pmc_mmq_dma.txt
+for x in 0 2; do
+rm -rf /tmp/pf$x
+GGML_HIP_MMQ_XCDN=$x timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf$x -o bench -- python bench.py --mode prefill --steps 1 --warmup 1 > gpurun_out/pf$x.log 2>&1
+echo "XCDN=$x"; python - <<PY
+import sqlite3,glob
+con=sqlite3.connect(glob.glob('/tmp/pf$x/*.db')[0])
+q="select e.name, d.grid_size_x, d.grid_size_y, count(*), avg(e.counter_value), avg(e.duration)/1e3 from pmc_events e join counters_collection d on d.dispatch_id=e.dispatch_id where e.name like '%k_mmq_dma%' and e.counter_name='FETCH_SIZE' and d.counter_name='FETCH_SIZE' group by 1,2,3"
+for r in con.execute(q): print(r[0][:24], (r[1],r[2]), r[3], "FETCH KiB %.0f  -> x2 = %.1f MB"%(r[4], 2*r[4]*1024/1e6), "us %.1f"%r[5])
+PY
+done
