@@ -1,13 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-for x in 0 2; do
-rm -rf /tmp/pf$x
-GGML_HIP_MMQ_XCDN=$x timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf$x -o bench -- python bench.py --mode prefill --steps 1 --warmup 1 > gpurun_out/pf$x.log 2>&1
-echo "XCDN=$x"; python - <<PY
-import sqlite3,glob
-con=sqlite3.connect(glob.glob('/tmp/pf$x/*.db')[0])
-q="select e.name, d.grid_size_x, d.grid_size_y, count(*), avg(e.counter_value), avg(e.duration)/1e3 from pmc_events e join counters_collection d on d.dispatch_id=e.dispatch_id where e.name like '%k_mmq_dma%' and e.counter_name='FETCH_SIZE' and d.counter_name='FETCH_SIZE' group by 1,2,3"
-for r in con.execute(q): print(r[0][:24], (r[1],r[2]), r[3], "FETCH KiB %.0f  -> x2 = %.1f MB"%(r[4], 2*r[4]*1024/1e6), "us %.1f"%r[5])
-PY
-done
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python bench.py > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "bench rc=$?"; cut -c1-400 gpurun_out/bench_decode.json
+timeout 600 python bench.py --mode prefill --steps 5 --warmup 2 > gpurun_out/bench_prefill.json 2>/dev/null; cut -c1-200 gpurun_out/bench_prefill.json
+rm -rf /tmp/prof_dec
+GGML_HIP_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_dec -o bench -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_dec.log 2>&1; echo "prof rc=$?"
+grep '"metric"' gpurun_out/prof_dec.log > gpurun_out/prof_dec_bench_line.json
+python tests/tools/kstats.py /tmp/prof_dec > gpurun_out/prof_dec_stats.txt; head -10 gpurun_out/prof_dec_stats.txt
