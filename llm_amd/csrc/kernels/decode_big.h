@@ -35,6 +35,11 @@ __device__ __forceinline__ constexpr int big_pf(int NR) {
     return 64 / per >= 8 ? 8 : 64 / per >= 2 ? 64 / per : 2;  // Q4_0: 6 steps of 2 rows, 8 steps of 1 row
 }
 
+#ifndef BIG_T
+#define BIG_T 1024  // threads per workgroup of k_mmvq_big (512 was measured too: see DESIGN.md)
+#endif
+#define BIG_W (BIG_T / 64)
+
 struct BigArgs {
     DecMmvqArgs d;
     float *y_out;  // XSRC_NORM: optional f32 copy of the normed row (final norm -> OutputRequest.embeddings)
@@ -69,7 +74,7 @@ struct BigX<XSRC_F32> {
         const int64_t n4 = nb * 8;
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
-            const int64_t i4 = (int64_t)it * 1024 + tid;
+            const int64_t i4 = (int64_t)it * BIG_T + tid;
             v[it] = ((const f32x4 *)a.d.xf)[i4 < n4 ? i4 : 0];
         }
     }
@@ -100,7 +105,7 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
                                             i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part) {
     const DecMmvqArgs &d = a.d;
     (void)s_part;
-    for (int64_t i = nb + tid; i < nbp; i += 1024) {
+    for (int64_t i = nb + tid; i < nbp; i += BIG_T) {
         s_lo[i] = i32x4{0, 0, 0, 0};
         s_hi[i] = i32x4{0, 0, 0, 0};
         s_d[i] = 0.0f;
@@ -117,8 +122,8 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
     } else if constexpr (XSRC == XSRC_F32) {
 #pragma unroll
         for (int it = 0; it < BigX<XSRC_F32>::MAXIT; it++) {
-            const int64_t i4 = (int64_t)it * 1024 + tid;
-            if ((int64_t)it * 1024 >= n4) break;  // uniform
+            const int64_t i4 = (int64_t)it * BIG_T + tid;
+            if ((int64_t)it * BIG_T >= n4) break;  // uniform
             const f32x4 v = i4 < n4 ? xr.v[it] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             quant4_to_lds<F16_D>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
         }
@@ -166,7 +171,7 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
 }
 
 template <int QT, int EPI, int XSRC>
-__global__ void __launch_bounds__(1024) k_mmvq_big(const BigArgs ba) {
+__global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     const DecMmvqArgs &a = ba.d;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_part[16];
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_big(const BigArgs ba) {
     // contiguous window of G*16 units of the matrix.  Lane i of the wave owns unit i's epilogue.
     const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0, M2 = EPI == EPI_QKV ? (int)a.w[2].M : 0;
     const int Utot = (M0 + M1 + M2) / RU;
-    const int u_first = (int)blockIdx.x * 16 + wave, u_stride = (int)gridDim.x * 16;
+    const int u_first = (int)blockIdx.x * BIG_W + wave, u_stride = (int)gridDim.x * BIG_W;
     const int nu = u_first < Utot ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
     const int S = nu * nbl;
     // EPI_ADD: lane i preloads the residual of unit i (a load issued in the epilogue would drain the queue)
@@ -281,8 +286,8 @@ __global__ void __launch_bounds__(1024) k_mmvq_big(const BigArgs ba) {
     // ---- 3. norm / re-quantization of x into LDS; meanwhile the last wave (not a stager) tabulates the RoPE
     //         rotation of this position: theta_k = freq_scale*p * theta_scale^k as ggml's iterated f32 product
     if constexpr (EPI == EPI_QKV) {
-        if (tid >= 1024 - 128 && tid - (1024 - 128) < (a.D >> 1)) {
-            const int kk = tid - (1024 - 128);
+        if (tid >= BIG_T - 128 && tid - (BIG_T - 128) < (a.D >> 1)) {
+            const int kk = tid - (BIG_T - 128);
             float theta = a.freq_scale * (float)n_past;
             for (int t = 0; t < kk; t++) theta *= a.theta_scale;
             s_rope[2 * kk] = cosf(theta);
