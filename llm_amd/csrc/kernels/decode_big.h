@@ -36,7 +36,8 @@ __device__ __forceinline__ constexpr int big_pf(int NR) {
 }
 
 #ifndef BIG_T
-#define BIG_T 1024  // threads per workgroup of k_mmvq_big (512 was measured too: see DESIGN.md)
+#define BIG_T 1024  // threads per workgroup of k_mmvq_big; 512 (-DBIG_T=512) starts faster (wo: barrier at 1.5 us instead
+                    // of 2.3) but streams slower with half the waves (w1|w3 10.3 us vs 9.2, lm_head 18.6 vs 12.7): 600 vs 612 tok/s
 #endif
 #define BIG_W (BIG_T / 64)
 
