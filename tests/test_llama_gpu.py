@@ -160,6 +160,37 @@ def test_model_loaded_from_ggjt_file_equals_in_memory_model(G, O, wtype, tmp_pat
     assert float(np.max(np.abs(outs[1][0] - ref))) / float(ref.std()) <= EDGE
 
 
+def test_two_sessions_on_two_threads_share_one_model(G, O):
+    """SURVEY §8b threading: models are Send+Sync, sessions are Send — several sessions on different threads may call
+    ggml_graph_compute concurrently over the same weights.  Two threads decode different prompts on one model at the
+    same time; each must produce exactly what it produces alone (the backend serialises graphs under its lock, and
+    the speculative next-graph build between compute_begin/compute_end must not leak across sessions)."""
+    import threading
+    hp, w, model = _mk(G, 2, seed=7)
+    prompts = [np.random.default_rng(100 + i).integers(0, hp["n_vocab"], 7).astype(np.int32) for i in range(2)]
+
+    def run(i, out):
+        s = model.start_session(n_batch=8)
+        s.feed_prompt(prompts[i])
+        toks = [s.infer_next_token() for _ in range(24)]
+        out[i] = (toks, s.last_logits())
+        s.free()
+
+    alone = {}
+    for i in range(2):
+        run(i, alone)
+    together = {}
+    th = [threading.Thread(target=run, args=(i, together)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert together[i][0] == alone[i][0]
+        assert np.array_equal(together[i][1], alone[i][1])
+    model.free()
+
+
 def test_interior_taps_final_norm(G, O):
     """OutputRequest.embeddings (final norm output) against the oracle tap, prompt batch (generic path)."""
     hp, w, model = _mk(G, 2, seed=7)
