@@ -134,7 +134,8 @@ struct Backend {
     long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
     size_t timeline_bytes = 0;
     int opt_mmq_splitk = 1;
-    int opt_mmq_dma = 1;    // prompt GEMM with LDS-DMA staging (kernels/mmq_dma.h) when K/32 is even
+    int opt_mmq_dma = 1;    // prompt GEMM with LDS-DMA staging (kernels/mmq_dma.h) when K/32 is even; 2 = int8 activations
+                            // dequantized in the kernel (13 KB instead of 20 KB per stage, 2x the VALU work: 413 vs 467 TFLOP/s)
     int opt_mmq_xcdn = 0;   // pin XCDs to token tiles (measured slower than the tile-id walk: 393 vs 446 TFLOP/s)
     int opt_mmq_min = 32;   // token count from which mul_mat runs on the MFMA GEMM (0 = never)
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
@@ -288,6 +289,15 @@ struct XF16Buf {  // the prefill GEMM's activation operand (kernels/mmq.h), cach
     const _Float16 *x = nullptr;
     bool valid = false;
 } g_xf16;
+struct XQ8Buf {  // int8 + f16-scale activations of the X8 prompt GEMM (kernels/mmq_dma.h)
+    const void *src_data = nullptr;
+    size_t src_bytes = 0;
+    bool f16_d = false;
+    int64_t nb = 0, ncols = 0;
+    const int8_t *q8 = nullptr;
+    const _Float16 *dx = nullptr;
+    bool valid = false;
+} g_xq8;
 
 char *ws_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -708,6 +718,34 @@ const _Float16 *quantize_activation_f16(const ggml_tensor *src1, bool f16_d) {
     return out;
 }
 
+void quantize_activation_q8p(const ggml_tensor *src1, bool f16_d, const int8_t **q8, const _Float16 **dx) {
+    BK_ASSERT(src1->type == GGML_TYPE_F32 && src1->nb[0] == 4 && src1->ne[2] == 1 && src1->ne[3] == 1);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
+    if (!(g_xq8.valid && g_xq8.src_data == src1->data && g_xq8.f16_d == f16_d && g_xq8.nb == nb && g_xq8.ncols == N)) {
+        int8_t *o8 = (int8_t *)ws_alloc((size_t)N * K);
+        _Float16 *od = (_Float16 *)ws_alloc((size_t)N * nb * 2);
+        Timed tm(GGML_HIP_KCLASS_OTHER, (double)(K * N * 5));
+        const int64_t threads = nb * N * 32;
+        if (f16_d)
+            hipLaunchKernelGGL(k_quant_act_q8p<true>, grid1(threads), dim3(256), 0, g.stream, dev_ptr(src1),
+                               (int64_t)src1->nb[1], nb, N, o8, od);
+        else
+            hipLaunchKernelGGL(k_quant_act_q8p<false>, grid1(threads), dim3(256), 0, g.stream, dev_ptr(src1),
+                               (int64_t)src1->nb[1], nb, N, o8, od);
+        HIP_CHECK(hipGetLastError());
+        g_xq8.valid = true;
+        g_xq8.src_data = src1->data;
+        g_xq8.src_bytes = ggml_nbytes(src1);
+        g_xq8.f16_d = f16_d;
+        g_xq8.nb = nb;
+        g_xq8.ncols = N;
+        g_xq8.q8 = o8;
+        g_xq8.dx = od;
+    }
+    *q8 = g_xq8.q8;
+    *dx = g_xq8.dx;
+}
+
 // Quantized GEMM on the f16 matrix cores (kernels/mmq.h); the `algo_bytes` slot of the MMQ_MFMA timing class
 // carries FLOPs (2*M*N*K), the unit that class is bounded by.
 void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
@@ -716,7 +754,14 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
     const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
     MmqArgs a;
     a.w = qweight_of(src0);
-    a.x = quantize_activation_f16(src1, f16_d);
+    const bool use_dma = g.opt_mmq_dma && nb % 2 == 0, use_x8 = use_dma && g.opt_mmq_dma >= 2;
+    a.x = nullptr;
+    a.x8 = nullptr;
+    a.dx = nullptr;
+    if (use_x8)
+        quantize_activation_q8p(src1, f16_d, &a.x8, &a.dx);
+    else
+        a.x = quantize_activation_f16(src1, f16_d);
     a.dst = (float *)dev_ptr(dst);
     a.ldd = (int64_t)dst->nb[1] / 4;
     a.M = a.w.M;
@@ -742,24 +787,35 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
         lds_attr_set = true;
     }
     Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)a.M * (double)N * (double)K);
-    if (g.opt_mmq_dma && nb % 2 == 0) {
+    if (use_dma) {
         static bool dma_attr_set = false;
         if (!dma_attr_set) {
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q8_0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q8_0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
             dma_attr_set = true;
         }
+#define LAUNCH_DMA(QT_)                                                                                             \
+    if (use_x8)                                                                                                     \
+        hipLaunchKernelGGL((k_mmq_dma<QT_, true>), grid, dim3(256), D8_LDS, g.stream, a);                           \
+    else                                                                                                            \
+        hipLaunchKernelGGL((k_mmq_dma<QT_, false>), grid, dim3(256), DMA_LDS, g.stream, a);
         switch (qt) {
-            case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma<QT_Q4_0>, grid, dim3(256), DMA_LDS, g.stream, a); break;
-            case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma<QT_Q4_1>, grid, dim3(256), DMA_LDS, g.stream, a); break;
-            case QT_Q5_0: hipLaunchKernelGGL(k_mmq_dma<QT_Q5_0>, grid, dim3(256), DMA_LDS, g.stream, a); break;
-            case QT_Q5_1: hipLaunchKernelGGL(k_mmq_dma<QT_Q5_1>, grid, dim3(256), DMA_LDS, g.stream, a); break;
-            case QT_Q8_0: hipLaunchKernelGGL(k_mmq_dma<QT_Q8_0>, grid, dim3(256), DMA_LDS, g.stream, a); break;
+            case QT_Q4_0: LAUNCH_DMA(QT_Q4_0) break;
+            case QT_Q4_1: LAUNCH_DMA(QT_Q4_1) break;
+            case QT_Q5_0: LAUNCH_DMA(QT_Q5_0) break;
+            case QT_Q5_1: LAUNCH_DMA(QT_Q5_1) break;
+            case QT_Q8_0: LAUNCH_DMA(QT_Q8_0) break;
             default: die("mmq: bad weight type");
         }
+#undef LAUNCH_DMA
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -1140,6 +1196,10 @@ void invalidate_xf16_if_overwritten_impl(const ggml_tensor *n) {
     const uintptr_t a0 = (uintptr_t)g_xf16.src_data, a1 = a0 + g_xf16.src_bytes;
     const uintptr_t b0 = (uintptr_t)n->data, b1 = b0 + ggml_nbytes(n);
     if (b0 < a1 && a0 < b1) g_xf16.valid = false;
+    if (g_xq8.valid) {
+        const uintptr_t c0 = (uintptr_t)g_xq8.src_data, c1 = c0 + g_xq8.src_bytes;
+        if (b0 < c1 && c0 < b1) g_xq8.valid = false;
+    }
 }
 
 #include "llama_plan.inc"
@@ -1158,6 +1218,7 @@ void execute_graph(ggml_cgraph *gr) {
     ws_reset();
     g_qact.valid = false;
     g_xf16.valid = false;
+    g_xq8.valid = false;
     if (try_decode_plan(gr)) return;  // single-token LLaMA decode: fused launches + hipGraph replay
     g.stat_generic_graphs++;
     upload_inputs(gr);
@@ -1353,6 +1414,7 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     ws_reset();
     g_qact.valid = false;
     g_xf16.valid = false;
+    g_xq8.valid = false;
     int async = 0;
     if (try_decode_plan(cgraph, true)) {
         async = 1;

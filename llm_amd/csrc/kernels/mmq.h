@@ -67,6 +67,26 @@ __global__ void __launch_bounds__(256) k_quant_act_f16(const char *__restrict__ 
     out[gblock * 32 + mmq_kperm_inv(l)] = (_Float16)r;
 }
 
+// X8 pre-pass: the same quantization, kept as int8 (block order as in a Q8_0 block) + one f16 scale per block.
+// The GEMM then forms f16(f16(d) * q): identical to the f16 pre-pass for the Q8_0 kind (d is an f16 value there),
+// one extra f16 rounding of d (2^-12) for the Q8_1 kind.
+template <bool F16_D>
+__global__ void __launch_bounds__(256) k_quant_act_q8p(const char *__restrict__ x, int64_t nb_row /*bytes*/, int64_t nblk,
+                                                       int64_t nrows, int8_t *__restrict__ q8, _Float16 *__restrict__ dx) {
+    const int64_t gblock = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    if (gblock >= nblk * nrows) return;
+    const int64_t row = gblock / nblk, b = gblock % nblk;
+    const float v = ((const float *)(x + row * nb_row))[b * 32 + l];
+    float amax = fabsf(v);
+    amax = g32_max_f32(amax);
+    float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const int q = (int)roundf(v * id);
+    q8[gblock * 32 + l] = (int8_t)q;
+    if (l == 0) dx[gblock] = (_Float16)fminf(F16_D ? round_f16(d) : d, 65504.0f / 127.0f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // block dequantization: 32 weights -> 4 x (8 f16) in the permuted order
 // ---------------------------------------------------------------------------------------------
@@ -166,6 +186,8 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
 struct MmqArgs {
     QWeight w;
     const _Float16 *x;  // [N][nb*32] permuted f16 activations
+    const int8_t *x8;   // X8 variant of k_mmq_dma: [N][nb*32] int8 quants (ggml order inside a block)
+    const _Float16 *dx; //                           [N][nb] f16 block scales
     float *dst;         // dst[n*ldd + m]
     int64_t ldd;
     int64_t M, N, nb;

@@ -20,6 +20,9 @@
 #pragma once
 #include "mmq.h"
 
+// X8 variant (template parameter): the activations stay int8 + f16 block scale in global memory (1.06 B per
+// element instead of 2: a stage ingests 13.3 KB instead of 20.5 — the kernel is bound by what a CU can ingest) and are
+// dequantized by the same threads and the same code path as Q8_0 weights into a second padded f16 tile.
 #define DMA_XS 0
 #define DMA_WQ 16384
 #define DMA_WQ2 20480
@@ -30,23 +33,33 @@
 #define DMA_RING 4
 #define DMA_WT (DMA_RING * DMA_SLOT)
 #define DMA_LDS (DMA_WT + 2 * MMQ_TILEB)
+// X8 ring slot: X8 [128 rows][64 B] at 0, DX (4 waves x 256 B) at 8192, then the weight parts at the same relative
+// offsets as above minus 7168
+#define D8_X8 0
+#define D8_DX 8192
+#define D8_SHIFT 7168 /* DMA_WQ - 9216: weight parts start at 9216 */
+#define D8_SLOT (DMA_SLOT - D8_SHIFT)
+#define D8_WT (DMA_RING * D8_SLOT)
+#define D8_XT (D8_WT + 2 * MMQ_TILEB)
+#define D8_LDS (D8_XT + 2 * MMQ_TILEB)
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int QT>
+template <int QT, bool X8 = false>
 __device__ __forceinline__ constexpr int dma_group() {  // DMA instructions per stage and wave
-    return 4 + 1 + (QT == QT_Q8_0 ? 1 : 0) + ((QT == QT_Q5_0 || QT == QT_Q5_1) ? 1 : 0) + 1 +
+    return (X8 ? 3 : 4) + 1 + (QT == QT_Q8_0 ? 1 : 0) + ((QT == QT_Q5_0 || QT == QT_Q5_1) ? 1 : 0) + 1 +
            ((QT == QT_Q4_1 || QT == QT_Q5_1) ? 1 : 0);
 }
 
-template <int QT>
+template <int QT, bool X8 = false>
 __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
-    constexpr int G = dma_group<QT>();
+    constexpr int G = dma_group<QT, X8>();
+    constexpr int WSH = X8 ? D8_SHIFT : 0, SLOT = X8 ? D8_SLOT : DMA_SLOT, WT = X8 ? D8_WT : DMA_WT;
 
     int tm, tn;
     if (a.xcd_by_n) {  // token-tile-major walk: the whole chip works on ONE 128-token slice of X at a time
@@ -70,11 +83,23 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
     // ---- per-lane DMA source addresses (bytes), advanced by a fixed stride per stage
     // X: instruction i (0..3) of wave w covers rows 32w + 8i .. +7; lane -> row +(lane>>3), physical chunk lane&7
     const char *xsrc[4];
+    const char *dxsrc = nullptr;
+    if constexpr (X8) {
+        // int8 rows: instruction i (0..1) of wave w covers rows 32w + 16i .. +15; lane -> row +(lane>>2), 16-B chunk lane&3
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = 32 * wave + 8 * i + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        xsrc[i] = (const char *)(a.x + min(n0 + r, a.N - 1) * (a.nb * 32)) + c * 16;
+        for (int i = 0; i < 2; i++) {
+            const int r = 32 * wave + 16 * i + (lane >> 2);
+            xsrc[i] = (const char *)a.x8 + min(n0 + r, a.N - 1) * (a.nb * 32) + (lane & 3) * 16;
+        }
+        xsrc[2] = xsrc[3] = xsrc[0];
+        dxsrc = (const char *)a.dx + min(n0 + 32 * wave + (lane & 31), a.N - 1) * (a.nb * 2);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 32 * wave + 8 * i + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            xsrc[i] = (const char *)(a.x + min(n0 + r, a.N - 1) * (a.nb * 32)) + c * 16;
+        }
     }
     // W: lane -> row 32w + (lane>>1), block lane&1 of the stage
     const int64_t wrow = min(m0 + 32 * wave + (lane >> 1), a.M - 1);
@@ -85,11 +110,20 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
     auto issue = [&](int s /* local stage, clamped */) {
         const int sc = min(s, nstage - 1);
         const int64_t kb = (int64_t)(s_begin + sc) * 2;  // first block of the stage
-        char *slot = lds + (s & (DMA_RING - 1)) * DMA_SLOT;
+        char *slot = lds + (s & (DMA_RING - 1)) * SLOT;
+        if constexpr (X8) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + kb * 64), (lptr_t)(slot + DMA_XS + (32 * wave + 8 * i) * 128),
-                                             16, 0, 0);
+            for (int i = 0; i < 2; i++)
+                __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + kb * 32), (lptr_t)(slot + D8_X8 + (32 * wave + 16 * i) * 64),
+                                                 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(dxsrc + kb * 2), (lptr_t)(slot + D8_DX + wave * 256), 4, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + kb * 64),
+                                                 (lptr_t)(slot + DMA_XS + (32 * wave + 8 * i) * 128), 16, 0, 0);
+        }
+        slot -= WSH;  // the weight parts of an X8 slot sit WSH bytes lower than in the f16 layout
         __builtin_amdgcn_global_load_lds((gptr_t)(a.w.qs + (wblk0 + kb) * 16), (lptr_t)(slot + DMA_WQ + wave * 1024), 16, 0, 0);
         if constexpr (QT == QT_Q8_0)
             __builtin_amdgcn_global_load_lds((gptr_t)(a.w.qs2 + (wblk0 + kb) * 16), (lptr_t)(slot + DMA_WQ2 + wave * 1024), 16,
@@ -117,7 +151,7 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
     const int wr = tid >> 1, wj = tid & 1;
     const int woff = wr * MMQ_ROWB + wj * 64;
     auto raw_load = [&](int s, u32x4 &q, u32x4 &q2, uint32_t &qh, _Float16 &d, _Float16 &m) {
-        const char *slot = lds + (s & (DMA_RING - 1)) * DMA_SLOT;
+        const char *slot = lds + (s & (DMA_RING - 1)) * SLOT - WSH;
         q = *(const u32x4 *)(slot + DMA_WQ + tid * 16);
         q2 = q;
         qh = 0;
@@ -128,6 +162,14 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
         d = *(const _Float16 *)(slot + DMA_WD + (wr >> 5) * 256 + (wr & 31) * 4 + wj * 2);
         if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1)
             m = *(const _Float16 *)(slot + DMA_WM + (wr >> 5) * 256 + (wr & 31) * 4 + wj * 2);
+    };
+
+    // X8: the thread's activation block (token row wr, block wj of the stage): 32 int8 + its f16 scale
+    auto xraw_load = [&](int s, u32x4 &xq, u32x4 &xq2, _Float16 &xd) {
+        const char *slot = lds + (s & (DMA_RING - 1)) * SLOT;
+        xq = *(const u32x4 *)(slot + D8_X8 + wr * 64 + wj * 32);
+        xq2 = *(const u32x4 *)(slot + D8_X8 + wr * 64 + wj * 32 + 16);
+        xd = *(const _Float16 *)(slot + D8_DX + (wr >> 5) * 256 + (wr & 31) * 4 + wj * 2);
     };
 
     // ---- prologue: groups 0, 1, 2 in flight; stage 0's weights dequantized into W tile 0
@@ -142,7 +184,15 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
         raw_load(0, q, q2, qh, d, m);
         mmq_dequant<QT>(q, q2, qh, d, m, o);
 #pragma unroll
-        for (int k = 0; k < 4; k++) *(u32x4 *)(lds + DMA_WT + woff + k * 16) = o[k];
+        for (int k = 0; k < 4; k++) *(u32x4 *)(lds + WT + woff + k * 16) = o[k];
+        if constexpr (X8) {
+            u32x4 xq, xq2;
+            _Float16 xd;
+            xraw_load(0, xq, xq2, xd);
+            mmq_dequant<QT_Q8_0>(xq, xq2, 0u, xd, (_Float16)0.0f, o);
+#pragma unroll
+            for (int k = 0; k < 4; k++) *(u32x4 *)(lds + D8_XT + woff + k * 16) = o[k];
+        }
     }
 
     const int frow_x = lane & 31, fh = lane >> 5;
@@ -150,19 +200,25 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
         // group s+1 landed (groups s+2 may still be in flight), this wave's W-tile writes of the previous stage done
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
         issue(s + 3);  // slot of stage s-1: every wave is past its MFMAs
-        const char *X = lds + (s & (DMA_RING - 1)) * DMA_SLOT + DMA_XS;
-        const char *W = lds + DMA_WT + (s & 1) * MMQ_TILEB;
-        char *Wn = lds + DMA_WT + ((s + 1) & 1) * MMQ_TILEB;
-        u32x4 q, q2;
+        const char *X = X8 ? lds + D8_XT + (s & 1) * MMQ_TILEB : lds + (s & (DMA_RING - 1)) * SLOT + DMA_XS;
+        const char *W = lds + WT + (s & 1) * MMQ_TILEB;
+        char *Wn = lds + WT + ((s + 1) & 1) * MMQ_TILEB;
+        char *Xn = lds + D8_XT + ((s + 1) & 1) * MMQ_TILEB;
+        u32x4 q, q2, xq = {0, 0, 0, 0}, xq2 = {0, 0, 0, 0};
         uint32_t qh;
-        _Float16 d, m;
+        _Float16 d, m, xd = (_Float16)0.0f;
         raw_load(s + 1, q, q2, qh, d, m);  // stage s+1 (clamped duplicates at the end are dequantized and never read)
-        const f16x2 dd = {d, d}, mm = {m, m};
+        if constexpr (X8) xraw_load(s + 1, xq, xq2, xd);
+        const f16x2 dd = {d, d}, mm = {m, m}, xdd = {xd, xd}, zz = {(_Float16)0.0f, (_Float16)0.0f};
         f16x8 fa[2][2], fb[2][2];
         auto xfrag = [&](int j, int ks) {
             const int R = wn * 64 + j * 32 + frow_x;
-            const int p = (ks * 2 + fh) ^ ((R >> 1) & 7);
-            return *(const f16x8 *)(X + R * 128 + p * 16);
+            if constexpr (X8) {
+                return *(const f16x8 *)(X + R * MMQ_ROWB + ks * 32 + fh * 16);
+            } else {
+                const int p = (ks * 2 + fh) ^ ((R >> 1) & 7);
+                return *(const f16x8 *)(X + R * 128 + p * 16);
+            }
         };
         auto wfrag = [&](int i, int ks) {
             return *(const f16x8 *)(W + (wm * 64 + i * 32 + frow_x) * MMQ_ROWB + ks * 32 + fh * 16);
@@ -174,7 +230,7 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            u32x4 o;
+            u32x4 o, ox;
 #pragma unroll
             for (int t2 = 0; t2 < 4; t2++) {
                 const int j = t2 >> 1, i = t2 & 1, cb = ks & 1, nb2 = cb ^ 1;
@@ -186,7 +242,11 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
                         fb[nb2][t2 - 2] = wfrag(t2 - 2, ks + 1);
                 }
                 o[t2] = mmq_dequant_slice<QT>(q, q2, qh, ks, t2, dd, mm);
-                if (t2 == 3) *(u32x4 *)(Wn + woff + ks * 16) = o;
+                if constexpr (X8) ox[t2] = mmq_dequant_slice<QT_Q8_0>(xq, xq2, 0u, ks, t2, xdd, zz);
+                if (t2 == 3) {
+                    *(u32x4 *)(Wn + woff + ks * 16) = o;
+                    if constexpr (X8) *(u32x4 *)(Xn + woff + ks * 16) = ox;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

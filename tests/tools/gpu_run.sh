@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_llama_gpu.py tests/test_fullsize_gpu.py -x -q -m gpu 2>&1 | tail -2
-for v in 1 0; do
-GGML_HIP_PREFETCH=$v timeout 600 python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('prefetch=$v', d['value'], d['ms_per_step'], d['config']['host_split_per_token'])"
+timeout 300 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "prefill" 2>&1 | tail -6
+timeout 300 python -m pytest tests/test_llama_gpu.py -x -q -m gpu -k "prefill" 2>&1 | tail -3
+for d in 2 1; do
+echo "DMA=$d"; GGML_HIP_MMQ_DMA=$d timeout 300 python bench.py --mode prefill --steps 5 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['class_ms_per_step'])"
 done
