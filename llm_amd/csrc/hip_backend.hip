@@ -37,6 +37,7 @@
 #include "kernels/ops.h"
 #include "kernels/decode.h"
 #include "kernels/decode_big.h"
+#include "kernels/decode_big8.h"
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -129,6 +130,7 @@ struct Backend {
     // options
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
+    int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
     int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
     int num_cus = 256;
     long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
@@ -180,6 +182,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_MMVQ_R")) g.opt_mmvq_rows = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_MIN")) g.opt_mmq_min = atoi(v);
     if (const char *v = getenv("GGML_HIP_BIG")) g.opt_big = atoi(v);
+    if (const char *v = getenv("GGML_HIP_PLAN_MULTI")) g.opt_plan_multi = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_SPLITK")) g.opt_mmq_splitk = atoi(v);
@@ -1680,6 +1683,10 @@ void ggml_hip_set_option(const char *key, int value) {
     else if (k == "prefetch") {
         if (g.opt_prefetch != value) drop_all_plans();
         g.opt_prefetch = value;
+    }
+    else if (k == "plan_multi") {
+        if (g.opt_plan_multi != value) drop_all_plans();
+        g.opt_plan_multi = value;
     }
     else if (k == "big") {
         if (g.opt_big != value) drop_all_plans();

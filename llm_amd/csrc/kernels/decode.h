@@ -17,9 +17,10 @@
 #include "ops.h"
 
 struct DecParams {
-    int n_past;   // tokens already in the KV cache = position of the token being decoded
+    int n_past;   // tokens already in the KV cache = position of the (first) token being evaluated
     int token;    // its id (row of tok_embeddings)
     int pad[2];
+    int tokens[8];  // multi-token plan (2..8 tokens of a prompt chunk): ids of all tokens, tokens[0] == token
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -34,6 +35,15 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
     float *s_y = (float *)smem;                 // E floats
     __shared__ double s_part[16];
     const int tid = threadIdx.x;
+    {  // one workgroup per activation row (blockIdx.x; a single row for decode, 2..8 for a prompt chunk)
+        const int64_t r = blockIdx.x;
+        x += r * E;
+        if (y_f32) y_f32 += r * E;
+        lo += r * (E / 2);
+        hi += r * (E / 2);
+        dq += r * (E / 32);
+        sumq += r * (E / 32);
+    }
     double s = 0.0;
     for (int i = tid; i < E; i += 1024) {
         const float v = x[i];
@@ -77,6 +87,14 @@ __global__ void __launch_bounds__(256) k_quant_row(const float *__restrict__ x, 
                                                    float *dq, int *sumq) {
     const int b = (blockIdx.x * 256 + threadIdx.x) >> 5, l = threadIdx.x & 31;
     if (b >= nblk) return;
+    {  // blockIdx.y = activation row
+        const int64_t r = blockIdx.y;
+        x += r * nblk * 32;
+        lo += r * nblk * 16;
+        hi += r * nblk * 16;
+        dq += r * nblk;
+        sumq += r * nblk;
+    }
     const float v = x[b * 32 + l];
     float amax = fabsf(v);
     amax = g32_max_f32(amax);
@@ -412,9 +430,11 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     __shared__ float s_red[16];
     __shared__ double s_redd[16];
     const int h = blockIdx.x, hk = h / n_rep;
+    const int qn = blockIdx.y;  // query token of a prompt chunk (0 for decode): position n_past + qn, row qn of q / outputs
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n_past = prm->n_past;  // requested first; nothing below waits for it until the masks are needed
-    const float *qh = q + (int64_t)h * D;
+    const int n_past = prm->n_past + qn;  // requested first; nothing below waits for it until the masks are needed
+    const int64_t Eq = (int64_t)gridDim.x * D;
+    const float *qh = q + qn * Eq + (int64_t)h * D;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // ---- speculative first pass (positions 0..255 of K and V) + q
@@ -539,7 +559,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     const int nblk = D / 32, l = tid & 31, b = tid >> 5;
     if (b < nblk) {
         const float v = s_o[b * 32 + l];
-        if (out_f32) out_f32[(int64_t)h * D + b * 32 + l] = v;
+        if (out_f32) out_f32[qn * Eq + (int64_t)h * D + b * 32 + l] = v;
         float amax = fabsf(v);
         amax = g32_max_f32(amax);
         const float d = amax / 127.0f;
@@ -547,7 +567,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
         const int qv = (int)roundf(v * id);
         int sq = qv;
         sq = g32_sum_i32(sq);
-        const int64_t gb = (int64_t)h * nblk + b;
+        const int64_t gb = qn * (Eq / 32) + (int64_t)h * nblk + b;
         (l < 16 ? lo : hi)[gb * 16 + (l & 15)] = (int8_t)qv;
         if (l == 0) {
             dq[gb] = F16_D ? round_f16(d) : d;
