@@ -180,6 +180,20 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big8(const Big8Args ba) {
             if (s + k < S) {
                 const int b = lane + 64 * cj;
                 const BigStep<QT, NR> &st = ring[k];
+                // unpack each weight block once, then one v_dot4 chain + scale per activation column
+                uint32_t wl[NR][4], wh[NR][4];
+                float dwf[NR], mwf[NR];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    u32x4 p2 = st.q[r];
+                    uint32_t hh = 0;
+                    mwf[r] = 0.0f;
+                    if constexpr (QT == QT_Q8_0) p2 = st.p[r];
+                    if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) hh = st.h[r];
+                    if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mwf[r] = __half2float(st.mw[r]);
+                    dwf[r] = __half2float(st.dw[r]);
+                    block_unpack<QT>(st.q[r], p2, hh, wl[r], wh[r]);
+                }
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     if (c < ncols) {  // uniform
@@ -187,15 +201,8 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big8(const Big8Args ba) {
                         const float xd = s_d[c * nbp + b];
                         const int xs = s_sum[c * nbp + b];
 #pragma unroll
-                        for (int r = 0; r < NR; r++) {
-                            u32x4 p2 = st.q[r];
-                            uint32_t hh = 0;
-                            float mw = 0.0f;
-                            if constexpr (QT == QT_Q8_0) p2 = st.p[r];
-                            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) hh = st.h[r];
-                            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mw = __half2float(st.mw[r]);
-                            acc[r][c] += block_dot<QT>(st.q[r], p2, hh, __half2float(st.dw[r]), mw, lo, hi, xd, xs);
-                        }
+                        for (int r = 0; r < NR; r++)
+                            acc[r][c] += block_dot_codes<QT>(wl[r], wh[r], dwf[r], mwf[r], lo, hi, xd, xs);
                     }
                 }
                 if (++cj == nbl) {

@@ -132,6 +132,51 @@ __device__ __forceinline__ float block_dot(const u32x4 q, const u32x4 q2, const 
     }
 }
 
+// The same arithmetic split in two for kernels that dot one weight block with several activation blocks
+// (decode_big8.h): unpack the 32 codes of the block once into 8 dwords of int8 (zero point NOT applied), then
+// block_dot_codes per activation column = 8 v_dot4 + the type's scale formula.
+template <int QT>
+__device__ __forceinline__ void block_unpack(const u32x4 q, const u32x4 q2, const uint32_t qh, uint32_t (&wl)[4],
+                                             uint32_t (&wh)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if constexpr (QT == QT_Q4_0 || QT == QT_Q4_1) {
+            wl[k] = q[k] & 0x0F0F0F0Fu;
+            wh[k] = (q[k] >> 4) & 0x0F0F0F0Fu;
+        } else if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) {
+            wl[k] = (q[k] & 0x0F0F0F0Fu) | spread_hi4((qh >> (4 * k)) & 0xFu);
+            wh[k] = ((q[k] >> 4) & 0x0F0F0F0Fu) | spread_hi4((qh >> (16 + 4 * k)) & 0xFu);
+        } else {
+            wl[k] = q[k];
+            wh[k] = q2[k];
+        }
+    }
+}
+template <int QT>
+__device__ __forceinline__ float block_dot_codes(const uint32_t (&wl)[4], const uint32_t (&wh)[4], const float dw,
+                                                 const float mw, const i32x4 lo, const i32x4 hi, const float xd,
+                                                 const int xs) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        s = SDOT4(wl[k], lo[k], s);
+        s = SDOT4(wh[k], hi[k], s);
+    }
+    if constexpr (QT == QT_Q4_0) {
+        s -= 8 * xs;
+        return ((float)s * dw) * xd;
+    } else if constexpr (QT == QT_Q4_1) {
+        return (dw * xd) * (float)s + mw * ((float)xs * xd);
+    } else if constexpr (QT == QT_Q5_0) {
+        s -= 16 * xs;
+        return (dw * xd) * (float)s;
+    } else if constexpr (QT == QT_Q5_1) {
+        return (dw * xd) * (float)s + mw * ((float)xs * xd);
+    } else {
+        return (float)s * (dw * xd);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // the mat-vec kernel.  grid.x = ceil(M / (4*R)); block = 256 threads = 4 waves; wave w owns rows
 // m0..m0+R-1.  dst column stride in floats = ldd.  Dynamic LDS = NCOLS*nb*40 bytes.
