@@ -1,18 +1,22 @@
-// decode_big.h — the decode mat-vec as ONE wave of big workgroups: grid = #CUs x 1024 threads, every workgroup owns
-// a contiguous slab of output rows, the weight stream is prefetched PF steps deep into registers BEFORE the
-// activation is touched, and the activation's norm / re-quantization is done by each workgroup while those loads
-// are in flight.  Same arithmetic as k_mmvq_dec (decode.h) / k_mmvq (mmvq.h); same epilogues.
+// decode_big.h — the decode mat-vec as ONE wave of big workgroups: grid = #CUs x 1024 threads, the workgroups walk the
+// output rows together (unit u -> workgroup (u / 16) mod G, so at any moment the chip streams one contiguous window of
+// the matrix), the activation's loads are the first memory operations of the kernel, the weight stream is prefetched
+// into a register ring (2 steps before the activation is staged, the rest after), and the activation's norm /
+// re-quantization is done by each workgroup while those loads are in flight.  Same arithmetic as k_mmvq_dec
+// (decode.h) / k_mmvq (mmvq.h); same epilogues.
 //
-// Why (measured on MI355X, profiles/r01_run8): with 256-thread workgroups a LLaMA-7B mat-vec needs 512..4000
-// workgroups, each of which re-stages x (4.6 KB from L2, ~1 us of latency before its first dot) and has one
+// Why (measured on MI355X, profiles/r01_run8 -> r01_run33): with 256-thread workgroups a LLaMA-7B mat-vec needs
+// 512..4000 workgroups, each of which re-stages x (4.6 KB from L2, ~1 us of latency before its first dot) and has one
 // K-step of weights in flight; the E x E mat-vec ran at 1.9 TB/s, wq|wk|wv at 3.0 TB/s, and the separate
 // rms_norm+quantize / quantize launches in front of them cost ~6 us each (a 1-workgroup latency chain plus a
 // kernel boundary).  Here:
 //   * 256 workgroups = one per CU, resident at once: no dispatch tail, x staged 256 times instead of 4000;
-//   * 16 waves x PF steps x 16 B x rows-per-step in flight per lane before anything else happens
-//     (>= 128 KB per CU): the whole HBM pipe is busy from the first cycle of the kernel;
-//   * staging x = rms_norm (f64 sum of squares) -> weight -> Q8 blocks in LDS costs each workgroup ~1.5 us of
-//     latency that overlaps the weight prefetch, and removes 3 launches per layer (8 -> 5).
+//   * 16 waves x up to 8 steps x 16 B x rows-per-step in flight per lane: the HBM pipe is busy from the start;
+//   * staging x = rms_norm (f64 sum of squares) -> weight -> Q8 blocks in LDS overlaps the weight prefetch and
+//     removes 3 launches per layer (8 -> 5).
+// The pitfalls that made the first version slower than what it replaced are listed in DESIGN.md section 4 (in-order
+// load return, vector loads of kernarg arrays, uncountable loads in flight, epilogue loads, x queued behind the
+// prefetch, 64-bit index math).
 // A "unit" is what one wave reduces together: a pair of adjacent rows for wq|wk|wv (RoPE rotates the pair),
 // row m of w1 and of w3 for the gate, one row otherwise.  A "step" is one 64-block column of a unit.
 #pragma once
