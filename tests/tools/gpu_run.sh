@@ -1,16 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_llama_gpu.py tests/test_fullsize_gpu.py -q -m gpu 2>&1 | tail -3
-python - <<'PY'
-import time, numpy as np
-from llm_amd import ggml as G, llama, synth
-hp, w = synth.make_llama_fast(synth.LLAMA_7B, G.TYPE_Q4_0)
-model = llama.Llama(hp, w, context_size=2048)
-prompt = np.random.default_rng(42).integers(0, hp["n_vocab"], 128).astype(np.int32)
-for rep in range(3):
-    s = model.start_session(n_batch=8)
-    G.lib().ggml_hip_synchronize(); t = time.perf_counter()
-    s.feed_prompt(prompt)
-    G.lib().ggml_hip_synchronize(); dt = time.perf_counter() - t
-    s.free()
-print(f"128-token prompt at n_batch=8: {dt*1e3:.1f} ms = {128/dt:.0f} tok/s")
-PY
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python bench.py > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/bench_decode.json
+timeout 600 python bench.py --mode prefill --steps 5 --warmup 2 > gpurun_out/bench_prefill.json 2>/dev/null; cut -c1-200 gpurun_out/bench_prefill.json
+rm -rf /tmp/prof_dec
+GGML_HIP_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_dec -o bench -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_dec.log 2>&1; echo "prof rc=$?"
+grep '"metric"' gpurun_out/prof_dec.log > gpurun_out/prof_dec_bench_line.json
+python tests/tools/kstats.py /tmp/prof_dec > gpurun_out/prof_dec_stats.txt; head -8 gpurun_out/prof_dec_stats.txt
