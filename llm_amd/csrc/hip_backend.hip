@@ -135,6 +135,7 @@ struct Backend {
     int num_cus = 256;
     long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
     size_t timeline_bytes = 0;
+    int timeline_wgs = 4;  // sampled workgroups per launch
     int opt_mmq_splitk = 1;
     int opt_mmq_dma = 1;    // prompt GEMM with LDS-DMA staging (kernels/mmq_dma.h) when K/32 is even; 2 = int8 activations
                             // dequantized in the kernel (13 KB instead of 20 KB per stage, 2x the VALU work: 413 vs 467 TFLOP/s)
@@ -1668,9 +1669,15 @@ void ggml_hip_set_option(const char *key, int value) {
     }
     else if (k == "timeline") {
         drop_all_plans();
+        if (g.timeline && value && (value == 1 ? 4 : value) != g.timeline_wgs) {
+            HIP_CHECK(hipStreamSynchronize(g.stream));
+            (void)hipFree(g.timeline);
+            g.timeline = nullptr;
+        }
         if (value && !g.timeline) {
             ensure_init();
-            g.timeline_bytes = (size_t)1024 * 4 * 8 * 8;
+            g.timeline_wgs = value == 1 ? 4 : value;
+            g.timeline_bytes = (size_t)1024 * g.timeline_wgs * 8 * 8;
             HIP_CHECK(hipMalloc((void **)&g.timeline, g.timeline_bytes));
         }
         if (!value && g.timeline) {

@@ -23,6 +23,20 @@ struct DecParams {
     int tokens[8];  // multi-token plan (2..8 tokens of a prompt chunk): ids of all tokens, tokens[0] == token
 };
 
+// (cos, sin) of the RoPE angle of pair kk of a head at this token's position, as ggml's rope computes them:
+// theta_kk = freq_scale*p * theta_scale^kk by repeated f32 multiplication (reference ggml.c rope, f32 branch).  One
+// launch per token; the wq|wk|wv mat-vec of every layer reads the table instead of re-deriving it (64 dependent
+// multiplies + sincos on two waves held up the whole workgroup's first barrier by ~2.5 us per layer).
+__global__ void __launch_bounds__(128) k_rope_table(const DecParams *__restrict__ prm, float theta_scale, float freq_scale,
+                                                    int half_d, float *__restrict__ out) {
+    const int kk = threadIdx.x;
+    if (kk >= half_d) return;
+    float theta = freq_scale * (float)prm->n_past;
+    for (int t = 0; t < kk; t++) theta *= theta_scale;
+    out[2 * kk] = cosf(theta);
+    out[2 * kk + 1] = sinf(theta);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // rms_norm (f64 Σx², eps) → multiply by weight → optional f32 copy → Q8 re-quantization, one 1024-thread
 // workgroup for the single activation row.

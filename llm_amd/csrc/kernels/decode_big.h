@@ -48,9 +48,10 @@ __device__ __forceinline__ constexpr int big_pf(int NR) {
 struct BigArgs {
     DecMmvqArgs d;
     float *y_out;  // XSRC_NORM: optional f32 copy of the normed row (final norm -> OutputRequest.embeddings)
-    long long *ts;  // optional timeline slot (ggml_hip_set_option("timeline", 1)): 8 x int64 per sampled workgroup
+    long long *ts;  // optional timeline slot (ggml_hip_set_option("timeline", n)): 8 x int64 per sampled workgroup
+    int ts_wgs;     // workgroups that record: 0, G/n, 2G/n, ... (n = 4 for "timeline" = 1, else the option's value)
+    const float *rope;  // EPI_QKV: (cos, sin) of this token's RoPE angle per pair of a head, from k_rope_table
 };
-#define BIG_TS_WGS 4  // workgroups 0, G/4, G/2, 3G/4 record
 __device__ __forceinline__ long long big_now() { return (long long)wall_clock64(); }  // 100 MHz, chip-wide
 
 // The activation's global loads, issued as the FIRST memory operations of the kernel: a wave's loads return in
@@ -107,7 +108,8 @@ struct BigX<XSRC_NORM> {
 // registers -> LDS as padded planar Q8 (nbp = nbl*64 blocks; blocks >= nb are zero so tail steps contribute 0)
 template <bool F16_D, int XSRC>
 __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int64_t nb, int64_t nbp, int tid,
-                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part) {
+                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part,
+                                            long long *tsx = nullptr) {
     const DecMmvqArgs &d = a.d;
     (void)s_part;
     for (int64_t i = nb + tid; i < nbp; i += BIG_T) {
@@ -149,8 +151,13 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
             }
             ss = wave_sum_f64(ss);
             if ((tid & 63) == 0) s_part[tid >> 6] = ss;
+            if (tsx) {
+                asm volatile("; x landed, summed %0" ::"v"((float)ss));
+                tsx[0] = big_now();
+            }
         }
         __syncthreads();
+        if (tsx) tsx[1] = big_now();
         if (stager) {
             double tot = 0.0;
 #pragma unroll
@@ -206,6 +213,13 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     if constexpr (EPI == EPI_QKV) n_past = a.prm->n_past;
     BigX<XSRC> xr;
     xr.load(ba, nb, tid);
+    // EPI_QKV: the last two waves fetch the token's RoPE table (k_rope_table); every wave issues the load so that all
+    // load queues keep one compile-time shape
+    f32x2 rope_pre = {0.0f, 0.0f};
+    if constexpr (EPI == EPI_QKV) {
+        const int kk = tid - (BIG_T - 128);
+        rope_pre = ((const f32x2 *)ba.rope)[(kk >= 0 && kk < (a.D >> 1)) ? kk : 0];
+    }
 
     // this wave's units: ((i * G + g) * 16 + wave), i < nu — at any moment the G workgroups together stream ONE
     // contiguous window of G*16 units of the matrix.  Lane i of the wave owns unit i's epilogue.
@@ -240,11 +254,16 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     // The loads of a step are UNCONDITIONAL (addresses clamped; lanes past the row end read block nb-1 and meet
     // zero x blocks in LDS): the number of memory operations in flight is a compile-time constant at every
     // wait, so hipcc waits for exactly the step it needs (s_waitcnt vmcnt(N)) instead of draining the queue.
-    auto issue = [&](BigStep<QT, NR> &st, int i, int j, bool dummy) {
+    // The row bases of the producer's current unit live in scalar registers and change only when the producer moves
+    // to the next unit: a step then costs two vector instructions of address math (block index, clamp) — the
+    // per-step resolve + pointer selects + 64-bit vector adds it replaces were ~12 VALU and, for wq|wk|wv, ~50 SALU
+    // per step, on a CU whose 16 waves share one scalar unit (in-kernel timeline: loads issued 1.6 us after entry).
+    const uint8_t *ub_qs[NR], *ub_qs2[NR];
+    const uint32_t *ub_qh[NR];
+    const __half *ub_d[NR], *ub_m[NR];
+    auto set_unit = [&](int i) {
         int sg, m0;
         resolve(i, sg, m0);
-        const int b = lane + 64 * j;
-        const int bc = dummy ? 0 : (b < nb ? b : nb - 1);  // a dummy step reads one line for the whole wave
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const uint8_t *qs = a.w[0].qs, *qs2 = a.w[0].qs2;
@@ -261,12 +280,24 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
                 wd = sg == 0 ? a.w[0].d : sg == 1 ? a.w[1].d : a.w[2].d;
                 wm = sg == 0 ? a.w[0].m : sg == 1 ? a.w[1].m : a.w[2].m;
             }
-            const uint32_t o = (uint32_t)(m0 + (EPI == EPI_QKV ? k : 0)) * (uint32_t)nb + (uint32_t)bc;
-            st.q[k] = __builtin_nontemporal_load((const u32x4 *)(qs + (size_t)o * 16));
-            if constexpr (QT == QT_Q8_0) st.p[k] = __builtin_nontemporal_load((const u32x4 *)(qs2 + (size_t)o * 16));
-            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) st.h[k] = __builtin_nontemporal_load(qh + o);
-            st.dw[k] = wd[o];
-            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) st.mw[k] = wm[o];
+            const size_t ro = (size_t)(uint32_t)(m0 + (EPI == EPI_QKV ? k : 0)) * (uint32_t)nb;  // first block of the row
+            ub_qs[k] = qs + ro * 16;
+            ub_qs2[k] = qs2 + ro * 16;
+            ub_qh[k] = qh + ro;
+            ub_d[k] = wd + ro;
+            ub_m[k] = wm + ro;
+        }
+    };
+    auto issue = [&](BigStep<QT, NR> &st, int j, bool dummy) {
+        const int b = lane + 64 * j;
+        const uint32_t bc = dummy ? 0u : (uint32_t)(b < nb ? b : nb - 1);  // a dummy step reads one line for the whole wave
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            st.q[k] = __builtin_nontemporal_load((const u32x4 *)(ub_qs[k] + (size_t)bc * 16));
+            if constexpr (QT == QT_Q8_0) st.p[k] = __builtin_nontemporal_load((const u32x4 *)(ub_qs2[k] + (size_t)bc * 16));
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) st.h[k] = __builtin_nontemporal_load(ub_qh[k] + bc);
+            st.dw[k] = ub_d[k][bc];
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) st.mw[k] = ub_m[k][bc];
         }
     };
 
@@ -278,33 +309,36 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     auto advance = [&](int k) {
         if (k + 1 < S && ++pj == nbl) {
             pj = 0;
-            pi++;
+            set_unit(++pi);
         }
     };
+    set_unit(0);
 #pragma unroll
     for (int k = 0; k < PF0; k++) {
-        issue(ring[k], pi, pj, k >= S);
+        issue(ring[k], pj, k >= S);
         advance(k);
     }
     const long long t_issued = ba.ts ? big_now() : 0;
 
-    // ---- 3. norm / re-quantization of x into LDS; meanwhile the last wave (not a stager) tabulates the RoPE
-    //         rotation of this position: theta_k = freq_scale*p * theta_scale^k as ggml's iterated f32 product
+    // ---- 3. norm / re-quantization of x into LDS; meanwhile the last two waves (not stagers) park the RoPE table
     if constexpr (EPI == EPI_QKV) {
         if (tid >= BIG_T - 128 && tid - (BIG_T - 128) < (a.D >> 1)) {
             const int kk = tid - (BIG_T - 128);
-            float theta = a.freq_scale * (float)n_past;
-            for (int t = 0; t < kk; t++) theta *= a.theta_scale;
-            s_rope[2 * kk] = cosf(theta);
-            s_rope[2 * kk + 1] = sinf(theta);
+            s_rope[2 * kk] = rope_pre[0];
+            s_rope[2 * kk + 1] = rope_pre[1];
         }
     }
+#ifdef BIG_TS_STAGE
+    long long tsx[2] = {0, 0};
+    big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, s_lo, s_hi, s_d, s_sum, s_part, ba.ts ? tsx : nullptr);
+#else
     big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, s_lo, s_hi, s_d, s_sum, s_part);
+#endif
     const long long t_staged = ba.ts ? big_now() : 0;
     // ---- 2b. the rest of the ring
 #pragma unroll
     for (int k = PF0; k < PF; k++) {
-        issue(ring[k], pi, pj, k >= S);
+        issue(ring[k], pj, k >= S);
         advance(k);
     }
     __syncthreads();
@@ -348,10 +382,10 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
                     ci++;
                 }
                 if (s + k + PF < S) {
-                    issue(ring[k], pi, pj, false);
+                    issue(ring[k], pj, false);
                     if (++pj == nbl) {
                         pj = 0;
-                        pi++;
+                        if (s + k + PF + 1 < S) set_unit(++pi);
                     }
                 }
             }
@@ -389,10 +423,13 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
         }
     }
     if (ba.ts && wave == 0 && lane == 0) {
-        const int q = (int)gridDim.x / BIG_TS_WGS;
-        if (q > 0 && blockIdx.x % q == 0 && (int)blockIdx.x / q < BIG_TS_WGS) {
+        const int q = (int)gridDim.x / ba.ts_wgs;
+        if (q > 0 && blockIdx.x % q == 0 && (int)blockIdx.x / q < ba.ts_wgs) {
             long long *o = ba.ts + ((int)blockIdx.x / q) * 8;
             o[0] = t_entry; o[1] = t_issued; o[2] = t_staged; o[3] = t_barrier; o[4] = t_first; o[5] = big_now();
+#ifdef BIG_TS_STAGE
+            if (XSRC == XSRC_NORM) { o[3] = tsx[0]; o[4] = tsx[1]; }  // x landed + summed; first barrier passed
+#endif
             o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = blockIdx.x;
         }
     }

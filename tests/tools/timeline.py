@@ -11,6 +11,35 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from llm_amd import ggml, llama, synth  # noqa: E402
 
 
+def distribution(t, L, nw):
+    """Entry / exit spread over ALL sampled workgroups per launch kind (layers 2..L-1 averaged): is the launch
+    waiting for a few slow workgroups?"""
+    n = 5 * L + 1
+    t = t[:n]
+    keep = [i for i in range(n) if not (i % 5 == 1 and i < 5 * L)]
+    t = t[keep].astype(np.float64) / 100.0
+    names = ["qkv", "wo", "gate", "down"]
+    pct = (0, 10, 50, 90, 99, 100)
+    print("per launch kind, us relative to the first workgroup's entry; percentiles over workgroups " + str(pct))
+    for k, nm in enumerate(names + ["lm_head"]):
+        rows = t[k + 8:4 * L:4] if k < 4 else t[4 * L:4 * L + 1]
+        e0 = rows[:, :, 0].min(axis=1, keepdims=True)
+        ent = rows[:, :, 0] - e0
+        ext = rows[:, :, 5] - e0
+        dur = rows[:, :, 5] - rows[:, :, 0]
+        stg = rows[:, :, 2] - rows[:, :, 0]
+        f = lambda a: " ".join("%6.2f" % np.percentile(a, q, axis=1).mean() for q in pct)
+        print(f"{nm:8s} entry  {f(ent)}")
+        print(f"{nm:8s} staged {f(stg)}")
+        print(f"{nm:8s} dur    {f(dur)}")
+        print(f"{nm:8s} exit   {f(ext)}")
+        # which workgroups are the slow ones?  (by XCD = blockIdx % 8 and by position in the grid)
+        by_xcd = [dur[:, x::8].mean() for x in range(8)]
+        print(f"{nm:8s} mean dur by blockIdx%8: " + " ".join("%5.2f" % v for v in by_xcd))
+        late = np.argsort(-ext.mean(axis=0))[:8]
+        print(f"{nm:8s} latest workgroups: " + " ".join("%d(%.2f)" % (int(rows[0, j, 7] * 100), ext[:, j].mean()) for j in late))
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "7b"
     hp0 = {"7b": synth.LLAMA_7B, "13b": synth.LLAMA_13B, "tiny": synth.TINY}[name]
@@ -20,13 +49,16 @@ def main():
     s.feed_prompt((np.arange(128, dtype=np.int32) * 7 + 5) % hp["n_vocab"])
     for _ in range(4):
         s.infer_next_token()
-    ggml.set_option("timeline", 1)
+    nw = int(sys.argv[2]) if len(sys.argv) > 2 else 4  # sampled workgroups per launch (e.g. 256 = all of them)
+    ggml.set_option("timeline", 1 if nw == 4 else nw)
     for _ in range(3):
         s.infer_next_token()
     ggml.lib().ggml_hip_synchronize()
-    t = ggml.read_timeline()
+    t = ggml.read_timeline(1024 * nw)
     ggml.set_option("timeline", 0)
-    t = t.reshape(-1, 4, 8)
+    t = t.reshape(-1, nw, 8)
+    if nw != 4:
+        return distribution(t, hp["n_layer"], nw)
     L = hp["n_layer"]
     n = 5 * L + 1
     t = t[:n]
