@@ -477,7 +477,10 @@ GGML_API void ggml_hip_timing_begin(void);
 GGML_API void ggml_hip_timing_end(void);
 GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes);
 /* Execution mode knobs: "fuse" (peephole fusion in the generic executor), "plan" (fused LLaMA decode plan),
- * "graph" (hipGraph replay of the plan), "mmvq_rows", "big", "mmq_min", "timeline"; also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH. */
+ * "graph" (hipGraph replay of the plan), "mmvq_rows", "big", "mmq_min", "mmq_splitk", "mmq_dma", "plan_multi",
+ * "xsrc", "timeline" (1 = 4 sampled workgroups per launch, n > 1 = n of them), "prefetch" (MB of w1|w3 that the idle
+ * CUs of the decode attention launch pull into the Infinity Cache, 0 = off, measured slower: DESIGN.md section 4);
+ * also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH / GGML_HIP_BIG / GGML_HIP_PREFETCH / GGML_HIP_MMQ_*. */
 GGML_API void ggml_hip_set_option(const char *key, int value);
 /* Replays the launches of one kernel class of the most recent fused decode plan `replays` times from a
  * dedicated hipGraph between two HIP events on the backend stream (bench.py roofline leg). 0 on success.
@@ -496,7 +499,7 @@ GGML_API int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph);
 GGML_API void ggml_hip_graph_compute_end(void);
 /* In-kernel timeline of the decode mat-vec launches (ggml_hip_set_option("timeline", 1), eager or graph mode):
  * records of 8 x int64 {entry, loads issued, x staged, barrier passed, first weights landed, exit (100 MHz
- * wall clock ticks), steps of wave 0, workgroup id}; 4 sampled workgroups per launch, launch order.
+ * wall clock ticks), steps of wave 0, workgroup id}; 4 (or "timeline" = n) sampled workgroups per launch, launch order.
  * Returns the number of records copied. */
 GGML_API size_t ggml_hip_read_timeline(int64_t *dst, size_t max_records);
 GGML_API const char *ggml_hip_version(void);

@@ -110,10 +110,8 @@ struct Backend {
     bool inited = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side_stream = nullptr;  // Infinity-Cache warm-up next to the attention launch (decode plan)
-    hipEvent_t side_ev[2] = {nullptr, nullptr}, side_join = nullptr;
-    int opt_prefetch = 0;  // measured: device time 1.50 -> 1.43 ms/token, but launching the two-branch hipGraph costs
-                           // the host 0.69 ms instead of 0.013 ms (438 vs 612 tok/s) — off
+    int opt_prefetch = 0;  // MB of w1|w3 (plus all of wo) that the idle CUs of the decode attention launch pull into the
+                           // Infinity Cache (llama_plan.inc); 0 = off
     std::map<uintptr_t, Arena> arenas;          // by base
     std::map<uintptr_t, DevTensor *> tensors;   // explicit records (transform_tensor / assign_buffers_no_scratch)
     std::map<uintptr_t, DevTensor *> auto_tensors;  // persistent leaves uploaded on first use (never offloaded by
@@ -172,9 +170,6 @@ void ensure_init() {
     if (g.device >= n) g.device = g.device % n;
     HIP_CHECK(hipSetDevice(g.device));
     HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&g.side_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&g.side_ev[i], hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&g.side_join, hipEventDisableTiming));
     if (const char *v = getenv("GGML_HIP_PREFETCH")) g.opt_prefetch = atoi(v);
     if (const char *v = getenv("GGML_HIP_FUSE")) g.opt_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN")) g.opt_plan = atoi(v);

@@ -387,24 +387,29 @@ __global__ void __launch_bounds__(256) k_mmvq_dec(const DecMmvqArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // Infinity-Cache warm-up: streams `n16` 16-byte pieces of up to three weight planes through the memory-side cache
-// (default cache policy, results discarded).  Runs on a side stream next to k_attn_decode, which keeps only
-// n_head CUs busy and leaves HBM idle for ~10 us per layer: the wo and w1|w3 weights that the next two mat-vecs
-// stream are then served from the 256 MB Infinity Cache (measured: w1|w3 mat-vec 12.9 -> 11.1 us when resident).
+// (default cache policy, results discarded).  Done by the spare workgroups of the decode k_attn_decode launch, which
+// keeps only n_head CUs busy and leaves HBM idle for ~10 us per layer: the wo and w1|w3 weights that the next two
+// mat-vecs stream are then served from the 256 MB Infinity Cache (measured: w1|w3 mat-vec 12.9 -> 11.1 us when
+// resident).  A separate kernel on a side stream did the same but made the hipGraph two-branched, which costs the
+// host 0.69 ms per launch instead of 0.013 ms.
 // ---------------------------------------------------------------------------------------------------
 struct PrefetchArgs {
     const u32x4 *p[3];
     int64_t n16[3];
     unsigned *sink;  // never written (the condition below is never true), keeps the loads alive
 };
-__global__ void __launch_bounds__(256) k_prefetch(const PrefetchArgs a) {
+// Part `part` of `parts` of the prefetch, by one 1024-thread workgroup: 8 independent 16-byte loads per thread in
+// flight, default cache policy, results discarded (the never-true store keeps them alive).
+__device__ __forceinline__ void prefetch_slice(const PrefetchArgs &a, int part, int parts) {
     u32x4 acc = {0, 0, 0, 0};
+    const int64_t T = blockDim.x;
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const int64_t n = a.n16[s];
-        for (int64_t i0 = (int64_t)blockIdx.x * 256 * 8 + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * 256 * 8) {
+        for (int64_t i0 = (int64_t)part * T * 8 + threadIdx.x; i0 < n; i0 += (int64_t)parts * T * 8) {
             u32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = i0 + u * 256 < n ? a.p[s][i0 + u * 256] : u32x4{0, 0, 0, 0};
+            for (int u = 0; u < 8; u++) v[u] = i0 + u * T < n ? a.p[s][i0 + u * T] : u32x4{0, 0, 0, 0};
 #pragma unroll
             for (int u = 0; u < 8; u++) acc ^= v[u];
         }
@@ -436,7 +441,14 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
                                                       const __half *__restrict__ mem_v, const DecParams *prm,
                                                       float scale, int D, int n_rep /* H / Hkv */, int64_t Egqa,
                                                       int64_t C, float *out_f32, int8_t *lo, int8_t *hi, float *dq,
-                                                      int *sumq, long long *ts) {
+                                                      int *sumq, long long *ts, int n_head, const PrefetchArgs pf) {
+    // Workgroups past the heads (decode only; the plan launches one per otherwise idle CU) pull the weights of the
+    // next two mat-vecs through the memory-side Infinity Cache: attention keeps n_head CUs busy on a latency
+    // chain and leaves HBM idle for its whole duration.
+    if ((int)blockIdx.x >= n_head) {
+        prefetch_slice(pf, (int)blockIdx.x - n_head, (int)gridDim.x - n_head);
+        return;
+    }
     const long long t_entry = ts ? (long long)wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_s = (float *)smem;  // C scores / probabilities
@@ -447,7 +459,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     const int qn = blockIdx.y;  // query token of a prompt chunk (0 for decode): position n_past + qn, row qn of q / outputs
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_past = prm->n_past + qn;  // requested first; nothing below waits for it until the masks are needed
-    const int64_t Eq = (int64_t)gridDim.x * D;
+    const int64_t Eq = (int64_t)n_head * D;
     const float *qh = q + qn * Eq + (int64_t)h * D;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
