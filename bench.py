@@ -113,18 +113,24 @@ def run_single(args):
     L.ggml_hip_synchronize()
     stat = lambda k: int(L.ggml_hip_get_stat(k.encode()))
     h0 = {k: stat(k) for k in ("ns_match", "ns_launch", "ns_wait", "ns_compute", "plan_tokens")}
+    sess.host_timing(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sess.infer_next_token()
     L.ggml_hip_synchronize()
     elapsed = time.perf_counter() - t0
     tok_s = args.steps / elapsed
+    ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
     h1 = {k: stat(k) - v for k, v in h0.items()}
     host_split = {"plan_tokens": h1["plan_tokens"],
                   "graph_build_and_sampling_ms": round((elapsed * 1e9 - h1["ns_compute"]) / args.steps / 1e6, 4),
                   "match_ms": round(h1["ns_match"] / args.steps / 1e6, 4),
                   "enqueue_ms": round(h1["ns_launch"] / args.steps / 1e6, 4),
-                  "device_wait_ms": round(h1["ns_wait"] / args.steps / 1e6, 4)}
+                  "device_wait_ms": round(h1["ns_wait"] / args.steps / 1e6, 4),
+                  "host_phases_us": {"adopt_or_build_graph": round(ht[0], 1), "token_write_and_plan": round(ht[1], 1),
+                                     "compute_begin": round(ht[2], 1), "speculative_build_next": round(ht[3], 1),
+                                     "compute_end_wait_and_copy": round(ht[4], 1), "argmax": round(ht[5], 1),
+                                     "evaluate_total": round(ht[6], 1)}}
 
     # roofline leg.  Dominant kernel = the w1|w3 (gate/up) mat-vec, k_mmvq_big<Q4_0, EPI_GATE, XSRC_NORM>: 45 % of the
     # weight bytes of a layer.  (a) HIP events on the backend's own stream around `rs` replays of a hipGraph that

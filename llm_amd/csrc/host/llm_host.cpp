@@ -9,6 +9,7 @@
 // of include/ggml_hip.h.
 #include "llm_host.h"
 
+#include <chrono>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -125,6 +126,12 @@ class InferenceSession {
     }
 
     using Builder = std::function<std::pair<ComputationGraph, GraphOutputs>(BuildContext &)>;
+    // host time per phase of compute(), ns, accumulated (llm_host_timing): [0] adopt/build, [1] token write + plan,
+    // [2] begin (match + enqueue), [3] speculative build of the next graph, [4] end (wait + result copy)
+    static inline double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static inline double now_ns() {
+        return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
 
     // inference_session.rs:220-295.  `next_builder` (optional) is a host-side latency optimisation that does not
     // change what is computed: while the device runs a single-token graph, the graph of the NEXT single-token call
@@ -135,6 +142,8 @@ class InferenceSession {
                          const std::function<Builder(size_t /*session_len*/)> &next_builder = nullptr,
                          const void *model_key = nullptr, size_t context_size = 0) {
         const bool single = input_tokens.size() == 1;
+        double t0 = now_ns(), t1;
+        auto lap = [&](int k) { t1 = now_ns(); host_ns[k] += t1 - t0; t0 = t1; };
         Built built;
         if (single && pre_.valid && pre_.n_past == n_past && pre_.model_key == model_key) {
             cur_ = pre_.slot;  // adopt the speculatively built graph
@@ -144,11 +153,14 @@ class InferenceSession {
             built = build_into(cur_, input_tokens.size(), builder);
         }
         pre_.valid = false;
+        lap(0);
         Context &ctx0 = ctx0_[cur_];
         built.embd.write_data(input_tokens.data(), input_tokens.size() * sizeof(TokenId));  // Write input tokens
         {
             GraphExecutionPlan plan(built.gf, config.n_threads);
+            lap(1);
             const bool running = single && speculate ? plan.execute_begin(ctx0) : (plan.execute(ctx0), false);
+            lap(2);
             if (running && next_builder && n_past + 2 <= context_size) {
                 pre_.b = build_into(cur_ ^ 1, 1, next_builder(n_past + 1));
                 pre_.slot = cur_ ^ 1;
@@ -156,7 +168,9 @@ class InferenceSession {
                 pre_.model_key = model_key;
                 pre_.valid = true;
             }
+            lap(3);
             if (single && speculate) GraphExecutionPlan::execute_end();
+            lap(4);
         }
         last_n_nodes = built.gf.raw()->n_nodes;
         last_n_leafs = built.gf.raw()->n_leafs;
@@ -733,6 +747,7 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
         fprintf(stderr, "llm_infer_next_token: InferenceError::ContextFull\n");
         abort();
     }
+    const double t0 = llm::InferenceSession::now_ns();
     const std::vector<float> &l = s->s->last_logits;
     size_t best = 0;
     for (size_t i = 1; i < l.size(); i++)
@@ -740,8 +755,17 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
     const llm::TokenId next = (llm::TokenId)best;
     s->s->tokens.push_back(next);
     llm::OutputRequest req;
+    const double t1 = llm::InferenceSession::now_ns();
     m->llama->evaluate(*s->s, std::vector<llm::TokenId>{next}, req);
+    llm::InferenceSession::host_ns[5] += t1 - t0;                                // argmax
+    llm::InferenceSession::host_ns[6] += llm::InferenceSession::now_ns() - t1;  // evaluate, all of it
     return next;
+}
+// Accumulated host nanoseconds per phase (see InferenceSession::host_ns; [5] greedy argmax, [6] evaluate as a whole);
+// reset != 0 clears the accumulators after the read.
+void llm_host_timing(double *out8, int reset) {
+    for (int i = 0; i < 8; i++) out8[i] = llm::InferenceSession::host_ns[i];
+    if (reset) for (int i = 0; i < 8; i++) llm::InferenceSession::host_ns[i] = 0;
 }
 int llm_session_rewind(llm_session *s, int num) {
     if ((size_t)num >= s->s->n_past) return -1;  // RewindError::NotEnoughTokens

@@ -87,6 +87,10 @@ GGML_API void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *token
 GGML_API int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s);
 /* InferenceSession::rewind (inference_session.rs:352-378) */
 GGML_API int llm_session_rewind(llm_session *s, int num);
+/* host nanoseconds per phase of the decode loop, accumulated: [0] adopt/build graph, [1] token write + plan,
+ * [2] compute begin (match + enqueue), [3] speculative build of the next graph, [4] compute end (wait + copy),
+ * [5] greedy argmax, [6] evaluate as a whole. */
+GGML_API void llm_host_timing(double *out8, int reset);
 GGML_API const float *llm_session_last_logits(const llm_session *s);
 GGML_API int llm_session_n_past(const llm_session *s);
 GGML_API int llm_model_n_vocab(const llm_model *m);

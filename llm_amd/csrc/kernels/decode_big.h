@@ -108,8 +108,7 @@ struct BigX<XSRC_NORM> {
 // registers -> LDS as padded planar Q8 (nbp = nbl*64 blocks; blocks >= nb are zero so tail steps contribute 0)
 template <bool F16_D, int XSRC>
 __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int64_t nb, int64_t nbp, int tid,
-                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part,
-                                            long long *tsx = nullptr) {
+                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part) {
     const DecMmvqArgs &d = a.d;
     (void)s_part;
     for (int64_t i = nb + tid; i < nbp; i += BIG_T) {
@@ -151,13 +150,8 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
             }
             ss = wave_sum_f64(ss);
             if ((tid & 63) == 0) s_part[tid >> 6] = ss;
-            if (tsx) {
-                asm volatile("; x landed, summed %0" ::"v"((float)ss));
-                tsx[0] = big_now();
-            }
         }
         __syncthreads();
-        if (tsx) tsx[1] = big_now();
         if (stager) {
             double tot = 0.0;
 #pragma unroll
@@ -328,12 +322,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
             s_rope[2 * kk + 1] = rope_pre[1];
         }
     }
-#ifdef BIG_TS_STAGE
-    long long tsx[2] = {0, 0};
-    big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, s_lo, s_hi, s_d, s_sum, s_part, ba.ts ? tsx : nullptr);
-#else
     big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, s_lo, s_hi, s_d, s_sum, s_part);
-#endif
     const long long t_staged = ba.ts ? big_now() : 0;
     // ---- 2b. the rest of the ring
 #pragma unroll
@@ -427,9 +416,6 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
         if (q > 0 && blockIdx.x % q == 0 && (int)blockIdx.x / q < ba.ts_wgs) {
             long long *o = ba.ts + ((int)blockIdx.x / q) * 8;
             o[0] = t_entry; o[1] = t_issued; o[2] = t_staged; o[3] = t_barrier; o[4] = t_first; o[5] = big_now();
-#ifdef BIG_TS_STAGE
-            if (XSRC == XSRC_NORM) { o[3] = tsx[0]; o[4] = tsx[1]; }  // x landed + summed; first barrier passed
-#endif
             o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = blockIdx.x;
         }
     }

@@ -57,6 +57,8 @@ def _lib():
         L.llm_feed_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.llm_infer_next_token_greedy.restype = C.c_int32
         L.llm_infer_next_token_greedy.argtypes = [C.c_void_p, C.c_void_p]
+        L.llm_host_timing.restype = None
+        L.llm_host_timing.argtypes = [C.POINTER(C.c_double), C.c_int]
         L.llm_session_rewind.restype = C.c_int
         L.llm_session_rewind.argtypes = [C.c_void_p, C.c_int]
         L.llm_session_last_logits.restype = C.POINTER(C.c_float)
@@ -203,6 +205,13 @@ class Session:
 
     def infer_next_token(self):
         return int(_lib().llm_infer_next_token_greedy(self.model.ptr, self.ptr))
+
+    @staticmethod
+    def host_timing(reset=False):
+        """Accumulated host ns per phase of the decode loop (llm_host_timing)."""
+        a = (C.c_double * 8)()
+        _lib().llm_host_timing(a, 1 if reset else 0)
+        return list(a)
 
     def rewind(self, num):
         return _lib().llm_session_rewind(self.ptr, num)
