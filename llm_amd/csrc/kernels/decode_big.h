@@ -44,6 +44,10 @@ __device__ __forceinline__ constexpr int big_pf(int NR) {
                     // of 2.3) but streams slower with half the waves (w1|w3 10.3 us vs 9.2, lm_head 18.6 vs 12.7): 600 vs 612 tok/s
 #endif
 #define BIG_W (BIG_T / 64)
+// k_mmvq_big itself runs with any multiple of 64 threads up to BIG_T (blockDim.x): the launcher picks the number of
+// waves per workgroup that deals the launch's units most evenly (launch_big).  12 waves x 256 workgroups give every
+// wave exactly 2 of the 6144 row pairs of a 7B wq|wk|wv; with 16 waves half of them get 2 and half 1, and the
+// launch lasts as long as the workgroups with the 2s.
 
 struct BigArgs {
     DecMmvqArgs d;
@@ -64,8 +68,8 @@ struct BigX<XSRC_Q8> {
     i32x4 lo, hi;
     float d;
     int sum;
-    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid) {
-        const int64_t i = tid < nb ? tid : 0;  // nb <= 1024 (checked by the launcher)
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
+        const int64_t i = tid < nb ? tid : 0;  // nb <= T (checked by the launcher)
         lo = a.d.x.lo[i];
         hi = a.d.x.hi[i];
         d = a.d.x.d[i];
@@ -74,13 +78,13 @@ struct BigX<XSRC_Q8> {
 };
 template <>
 struct BigX<XSRC_F32> {
-    static constexpr int MAXIT = 6;  // rows up to 24576 wide
+    static constexpr int MAXIT = 6;  // rows up to 24 * T wide (24576 at 1024 threads; checked by the launcher)
     f32x4 v[MAXIT];
-    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid) {
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
         const int64_t n4 = nb * 8;
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
-            const int64_t i4 = (int64_t)it * BIG_T + tid;
+            const int64_t i4 = (int64_t)it * T + tid;
             v[it] = ((const f32x4 *)a.d.xf)[i4 < n4 ? i4 : 0];
         }
     }
@@ -93,7 +97,7 @@ struct BigX<XSRC_NORM> {
     // number of (single-address) loads so that every wave's load queue has the same compile-time shape.
     static constexpr int NT = 512, MAXIT = 4;  // rows up to 8192 wide
     f32x4 v[MAXIT], w[MAXIT];
-    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid) {
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
         const int64_t n4 = nb * 8;
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
@@ -107,11 +111,11 @@ struct BigX<XSRC_NORM> {
 
 // registers -> LDS as padded planar Q8 (nbp = nbl*64 blocks; blocks >= nb are zero so tail steps contribute 0)
 template <bool F16_D, int XSRC>
-__device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int64_t nb, int64_t nbp, int tid,
+__device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int64_t nb, int64_t nbp, int tid, int T,
                                             i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part) {
     const DecMmvqArgs &d = a.d;
     (void)s_part;
-    for (int64_t i = nb + tid; i < nbp; i += BIG_T) {
+    for (int64_t i = nb + tid; i < nbp; i += T) {
         s_lo[i] = i32x4{0, 0, 0, 0};
         s_hi[i] = i32x4{0, 0, 0, 0};
         s_d[i] = 0.0f;
@@ -128,8 +132,8 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
     } else if constexpr (XSRC == XSRC_F32) {
 #pragma unroll
         for (int it = 0; it < BigX<XSRC_F32>::MAXIT; it++) {
-            const int64_t i4 = (int64_t)it * BIG_T + tid;
-            if ((int64_t)it * BIG_T >= n4) break;  // uniform
+            const int64_t i4 = (int64_t)it * T + tid;
+            if ((int64_t)it * T >= n4) break;  // uniform
             const f32x4 v = i4 < n4 ? xr.v[it] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             quant4_to_lds<F16_D>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
         }
@@ -196,6 +200,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     float *s_d = (float *)(s_hi + nbp);
     int *s_sum = (int *)(s_d + nbp);
     const int tid = threadIdx.x, lane = tid & 63;
+    const int T = (int)blockDim.x, W = T >> 6;  // waves per workgroup: chosen per launch (launch_big)
     // wave-uniform values must be uniform FOR THE COMPILER too (scalar registers, scalar selects of the matrix
     // pointers): a kernarg array indexed by a "divergent" segment id is fetched with vector loads, and waiting for
     // those drains the whole in-order load queue at every step
@@ -206,12 +211,12 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     int n_past = 0;
     if constexpr (EPI == EPI_QKV) n_past = a.prm->n_past;
     BigX<XSRC> xr;
-    xr.load(ba, nb, tid);
+    xr.load(ba, nb, tid, T);
     // EPI_QKV: the last two waves fetch the token's RoPE table (k_rope_table); every wave issues the load so that all
     // load queues keep one compile-time shape
     f32x2 rope_pre = {0.0f, 0.0f};
     if constexpr (EPI == EPI_QKV) {
-        const int kk = tid - (BIG_T - 128);
+        const int kk = tid - (T - 128);
         rope_pre = ((const f32x2 *)ba.rope)[(kk >= 0 && kk < (a.D >> 1)) ? kk : 0];
     }
 
@@ -219,7 +224,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     // contiguous window of G*16 units of the matrix.  Lane i of the wave owns unit i's epilogue.
     const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0, M2 = EPI == EPI_QKV ? (int)a.w[2].M : 0;
     const int Utot = (M0 + M1 + M2) / RU;
-    const int u_first = (int)blockIdx.x * BIG_W + wave, u_stride = (int)gridDim.x * BIG_W;
+    const int u_first = (int)blockIdx.x * W + wave, u_stride = (int)gridDim.x * W;
     const int nu = u_first < Utot ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
     const int S = nu * nbl;
     // EPI_ADD: lane i preloads the residual of unit i (a load issued in the epilogue would drain the queue)
@@ -316,13 +321,13 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
 
     // ---- 3. norm / re-quantization of x into LDS; meanwhile the last two waves (not stagers) park the RoPE table
     if constexpr (EPI == EPI_QKV) {
-        if (tid >= BIG_T - 128 && tid - (BIG_T - 128) < (a.D >> 1)) {
-            const int kk = tid - (BIG_T - 128);
+        if (tid >= T - 128 && tid - (T - 128) < (a.D >> 1)) {
+            const int kk = tid - (T - 128);
             s_rope[2 * kk] = rope_pre[0];
             s_rope[2 * kk + 1] = rope_pre[1];
         }
     }
-    big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, s_lo, s_hi, s_d, s_sum, s_part);
+    big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, T, s_lo, s_hi, s_d, s_sum, s_part);
     const long long t_staged = ba.ts ? big_now() : 0;
     // ---- 2b. the rest of the ring
 #pragma unroll
