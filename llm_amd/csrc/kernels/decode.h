@@ -29,12 +29,12 @@ struct DecParams {
 // multiplies + sincos on two waves held up the whole workgroup's first barrier by ~2.5 us per layer).
 __global__ void __launch_bounds__(128) k_rope_table(const DecParams *__restrict__ prm, float theta_scale, float freq_scale,
                                                     int half_d, float *__restrict__ out) {
-    const int kk = threadIdx.x;
+    const int kk = threadIdx.x, c = blockIdx.x;  // block c: token c of a prompt chunk (position n_past + c), 128 floats each
     if (kk >= half_d) return;
-    float theta = freq_scale * (float)prm->n_past;
+    float theta = freq_scale * (float)(prm->n_past + c);
     for (int t = 0; t < kk; t++) theta *= theta_scale;
-    out[2 * kk] = cosf(theta);
-    out[2 * kk + 1] = sinf(theta);
+    out[c * 128 + 2 * kk] = cosf(theta);
+    out[c * 128 + 2 * kk + 1] = sinf(theta);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ struct Big8Args {
     DecMmvqArgs d;     // d.x: Q8 rows [ncols][nb] (planar lo / hi / d / sum), d.dst / d.res: row 0
     int ncols;         // 2..8 (1 works too)
     int64_t ldd, ldr;  // floats between consecutive rows of dst / res (and of the Q output for EPI_QKV)
+    const float *rope; // EPI_QKV: (cos, sin) tables of the chunk's positions, 128 floats per token (k_rope_table)
 };
 
 template <int QT, int EPI>
@@ -33,28 +34,35 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big8(const Big8Args ba) {
     int *s_sum = (int *)(s_d + (size_t)NC * nbp);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = (int)blockDim.x, W = T >> 6;  // waves per workgroup: chosen per launch (launch_big8), >= 8
 
     // ---- 1. activation loads first (see decode_big.h): up to 4 blocks per thread
     int n_past = 0;
     if constexpr (EPI == EPI_QKV) n_past = a.prm->n_past;
-    constexpr int MAXB = 4;  // ncols * nb <= 4 * BIG_T blocks (checked by the matcher)
+    constexpr int MAXB = 4;  // ncols * nb <= 4 * T blocks (checked by the launcher)
     i32x4 xl[MAXB], xh[MAXB];
     float xdv[MAXB];
     int xsv[MAXB];
     const int nx = ncols * nb;  // the Q8 rows are contiguous: block index = c * nb + b
 #pragma unroll
     for (int u = 0; u < MAXB; u++) {
-        const int i = u * BIG_T + tid;
+        const int i = u * T + tid;
         const int ic = i < nx ? i : 0;
         xl[u] = a.x.lo[ic];
         xh[u] = a.x.hi[ic];
         xdv[u] = a.x.d[ic];
         xsv[u] = a.x.sum[ic];
     }
+    // EPI_QKV: the last 512 threads fetch the RoPE tables of the chunk's positions (8 columns x 64 pairs)
+    f32x2 rope_pre = {0.0f, 0.0f};
+    if constexpr (EPI == EPI_QKV) {
+        const int e = tid - (T - 512), c = e >> 6, kk = e & 63;
+        rope_pre = ((const f32x2 *)ba.rope)[(e >= 0 && c < ncols && kk < (a.D >> 1)) ? c * 64 + kk : 0];
+    }
 
     const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0, M2 = EPI == EPI_QKV ? (int)a.w[2].M : 0;
     const int Utot = (M0 + M1 + M2) / RU;
-    const int u_first = (int)blockIdx.x * BIG_W + wave, u_stride = (int)gridDim.x * BIG_W;
+    const int u_first = (int)blockIdx.x * W + wave, u_stride = (int)gridDim.x * W;
     const int nu = u_first < Utot ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
     const int S = nu * nbl;
     // EPI_ADD: lane i preloads the residuals of unit i, one per column
@@ -128,19 +136,17 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big8(const Big8Args ba) {
         advance(k);
     }
 
-    // ---- 3. activations -> LDS (zero padding up to nbp per column); RoPE table of the chunk's positions
+    // ---- 3. activations -> LDS (zero padding up to nbp per column); RoPE tables of the chunk's positions
     if constexpr (EPI == EPI_QKV) {
-        if (tid >= BIG_T - 512) {
-            const int e = tid - (BIG_T - 512), c = e >> 6, kk = e & 63;
+        if (tid >= T - 512) {
+            const int e = tid - (T - 512), c = e >> 6, kk = e & 63;
             if (c < ncols && kk < (a.D >> 1)) {
-                float theta = a.freq_scale * (float)(n_past + c);
-                for (int t = 0; t < kk; t++) theta *= a.theta_scale;
-                s_rope[(c * 64 + kk) * 2] = cosf(theta);
-                s_rope[(c * 64 + kk) * 2 + 1] = sinf(theta);
+                s_rope[(c * 64 + kk) * 2] = rope_pre[0];
+                s_rope[(c * 64 + kk) * 2 + 1] = rope_pre[1];
             }
         }
     }
-    for (int i = tid; i < NC * nbp; i += BIG_T) {
+    for (int i = tid; i < NC * nbp; i += T) {
         const int c = i / nbp, b = i - c * nbp;
         if (b >= nb || c >= ncols) {
             s_lo[i] = i32x4{0, 0, 0, 0};
@@ -151,7 +157,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big8(const Big8Args ba) {
     }
 #pragma unroll
     for (int u = 0; u < MAXB; u++) {
-        const int i = u * BIG_T + tid;
+        const int i = u * T + tid;
         if (i < nx) {
             const int c = i / nb, b = i - c * nb;
             s_lo[c * nbp + b] = xl[u];
