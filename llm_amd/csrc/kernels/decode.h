@@ -423,7 +423,7 @@ __device__ __forceinline__ void prefetch_slice(const PrefetchArgs &a, int part, 
 //   p   = softmax(s·scale) with ggml's f16-rounded exp, then rounded to f16 (src1 of the V matmul)
 //   o_d = Σ_t V[d][t]·p_t ; the head's D outputs are re-quantized to Q8 blocks for the wo mat-vec and
 //   optionally written as f32 (merge-heads layout [E]).
-// K: [C][Egqa] f16 (per layer), V: [Egqa][C] f16 (per layer).  Dynamic LDS: (C + D) floats.
+// K: [C][Egqa] f16 (per layer), V: [Egqa][C] f16 (per layer).  Dynamic LDS: (C + D) floats + C halves.
 //
 // At short context the kernel is a pure latency chain (a few tens of KB per head), so its shape is dictated by
 // round trips and instruction issue, not bandwidth (in-kernel timeline at 135 positions: position -> K/V loads
@@ -451,8 +451,9 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     }
     const long long t_entry = ts ? (long long)wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_s = (float *)smem;  // C scores / probabilities
+    float *s_s = (float *)smem;  // C scores
     float *s_o = s_s + C;        // D outputs
+    _Float16 *s_p = (_Float16 *)(s_o + D);  // C probabilities as f16 (src1 of the V matmul); C % 8 == 0
     __shared__ float s_red[16];
     __shared__ double s_redd[16];
     const int h = blockIdx.x, hk = h / n_rep;
@@ -489,11 +490,11 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
         q0 = *(const f32x4 *)(qh + d0);
         q1 = *(const f32x4 *)(qh + d0 + 4);
     }
-    float qf[8];
+    f16x2 qh2[4];  // ggml rounds src1 (Q) to f16; the products below are exact in f32 (v_dot2_f32_f16)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        qf[j] = round_f16(q0[j]);  // ggml rounds src1 (Q) to f16
-        qf[4 + j] = round_f16(q1[j]);
+    for (int j = 0; j < 2; j++) {
+        qh2[j] = f16x2{(_Float16)q0[2 * j], (_Float16)q0[2 * j + 1]};
+        qh2[2 + j] = f16x2{(_Float16)q1[2 * j], (_Float16)q1[2 * j + 1]};
     }
     const int T = n_past + 1;
     const int T8 = (T + 7) & ~7;
@@ -515,7 +516,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
             const int t = t0 + 64 * u;
             float s = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; j++) s += (float)kv[u][j] * qf[j];
+            for (int j = 0; j < 4; j++) s = __builtin_amdgcn_fdot2(f16x2{kv[u][2 * j], kv[u][2 * j + 1]}, qh2[j], s, false);
             s = g16_sum_f32(s);
             if (gl == 0 && t < T) s_s[t] = s * scale;
         }
@@ -545,7 +546,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     for (int i = 0; i < 16; i++) tot += s_redd[i];
     const float inv = (float)(1.0 / tot);
     for (int t = tid; t < T8; t += 1024)
-        s_s[t] = t < T ? round_f16(s_s[t] * inv) : 0.0f;  // probabilities as f16 (src1 of V·P); padding = 0
+        s_p[t] = t < T ? (_Float16)(s_s[t] * inv) : (_Float16)0.0f;  // probabilities as f16 (src1 of V·P); padding = 0
     __syncthreads();
     const long long t_softmax = ts ? (long long)wall_clock64() : 0;
     // ---- V·P ----
@@ -564,15 +565,10 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
             for (int u = 0; u < 4; u++) {
                 const int pos = p0 + 64 * u + pj;
                 if (pos < T8) {  // 8-position chunks past the context are never touched (their V is not ours)
-                    const f32x4 pa = *(const f32x4 *)(s_s + pos), pb = *(const f32x4 *)(s_s + pos + 4);
-                    acc += (float)vv[u][0] * pa[0];
-                    acc += (float)vv[u][1] * pa[1];
-                    acc += (float)vv[u][2] * pa[2];
-                    acc += (float)vv[u][3] * pa[3];
-                    acc += (float)vv[u][4] * pb[0];
-                    acc += (float)vv[u][5] * pb[1];
-                    acc += (float)vv[u][6] * pb[2];
-                    acc += (float)vv[u][7] * pb[3];
+                    const f16x8 pp = *(const f16x8 *)(s_p + pos);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc = __builtin_amdgcn_fdot2(f16x2{vv[u][2 * j], vv[u][2 * j + 1]}, f16x2{pp[2 * j], pp[2 * j + 1]}, acc, false);
                 }
             }
         }

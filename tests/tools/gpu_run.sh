@@ -2,16 +2,10 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_llama_gpu.py tests/test_fullsize_gpu.py tests/test_entry_gpu.py -q -x 2>&1 | tail -3
-for w in 16 0; do
-GGML_HIP_BIG_WAVES=$w timeout 300 python - <<'PY'
-import time, numpy as np, os
-from llm_amd import ggml, llama, synth
-hp, w = synth.make_llama_fast(synth.LLAMA_7B, ggml.TYPE_Q4_0)
-model = llama.Llama(hp, w, context_size=2048)
-s = model.start_session(n_batch=8)
-toks = (np.arange(512, dtype=np.int32) * 7 + 5) % hp["n_vocab"]
-s.feed_prompt(toks[:64]); ggml.lib().ggml_hip_synchronize()
-t0 = time.perf_counter(); s.feed_prompt(toks[64:448]); ggml.lib().ggml_hip_synchronize(); dt = time.perf_counter() - t0
-print("waves", os.environ.get("GGML_HIP_BIG_WAVES"), "prompt feed n_batch=8: %.0f tok/s (%.2f ms per 8-token chunk)" % (384 / dt, dt / 48 * 1e3))
+timeout 300 python bench.py --no-cpu-baseline --steps 128 > gpurun_out/bench_decode.json 2>gpurun_out/bench.err || tail -3 gpurun_out/bench.err
+python - <<PY
+import json
+d=json.load(open("gpurun_out/bench_decode.json"))
+print(d["value"], "tok/s", d["ms_per_step"], "ms; device", d["config"]["host_split_per_token"]["device_wait_ms"])
 PY
-done
+timeout 300 python tests/tools/timeline.py 7b > gpurun_out/timeline.txt 2>&1; grep "^attention\|token span" gpurun_out/timeline.txt
