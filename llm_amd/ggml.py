@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libggml_hip.so")
+LIB_PATH = os.environ.get("GGML_HIP_LIB") or os.path.join(_HERE, "libggml_hip.so")  # GGML_HIP_LIB: an experiment build
 
 # enums (include/ggml_hip.h)
 TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q4_1, TYPE_Q5_0, TYPE_Q5_1, TYPE_Q8_0, TYPE_Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9

@@ -1,11 +1,12 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -2
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 600 python bench.py > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "bench rc=$?"; cut -c1-200 gpurun_out/bench_decode.json
-timeout 600 python bench.py --mode prefill --steps 5 --warmup 2 > gpurun_out/bench_prefill.json 2>/dev/null; cut -c1-200 gpurun_out/bench_prefill.json
-rm -rf /tmp/prof_dec
-GGML_HIP_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_dec -o bench -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_dec.log 2>&1; echo "prof rc=$?"
-grep '"metric"' gpurun_out/prof_dec.log > gpurun_out/prof_dec_bench_line.json
-python tests/tools/kstats.py /tmp/prof_dec > gpurun_out/prof_dec_stats.txt; head -8 gpurun_out/prof_dec_stats.txt
+for lib in libggml_hip.so libggml_hip_xf9.so libggml_hip_xf31.so; do
+  GGML_HIP_LIB=$GRAFT_REPO_ROOT/llm_amd/$lib timeout 300 python bench.py --no-cpu-baseline --steps 128 > gpurun_out/bench_$lib.json 2>gpurun_out/bench.err || tail -3 gpurun_out/bench.err
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/bench_$lib.json")); r=d["roofline"]["per_kind"]
+print("$lib:", d["value"], "tok/s; device", d["config"]["host_split_per_token"]["device_wait_ms"], {k:(v["us_per_launch_incl_boundary"], v["us_in_kernel"]) for k,v in r.items()})
+PY
+done
+GGML_HIP_LIB=$GRAFT_REPO_ROOT/llm_amd/libggml_hip_xf31.so timeout 300 python tests/tools/timeline.py 7b > gpurun_out/timeline.txt 2>&1; grep "^avg\|token span" gpurun_out/timeline.txt
