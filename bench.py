@@ -121,6 +121,14 @@ def run_single(args):
     elapsed = time.perf_counter() - t0
     tok_s = args.steps / elapsed
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
+    # the same greedy decode with the sampler on the device: ids identical to the loop above
+    # (tests/test_llama_gpu.py), no logits read-back / host sync per token.  Reported beside the metric, not as it.
+    sess.infer_next_token()
+    L.ggml_hip_synchronize()
+    td = time.perf_counter()
+    sess.infer_tokens_device(args.steps)
+    L.ggml_hip_synchronize()
+    dev_s = time.perf_counter() - td
     h1 = {k: stat(k) - v for k, v in h0.items()}
     host_split = {"plan_tokens": h1["plan_tokens"],
                   "graph_build_and_sampling_ms": round((elapsed * 1e9 - h1["ns_compute"]) / args.steps / 1e6, 4),
@@ -203,6 +211,9 @@ def run_single(args):
                                   f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",
                       "n_past_at_start": args.prompt + args.warmup, "parallelism": "1 GPU",
                       "weights_in_hbm_before_timing": True, "host_split_per_token": host_split,
+                      "device_sampling": {"tokens_per_s": round(args.steps / dev_s, 2), "ms_per_token": round(dev_s / args.steps * 1e3, 4),
+                                          "note": "same greedy tokens via llm_infer_tokens_greedy_device (argmax kernel feeds the next "
+                                                  "replay; logits stay in HBM until the last token)"},
                       "prompt_feed": {"tokens": int(args.prompt), "n_batch": 8, "ms": round(prompt_s * 1e3, 1),
                                       "tokens_per_s": round(args.prompt / prompt_s, 1),
                                       "note": "first call of the process: includes hipGraph capture of the plans"}, "prep": {k: round(v, 2) for k, v in prep.items()}},

@@ -497,6 +497,14 @@ GGML_API int64_t ggml_hip_get_stat(const char *key);
  * host-visible results (CPU-backend nodes).  No result may be read, and no other graph computed, in between. */
 GGML_API int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph);
 GGML_API void ggml_hip_graph_compute_end(void);
+/* Greedy sampling on the device (the step after the path): decodes n more tokens — each the first
+ * argmax of the previous logits, what `infer_next_token` with a greedy sampler yields (inference_session.rs:381-424,
+ * samplers.rs:289-306) — without the per-token logits read-back and host sync.  `last` = the cgraph of the caller's
+ * most recent ggml_graph_compute, which must have been a single-token LLaMA evaluation executed by the fused plan.
+ * out_tokens[n] receives the ids; last_logits (V floats, may be NULL) the logits after the n-th token.  The K/V
+ * memory advances by n positions; the caller adds n to its n_past.  Returns 0, or -1 if the precondition does not
+ * hold (nothing was executed: decode token by token instead). */
+GGML_API int ggml_hip_decode_greedy_chain(struct ggml_cgraph *last, int n, int32_t *out_tokens, float *last_logits);
 /* In-kernel timeline of the decode mat-vec launches (ggml_hip_set_option("timeline", 1), eager or graph mode):
  * records of 8 x int64 {entry, loads issued, x staged, barrier passed, first weights landed, exit (100 MHz
  * wall clock ticks), steps of wave 0, workgroup id}; 4 (or "timeline" = n) sampled workgroups per launch, launch order.

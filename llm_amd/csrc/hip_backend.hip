@@ -143,6 +143,8 @@ struct Backend {
     int opt_graph = 1;      // replay the plan from a captured hipGraph
     int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
     uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0;
+    void *chain_plan = nullptr;            // the plan a greedy chain may continue (set by its last single-token run)
+    ggml_cgraph *chain_graph = nullptr;    // ... and the cgraph that run executed
     bool pending_wait = false;  // a decode plan was launched by graph_compute_begin and not yet waited for
     uint64_t ns_match = 0, ns_launch = 0, ns_wait = 0, ns_compute = 0;  // host-side time split of plan tokens
     size_t dead_shadow_bytes = 0;
@@ -1201,6 +1203,7 @@ void invalidate_xf16_if_overwritten_impl(const ggml_tensor *n) {
     }
 }
 
+void finish_pending();
 #include "llama_plan.inc"
 
 void finish_pending() {
@@ -1762,6 +1765,11 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     if (launches_per_replay) *launches_per_replay = st.launches[kclass];
     if (algo_bytes_per_replay) *algo_bytes_per_replay = st.bytes[kclass];
     return 0;
+}
+
+int ggml_hip_decode_greedy_chain(struct ggml_cgraph *last, int n, int32_t *out_tokens, float *last_logits) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    return decode_greedy_chain(last, n, out_tokens, last_logits);
 }
 
 int64_t ggml_hip_get_stat(const char *key) {

@@ -180,6 +180,15 @@ class InferenceSession {
         return GraphOutputs{built.out.result.share(), built.out.embedding_result.share()};
     }
 
+    // n tokens were decoded on the device behind this session's back (ggml_hip_decode_greedy_chain): the K/V memory
+    // holds them; bring the bookkeeping of inference_session.rs (n_past, tokens) in line.
+    void advance_device_chain(const TokenId *toks, size_t n) {
+        tokens.insert(tokens.end(), toks, toks + n);
+        n_past += n;
+        pre_.valid = false;  // the speculatively built graph assumed n_past + 1
+        last_graph = nullptr;
+    }
+
     void make_stage_buffers(size_t n_embd, bool in, bool out) {
         stage_ctx_ = std::make_shared<Context>(Context::new_with_allocate(2 * (n_embd * config.n_batch * 4 + 1024)));
         if (in) {
@@ -760,6 +769,29 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
     llm::InferenceSession::host_ns[5] += t1 - t0;                                // argmax
     llm::InferenceSession::host_ns[6] += llm::InferenceSession::now_ns() - t1;  // evaluate, all of it
     return next;
+}
+// n greedy tokens with the sampler on the device (ggml_hip_decode_greedy_chain): the same ids and the
+// same final logits as n calls of llm_infer_next_token_greedy, without a logits read-back and host sync per token.
+// Falls back to that loop when the backend cannot chain (last evaluation not a single-token fused-plan run, layer
+// split stage, ...).  Returns the number of tokens written to out (n).
+int llm_infer_tokens_greedy_device(llm_model *m, llm_session *s, int n, int32_t *out) {
+    if (n < 1) return 0;
+    if (s->s->n_past + (size_t)n >= m->llama->params.context_size) {
+        fprintf(stderr, "llm_infer_tokens_greedy_device: InferenceError::ContextFull\n");
+        abort();
+    }
+    int done = 0;
+    // the chain continues a single-token fused-plan run; after a prompt chunk (or a fresh session) one normal step arms it
+    for (int attempt = 0; attempt < 2 && done < n; attempt++) {
+        if (s->s->last_graph &&
+            ggml_hip_decode_greedy_chain(s->s->last_graph, n - done, out + done, s->s->last_logits.data()) == 0) {
+            s->s->advance_device_chain((const llm::TokenId *)(out + done), (size_t)(n - done));
+            return n;
+        }
+        out[done++] = llm_infer_next_token_greedy(m, s);
+    }
+    for (; done < n; done++) out[done] = llm_infer_next_token_greedy(m, s);
+    return n;
 }
 // Accumulated host nanoseconds per phase (see InferenceSession::host_ns; [5] greedy argmax, [6] evaluate as a whole);
 // reset != 0 clears the accumulators after the read.

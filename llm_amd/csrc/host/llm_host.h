@@ -86,6 +86,9 @@ GGML_API void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *token
 /* InferenceSession::infer_next_token with a greedy (argmax) sampler; returns the sampled token id */
 GGML_API int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s);
 /* InferenceSession::rewind (inference_session.rs:352-378) */
+/* n greedy tokens with the argmax on the device (ggml_hip_decode_greedy_chain): same ids and final logits as n calls
+ * of llm_infer_next_token_greedy, no per-token logits read-back; falls back to that loop when chaining is impossible */
+GGML_API int llm_infer_tokens_greedy_device(llm_model *m, llm_session *s, int n, int32_t *out);
 GGML_API int llm_session_rewind(llm_session *s, int num);
 /* host nanoseconds per phase of the decode loop, accumulated: [0] adopt/build graph, [1] token write + plan,
  * [2] compute begin (match + enqueue), [3] speculative build of the next graph, [4] compute end (wait + copy),

@@ -23,6 +23,52 @@ struct DecParams {
     int tokens[8];  // multi-token plan (2..8 tokens of a prompt chunk): ids of all tokens, tokens[0] == token
 };
 
+// Greedy sampling on the device: token = first index of the maximum logit — what a host loop
+// `if (l[i] > l[best]) best = i` returns — written straight into the decode parameters of the NEXT replay of the plan
+// (token id, position + 1) and into out[0], so that a chain of greedy tokens needs neither the 128 KB logits
+// read-back nor a host round trip per token.  One 1024-thread workgroup.
+__global__ void __launch_bounds__(1024) k_argmax_next(const float *__restrict__ logits, int V, DecParams *prm,
+                                                      int *__restrict__ out) {
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 1024) {  // increasing i: strict > keeps the first maximum of this thread's subsequence
+        const float v = logits[i];
+        if (v > bv || bi == 0x7fffffff) {
+            bv = v;
+            bi = i;
+        }
+    }
+    auto better = [](float v, int i, float bv_, int bi_) { return v > bv_ || (v == bv_ && i < bi_); };
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (better(ov, oi, bv, bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++)
+            if (better(s_v[w], s_i[w], bv, bi)) {
+                bv = s_v[w];
+                bi = s_i[w];
+            }
+        prm->token = bi;
+        prm->tokens[0] = bi;
+        prm->n_past = prm->n_past + 1;
+        out[0] = bi;
+    }
+}
+
 // (cos, sin) of the RoPE angle of pair kk of a head at this token's position, as ggml's rope computes them:
 // theta_kk = freq_scale*p * theta_scale^kk by repeated f32 multiplication (reference ggml.c rope, f32 branch).  One
 // launch per token; the wq|wk|wv mat-vec of every layer reads the table instead of re-deriving it (64 dependent

@@ -57,6 +57,8 @@ def _lib():
         L.llm_feed_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.llm_infer_next_token_greedy.restype = C.c_int32
         L.llm_infer_next_token_greedy.argtypes = [C.c_void_p, C.c_void_p]
+        L.llm_infer_tokens_greedy_device.restype = C.c_int
+        L.llm_infer_tokens_greedy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.llm_host_timing.restype = None
         L.llm_host_timing.argtypes = [C.POINTER(C.c_double), C.c_int]
         L.llm_session_rewind.restype = C.c_int
@@ -205,6 +207,12 @@ class Session:
 
     def infer_next_token(self):
         return int(_lib().llm_infer_next_token_greedy(self.model.ptr, self.ptr))
+
+    def infer_tokens_device(self, n):
+        """n greedy tokens sampled on the device (llm_infer_tokens_greedy_device); returns their ids."""
+        out = np.zeros(n, np.int32)
+        _lib().llm_infer_tokens_greedy_device(self.model.ptr, self.ptr, n, out.ctypes.data)
+        return out
 
     @staticmethod
     def host_timing(reset=False):

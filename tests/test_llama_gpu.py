@@ -268,6 +268,60 @@ def test_greedy_is_deterministic_and_matches_oracle_tokens(G, O):
     model.free()
 
 
+@pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
+def test_device_sampled_chain_equals_token_by_token_greedy(G, O, wtype):
+    """SURVEY 8f N3 (ggml_hip_decode_greedy_chain): n tokens with the argmax on the device are bit-identical to n
+    calls of infer_next_token (host argmax over the read-back logits): same ids, same final logits, same K/V, and the
+    session continues normally afterwards."""
+    hp, w, model = _mk(G, wtype, seed=7)
+    prompt = np.random.default_rng(5).integers(0, hp["n_vocab"], 11).astype(np.int32)
+    a = model.start_session(n_batch=8)
+    a.feed_prompt(prompt)
+    ref = [a.infer_next_token() for _ in range(20)]
+    ref_logits = a.last_logits()
+    b = model.start_session(n_batch=8)
+    b.feed_prompt(prompt)  # ends with a multi-token chunk: the first step is a normal one, the rest chains
+    t0 = _stat(G, "plan_tokens")
+    got = list(b.infer_tokens_device(12))
+    assert _stat(G, "plan_tokens") - t0 == 12
+    got += [b.infer_next_token()]          # a normal step in the middle
+    got += list(b.infer_tokens_device(7))  # and a chain armed by it
+    assert got == ref
+    assert np.array_equal(b.last_logits(), ref_logits)
+    ka, va = a.get_kv()
+    kb, vb = b.get_kv()
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    # the chain is not available to a later stage of a layer split / generic graphs: the call still returns the tokens
+    G.set_option("plan", 0)
+    c = model.start_session(n_batch=8)
+    c.feed_prompt(prompt)
+    assert list(c.infer_tokens_device(5)) == ref[:5]
+    G.set_option("plan", 1)
+    for s in (a, b, c):
+        s.free()
+    model.free()
+
+
+def test_device_argmax_takes_the_first_maximum(G, O):
+    """k_argmax_next = the host loop `if (l[i] > l[best]) best = i`: ties go to the lowest index.  Checked through the
+    chain on a model whose lm_head has duplicated rows (equal logits by construction)."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(synth.TINY, 2, seed=3)
+    row = hp["n_embd"] // 32 * 18  # bytes per Q4_0 row of lm_head
+    arr = w["output.weight"].copy().reshape(hp["n_vocab"], row)
+    arr[1::2] = arr[0::2]  # every odd row duplicates the even row before it: logits[2k+1] == logits[2k]
+    w = dict(w)
+    w["output.weight"] = arr.reshape(-1)
+    model = llama.Llama(hp, w, context_size=64)
+    s = model.start_session(n_batch=8)
+    s.feed_prompt(np.array([5, 9, 200], np.int32))
+    first = s.infer_next_token()
+    toks = s.infer_tokens_device(10)
+    assert first % 2 == 0 and all(int(t) % 2 == 0 for t in toks)
+    s.free()
+    model.free()
+
+
 def test_rewind_then_refeed_reproduces_logits(G, O):
     """binaries/llm-test/src/delete.rs:48-56: logits after rewind(1)+re-feed equal the originals."""
     hp, w, model = _mk(G, 2)
