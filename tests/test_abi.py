@@ -73,6 +73,19 @@ def test_product_quantizer_matches_oracle_bytes_and_hist(G, O, t):
     assert np.array_equal(h1, h2) and h1.sum() == x.size
 
 
+@pytest.mark.parametrize("t", [2, 7])
+def test_product_quantizer_large_tensor_threaded_equals_serial(G, O, t):
+    """Above 2^15 blocks ggml_quantize_q* cuts the tensor over threads: bytes and histogram must not
+    depend on that."""
+    x = (0.02 * np.random.default_rng(t).standard_normal((1100, 1024))).astype(np.float32)
+    out1, out2 = np.zeros(G.row_bytes(t, x.size), np.uint8), np.zeros(G.row_bytes(t, x.size), np.uint8)
+    h1, h2 = np.zeros(16, np.int64), np.zeros(16, np.int64)
+    fn = getattr(G.lib(), "ggml_quantize_" + G.TYPE_NAMES[t])
+    assert fn(x.ctypes.data, out1.ctypes.data, x.size, 1024, h1.ctypes.data) == out1.size
+    O.lib().orc_quantize(t, x.ctypes.data, out2.ctypes.data, x.size, 1024, h2.ctypes.data)
+    assert np.array_equal(out1, out2) and np.array_equal(h1, h2) and h1.sum() == x.size
+
+
 def test_fp16_product_matches_numpy(G):
     x = np.random.default_rng(0).standard_normal(4096).astype(np.float32) * 100
     out = np.zeros(x.size, np.uint16)
