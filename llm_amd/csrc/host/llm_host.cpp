@@ -836,6 +836,70 @@ size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbyt
     return nbytes;
 }
 
+// InferenceSession::get_snapshot / from_snapshot (inference_session.rs:590-646): npast, config, tokens, last_logits,
+// memory_k, memory_v.  The reference serialises the struct with serde/bincode; without a Rust toolchain the byte
+// format here is our own (little-endian header + the four payloads), the CONTENT is the reference's.  The K/V memory
+// lives on the device, so both directions go through the backend (ggml_hip_tensor_get / _set).
+namespace {
+struct SnapHeader {
+    char magic[8];  // "LLMSNAP1"
+    uint64_t npast, n_tokens, n_logits, k_bytes, v_bytes;
+    int32_t memory_k_type, memory_v_type, n_batch, n_threads;
+};
+}  // namespace
+size_t llm_session_snapshot(llm_session *s, void *buf, size_t cap) {
+    llm::InferenceSession &ss = *s->s;
+    SnapHeader h;
+    memcpy(h.magic, "LLMSNAP1", 8);
+    h.npast = ss.n_past;
+    h.n_tokens = ss.tokens.size();
+    h.n_logits = ss.last_logits.size();
+    h.k_bytes = ss.memory_k.nbytes();
+    h.v_bytes = ss.memory_v.nbytes();
+    h.memory_k_type = (int32_t)ss.config.memory_k_type;
+    h.memory_v_type = (int32_t)ss.config.memory_v_type;
+    h.n_batch = (int32_t)ss.config.n_batch;
+    h.n_threads = (int32_t)ss.config.n_threads;
+    const size_t need = sizeof(h) + h.n_tokens * 4 + h.n_logits * 4 + h.k_bytes + h.v_bytes;
+    if (!buf || cap < need) return need;
+    char *p = (char *)buf;
+    memcpy(p, &h, sizeof(h));
+    p += sizeof(h);
+    memcpy(p, ss.tokens.data(), h.n_tokens * 4);
+    p += h.n_tokens * 4;
+    memcpy(p, ss.last_logits.data(), h.n_logits * 4);
+    p += h.n_logits * 4;
+    ggml_hip_tensor_get(ss.memory_k.ptr(), p, 0, h.k_bytes);
+    p += h.k_bytes;
+    ggml_hip_tensor_get(ss.memory_v.ptr(), p, 0, h.v_bytes);
+    return need;
+}
+// NULL = SnapshotError (bad header, or MemorySizeMismatch: the model's session has other K/V sizes than the snapshot)
+llm_session *llm_session_from_snapshot(llm_model *m, const void *buf, size_t n) {
+    SnapHeader h;
+    if (!buf || n < sizeof(h)) return nullptr;
+    memcpy(&h, buf, sizeof(h));
+    if (memcmp(h.magic, "LLMSNAP1", 8) != 0) return nullptr;
+    if (n != sizeof(h) + h.n_tokens * 4 + h.n_logits * 4 + h.k_bytes + h.v_bytes) return nullptr;
+    llm_session_config cfg{h.memory_k_type, h.memory_v_type, h.n_batch, h.n_threads};
+    llm_session *s = llm_start_session(m, &cfg);
+    llm::InferenceSession &ss = *s->s;
+    if (ss.memory_k.nbytes() != h.k_bytes || ss.memory_v.nbytes() != h.v_bytes || ss.last_logits.size() != h.n_logits) {
+        llm_session_free(s);
+        return nullptr;  // SnapshotError::MemorySizeMismatch
+    }
+    const char *p = (const char *)buf + sizeof(h);
+    ss.tokens.assign((const llm::TokenId *)p, (const llm::TokenId *)p + h.n_tokens);
+    p += h.n_tokens * 4;
+    memcpy(ss.last_logits.data(), p, h.n_logits * 4);
+    p += h.n_logits * 4;
+    ggml_hip_tensor_set(ss.memory_k.ptr(), p, 0, h.k_bytes);
+    p += h.k_bytes;
+    ggml_hip_tensor_set(ss.memory_v.ptr(), p, 0, h.v_bytes);
+    ss.n_past = h.npast;
+    return s;
+}
+
 // test hook: device contents of a node of the last evaluated graph, by index (>= 0) or by the k-th node
 // carrying `name` (index < 0).  Returns the number of bytes the node holds, 0 if not found.
 size_t llm_session_read_node(const llm_session *s, int index, const char *name, int occurrence, void *dst,

@@ -105,6 +105,11 @@ GGML_API void llm_session_stage_buffers(llm_session *s, void **in_dev, void **ou
 /* raw K/V memory of a session (which: 0 = memory_k, 1 = memory_v; set: 0 = read into buf, 1 = write from buf);
  * buf == NULL returns the size.  The InferenceSnapshot payload (inference_session.rs:599-646). */
 GGML_API size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbytes);
+/* InferenceSession::get_snapshot / from_snapshot (inference_session.rs:590-646): npast, config, tokens, last_logits and
+ * the K/V memory (read from / written to the device).  snapshot: buf == NULL or cap too small returns the size needed.
+ * from_snapshot: NULL on a malformed buffer or SnapshotError::MemorySizeMismatch. */
+GGML_API size_t llm_session_snapshot(llm_session *s, void *buf, size_t cap);
+GGML_API llm_session *llm_session_from_snapshot(llm_model *m, const void *buf, size_t n);
 /* test hook: reads the device contents of a node of the last evaluated graph (by index, or k-th node named `name`) */
 GGML_API size_t llm_session_read_node(const llm_session *s, int index, const char *name, int occurrence, void *dst,
                                       size_t max_bytes);

@@ -57,6 +57,10 @@ def _lib():
         L.llm_feed_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.llm_infer_next_token_greedy.restype = C.c_int32
         L.llm_infer_next_token_greedy.argtypes = [C.c_void_p, C.c_void_p]
+        L.llm_session_snapshot.restype = C.c_size_t
+        L.llm_session_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.llm_session_from_snapshot.restype = C.c_void_p
+        L.llm_session_from_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.llm_infer_tokens_greedy_device.restype = C.c_int
         L.llm_infer_tokens_greedy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.llm_host_timing.restype = None
@@ -170,6 +174,16 @@ class Llama:
     def start_session(self, n_batch=8, kv_type=ggml.TYPE_F16):
         return Session(self, n_batch, kv_type)
 
+    def session_from_snapshot(self, blob):
+        """InferenceSession::from_snapshot; None on SnapshotError."""
+        blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+        ptr = _lib().llm_session_from_snapshot(self.ptr, blob.ctypes.data, blob.size)
+        if not ptr:
+            return None
+        s = Session.__new__(Session)
+        s.model, s.ptr = self, ptr
+        return s
+
     def free(self):
         if self.ptr:
             _lib().llm_model_free(self.ptr)
@@ -207,6 +221,13 @@ class Session:
 
     def infer_next_token(self):
         return int(_lib().llm_infer_next_token_greedy(self.model.ptr, self.ptr))
+
+    def snapshot(self):
+        """InferenceSession::get_snapshot as bytes (npast, config, tokens, last_logits, memory_k, memory_v)."""
+        n = _lib().llm_session_snapshot(self.ptr, None, 0)
+        buf = np.zeros(n, np.uint8)
+        _lib().llm_session_snapshot(self.ptr, buf.ctypes.data, n)
+        return buf.tobytes()
 
     def infer_tokens_device(self, n):
         """n greedy tokens sampled on the device (llm_infer_tokens_greedy_device); returns their ids."""

@@ -322,6 +322,44 @@ def test_device_argmax_takes_the_first_maximum(G, O):
     model.free()
 
 
+@pytest.mark.parametrize("kv", ["f16", "f32"])
+def test_snapshot_restores_a_session_bit_exactly(G, O, kv):
+    """InferenceSession::get_snapshot / from_snapshot (inference_session.rs:590-646) with the K/V memory on the device:
+    a session restored from a snapshot continues with the same tokens and logits as the original; a snapshot of a
+    different model shape is refused (SnapshotError::MemorySizeMismatch)."""
+    from llm_amd import llama, synth
+    hp, w, model = _mk(G, 2, seed=11)
+    kvt = G.TYPE_F16 if kv == "f16" else G.TYPE_F32
+    prompt = np.random.default_rng(2).integers(0, hp["n_vocab"], 13).astype(np.int32)
+    a = model.start_session(n_batch=8, kv_type=kvt)
+    a.feed_prompt(prompt)
+    head = [a.infer_next_token() for _ in range(5)]
+    blob = a.snapshot()
+    tail = [a.infer_next_token() for _ in range(9)]
+    b = model.session_from_snapshot(blob)
+    assert b is not None and b.n_past == len(prompt) + len(head)
+    c = model.session_from_snapshot(blob)
+    assert np.array_equal(b.last_logits(), c.last_logits())
+    c.free()
+    assert [b.infer_next_token() for _ in range(9)] == tail
+    assert np.array_equal(a.last_logits(), b.last_logits())
+    ka, va = a.get_kv()
+    kb, vb = b.get_kv()
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    # malformed / mismatching snapshots
+    assert model.session_from_snapshot(blob[:-1]) is None
+    assert model.session_from_snapshot(b"garbage0" + blob[8:]) is None
+    hp2 = dict(synth.TINY)
+    hp2["n_layer"] = 1
+    hp2, w2 = synth.make_llama(hp2, 2, seed=11)
+    other = llama.Llama(hp2, w2, context_size=64)
+    assert other.session_from_snapshot(blob) is None
+    other.free()
+    a.free()
+    b.free()
+    model.free()
+
+
 def test_rewind_then_refeed_reproduces_logits(G, O):
     """binaries/llm-test/src/delete.rs:48-56: logits after rewind(1)+re-feed equal the originals."""
     hp, w, model = _mk(G, 2)
