@@ -38,6 +38,7 @@
 #include "kernels/decode.h"
 #include "kernels/decode_big.h"
 #include "kernels/decode_big8.h"
+#include "kernels/decode_attn_split.h"
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -110,6 +111,7 @@ struct Backend {
     bool inited = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    int opt_attn_split = 1;  // long contexts: attention split over positions too (kernels/decode_attn_split.h)
     int opt_prefetch = 0;  // MB of w1|w3 (plus all of wo) that the idle CUs of the decode attention launch pull into the
                            // Infinity Cache (llama_plan.inc); 0 = off
     std::map<uintptr_t, Arena> arenas;          // by base
@@ -142,7 +144,7 @@ struct Backend {
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
     int opt_graph = 1;      // replay the plan from a captured hipGraph
     int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
-    uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0;
+    uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0, stat_split_tokens = 0;
     void *chain_plan = nullptr;            // the plan a greedy chain may continue (set by its last single-token run)
     ggml_cgraph *chain_graph = nullptr;    // ... and the cgraph that run executed
     bool pending_wait = false;  // a decode plan was launched by graph_compute_begin and not yet waited for
@@ -173,6 +175,7 @@ void ensure_init() {
     HIP_CHECK(hipSetDevice(g.device));
     HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (const char *v = getenv("GGML_HIP_PREFETCH")) g.opt_prefetch = atoi(v);
+    if (const char *v = getenv("GGML_HIP_ATTN_SPLIT")) g.opt_attn_split = atoi(v);
     if (const char *v = getenv("GGML_HIP_FUSE")) g.opt_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN")) g.opt_plan = atoi(v);
     if (const char *v = getenv("GGML_HIP_GRAPH")) g.opt_graph = atoi(v);
@@ -1685,6 +1688,10 @@ void ggml_hip_set_option(const char *key, int value) {
         }
         if (g.timeline) HIP_CHECK(hipMemsetAsync(g.timeline, 0, g.timeline_bytes, g.stream));
     }
+    else if (k == "attn_split") {
+        if (g.opt_attn_split != value) drop_all_plans();
+        g.opt_attn_split = value;
+    }
     else if (k == "prefetch") {
         if (g.opt_prefetch != value) drop_all_plans();
         g.opt_prefetch = value;
@@ -1775,6 +1782,7 @@ int ggml_hip_decode_greedy_chain(struct ggml_cgraph *last, int n, int32_t *out_t
 int64_t ggml_hip_get_stat(const char *key) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     const std::string k(key);
+    if (k == "attn_split_tokens") return (int64_t)g.stat_split_tokens;  // tokens whose attention ran split over positions
     if (k == "plan_tokens") return (int64_t)g.stat_plan_tokens;       // tokens executed by the fused decode plan
     if (k == "graph_replays") {
         int64_t n = 0;

@@ -360,6 +360,38 @@ def test_snapshot_restores_a_session_bit_exactly(G, O, kv):
     model.free()
 
 
+@pytest.mark.parametrize("wtype", [2, 7])
+def test_long_context_split_attention_matches_single_launch_and_oracle(G, O, wtype):
+    """From 512 positions on the decode plan splits every head's attention over positions (three launches,
+    kernels/decode_attn_split.h).  Same rounding points as the single launch (row max, f16 exp, exact f64 sum, f16
+    probabilities); only the f32 association of the V.P sum differs."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(synth.TINY, wtype, seed=7)
+    model = llama.Llama(hp, w, context_size=1024)
+    toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 790).astype(np.int32)
+    nxt = np.random.default_rng(10).integers(0, hp["n_vocab"], 6).astype(np.int32)
+    outs = {}
+    for split in (1, 0):
+        G.set_option("attn_split", split)
+        s = model.start_session(n_batch=8)
+        s.feed_prompt(toks)
+        before = _stat(G, "attn_split_tokens")
+        outs[split] = [s.evaluate(np.array([t], np.int32))[-1].copy() for t in nxt]
+        assert _stat(G, "attn_split_tokens") - before == (len(nxt) if split else 0)
+        s.free()
+    G.set_option("attn_split", 1)
+    orc = O.Llama(hp, w, 1024)
+    orc.evaluate(toks, mode=0)
+    worst_ab = worst_o = 0.0
+    for i, t in enumerate(nxt):
+        ref = orc.evaluate(np.array([t], np.int32), mode=0)[-1]
+        worst_ab = max(worst_ab, float(np.max(np.abs(outs[1][i] - outs[0][i])) / ref.std()))
+        worst_o = max(worst_o, float(np.max(np.abs(outs[1][i] - ref)) / ref.std()))
+    print("split vs single launch:", worst_ab, " split vs oracle:", worst_o)
+    assert worst_ab <= EDGE and worst_o <= EDGE
+    model.free()
+
+
 def test_rewind_then_refeed_reproduces_logits(G, O):
     """binaries/llm-test/src/delete.rs:48-56: logits after rewind(1)+re-feed equal the originals."""
     hp, w, model = _mk(G, 2)
