@@ -121,6 +121,7 @@ def run_single(args):
     elapsed = time.perf_counter() - t0
     tok_s = args.steps / elapsed
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
+    h1 = {k: stat(k) - v for k, v in h0.items()}
     # the same greedy decode with the sampler on the device: ids identical to the loop above
     # (tests/test_llama_gpu.py), no logits read-back / host sync per token.  Reported beside the metric, not as it.
     sess.infer_next_token()
@@ -129,7 +130,24 @@ def run_single(args):
     sess.infer_tokens_device(args.steps)
     L.ggml_hip_synchronize()
     dev_s = time.perf_counter() - td
-    h1 = {k: stat(k) - v for k, v in h0.items()}
+    # the same decode deep into the context (n_past ~1800 of 2048): attention split over positions (decode_attn_split.h)
+    long_ctx = None
+    if args.model != "tiny":
+        ls = model.start_session(n_batch=512)
+        ls.feed_prompt(np.random.default_rng(43).integers(0, hp["n_vocab"], 1792).astype(np.int32))
+        for _ in range(8):
+            ls.infer_next_token()
+        L.ggml_hip_synchronize()
+        tl0 = time.perf_counter()
+        for _ in range(32):
+            ls.infer_next_token()
+        L.ggml_hip_synchronize()
+        long_s = time.perf_counter() - tl0
+        long_ctx = {"n_past_at_start": 1800, "tokens": 32, "tokens_per_s": round(32 / long_s, 2),
+                    "ms_per_token": round(long_s / 32 * 1e3, 4)}
+        ls.free()  # freeing device tensors drops the cached plans: one more token rebuilds the main session's
+        sess.infer_next_token()
+        L.ggml_hip_synchronize()
     host_split = {"plan_tokens": h1["plan_tokens"],
                   "graph_build_and_sampling_ms": round((elapsed * 1e9 - h1["ns_compute"]) / args.steps / 1e6, 4),
                   "match_ms": round(h1["ns_match"] / args.steps / 1e6, 4),
@@ -211,6 +229,7 @@ def run_single(args):
                                   f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",
                       "n_past_at_start": args.prompt + args.warmup, "parallelism": "1 GPU",
                       "weights_in_hbm_before_timing": True, "host_split_per_token": host_split,
+                      "long_context": long_ctx,
                       "device_sampling": {"tokens_per_s": round(args.steps / dev_s, 2), "ms_per_token": round(dev_s / args.steps * 1e3, 4),
                                           "note": "same greedy tokens via llm_infer_tokens_greedy_device (argmax kernel feeds the next "
                                                   "replay; logits stay in HBM until the last token)"},
