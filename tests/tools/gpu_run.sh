@@ -1,21 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python - <<'PY'
-import time, numpy as np
-from llm_amd import ggml, llama, synth
-hp, w = synth.make_llama_fast(synth.LLAMA_7B, ggml.TYPE_Q4_0)
-model = llama.Llama(hp, w, context_size=2048)
-toks = (np.arange(1900, dtype=np.int32) * 7 + 5) % hp["n_vocab"]
-for n0 in (200, 330, 460, 590):
-    for split in (0, 64):
-        ggml.set_option("attn_split", split)
-        s = model.start_session(n_batch=512)
-        s.feed_prompt(toks[:n0])
-        for _ in range(4): s.infer_next_token()
-        ggml.lib().ggml_hip_synchronize(); t0 = time.perf_counter()
-        for _ in range(48): s.infer_next_token()
-        ggml.lib().ggml_hip_synchronize(); dt = time.perf_counter() - t0
-        print("n_past %4d split %d: %.1f tok/s (%.3f ms)" % (n0, split, 48 / dt, dt / 48 * 1e3))
-        s.free()
-PY
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 600 python bench.py > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "bench rc=$?"; cut -c1-200 gpurun_out/bench_decode.json; tail -2 gpurun_out/bench_decode.err
+timeout 600 python bench.py --mode prefill --steps 5 --warmup 2 > gpurun_out/bench_prefill.json 2>/dev/null; cut -c1-200 gpurun_out/bench_prefill.json
+rm -rf /tmp/prof_dec
+GGML_HIP_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_dec -o bench -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_dec.log 2>&1; echo "prof rc=$?"
+grep '"metric"' gpurun_out/prof_dec.log > gpurun_out/prof_dec_bench_line.json
+python tests/tools/kstats.py /tmp/prof_dec > gpurun_out/prof_dec_stats.txt; head -12 gpurun_out/prof_dec_stats.txt
