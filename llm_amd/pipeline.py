@@ -213,8 +213,11 @@ def run_bench(args):
     os.environ["GGML_HIP_DEVICE"] = str(local_rank)  # one process drives one GPU (read at backend init)
     backend = os.environ.get("LLM_PIPELINE_BACKEND", "nccl")
     device = None
-    if backend == "nccl" and torch.cuda.device_count() <= local_rank:
-        backend = "gloo"  # fewer visible GPUs than ranks (e.g. a 1-GPU box running the 2-rank functional check)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if backend == "nccl" and torch.cuda.device_count() < local_world:
+        # fewer visible GPUs than ranks on this node (e.g. a 1-GPU box running the 2-rank functional check): EVERY rank
+        # must take this branch, so the test is on the node's rank count, not on this rank's own ordinal
+        backend = "gloo"
         os.environ["GGML_HIP_DEVICE"] = str(local_rank % max(torch.cuda.device_count(), 1))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
