@@ -1,4 +1,11 @@
+# scratch script of the last `gpurun` call (see README.md in this directory); the round-end validation was:
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 16 --warmup 4 > gpurun_out/bench_2rank.json 2> gpurun_out/bench_2rank.err; echo "rc=$?"; tail -3 gpurun_out/bench_2rank.err | cut -c1-300; cut -c1-700 gpurun_out/bench_2rank.json
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 600 python bench.py > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "bench rc=$?"
+timeout 600 python bench.py --mode prefill --steps 5 --warmup 2 > gpurun_out/bench_prefill.json 2>/dev/null
+rm -rf /tmp/prof_dec
+GGML_HIP_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_dec -o bench -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_dec.log 2>&1
+python tests/tools/kstats.py /tmp/prof_dec > gpurun_out/prof_dec_stats.txt
