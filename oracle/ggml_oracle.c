@@ -138,7 +138,24 @@ _Static_assert(sizeof(block_q5_1) == 24, "q5_1");
 _Static_assert(sizeof(block_q8_0) == 34, "q8_0");
 _Static_assert(sizeof(block_q8_1) == 40, "q8_1");
 
-enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9 };
+enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9,
+       T_Q4_K = 12, T_Q6_K = 14, T_Q8_K = 15 };
+
+/* ---- K-quants (k_quants.c upstream): groundwork for the next step after the path — the oracle side
+ * only; the product aborts on these types.  Struct layouts ARE in tree (bindgen: crates/ggml/sys/src/lib.rs:3103-3108,
+ * 3240-3245, 3303-3307, sizes 144 / 210 / 292 asserted at :3115, :3252, :3314; QK_K = 256, K_SCALE_SIZE = 12 at
+ * :31-32); the arithmetic (scale packing, dequantization, the q8_K dot products) is restated from memory of upstream
+ * like everything else here.  The ENCODERS for Q4_K / Q6_K below are plain min/max and abs-max fits, NOT upstream's
+ * iterative make_qkx1_quants / make_qx_quants search: any bytes that decode are valid weights for parity work. */
+#define QK_K 256
+#pragma pack(push, 1)
+typedef struct { fp16_t d; fp16_t dmin; uint8_t scales[12]; uint8_t qs[QK_K / 2]; } block_q4_K;           /* 144 B */
+typedef struct { uint8_t ql[QK_K / 2]; uint8_t qh[QK_K / 4]; int8_t scales[QK_K / 16]; fp16_t d; } block_q6_K; /* 210 B */
+typedef struct { float d; int8_t qs[QK_K]; int16_t bsums[QK_K / 16]; } block_q8_K;                         /* 292 B */
+#pragma pack(pop)
+_Static_assert(sizeof(block_q4_K) == 144, "q4_K");
+_Static_assert(sizeof(block_q6_K) == 210, "q6_K");
+_Static_assert(sizeof(block_q8_K) == 292, "q8_K");
 
 EXPORT int orc_type_size(int type) {
     switch (type) {
@@ -150,15 +167,22 @@ EXPORT int orc_type_size(int type) {
         case T_Q5_1: return 24;
         case T_Q8_0: return 34;
         case T_Q8_1: return 40;
+        case T_Q4_K: return 144;
+        case T_Q6_K: return 210;
+        case T_Q8_K: return 292;
     }
     return 0;
 }
-EXPORT int orc_blck_size(int type) { return (type == T_F32 || type == T_F16) ? 1 : QK; }
+EXPORT int orc_blck_size(int type) {
+    if (type == T_Q4_K || type == T_Q6_K || type == T_Q8_K) return QK_K;
+    return (type == T_F32 || type == T_F16) ? 1 : QK;
+}
 /* vec_dot_type column of ggml's type_traits table (shape visible at sys/src/lib.rs:2900-2906) */
 EXPORT int orc_vec_dot_type(int type) {
     switch (type) {
         case T_Q4_0: case T_Q5_0: case T_Q8_0: return T_Q8_0;
         case T_Q4_1: case T_Q5_1: return T_Q8_1;
+        case T_Q4_K: case T_Q6_K: return T_Q8_K;
         case T_F16: return T_F16;
     }
     return T_F32;
@@ -302,6 +326,246 @@ static void quantize_row_q8_1(const float *x, block_q8_1 *y, int k) {
     }
 }
 
+
+/* ---- K-quant codecs ---------------------------------------------------------------------------- */
+static inline int nearest_int(float f) { return (int)lrintf(f); }
+/* get_scale_min_k4 (k_quants.c): 8 six-bit (scale, min) pairs in 12 bytes */
+static inline void get_scale_min_k4(int j, const uint8_t *q, uint8_t *d, uint8_t *m) {
+    if (j < 4) {
+        *d = q[j] & 63;
+        *m = q[j + 4] & 63;
+    } else {
+        *d = (uint8_t)((q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4));
+        *m = (uint8_t)((q[j + 4] >> 4) | ((q[j - 0] >> 6) << 4));
+    }
+}
+static inline void set_scale_min_k4(int j, uint8_t *q, uint8_t ls, uint8_t lm) { /* inverse of the above */
+    if (j < 4) {
+        q[j] = (uint8_t)((q[j] & 0xC0) | ls);
+        q[j + 4] = (uint8_t)((q[j + 4] & 0xC0) | lm);
+    } else {
+        q[j + 4] = (uint8_t)((ls & 0xF) | ((lm & 0xF) << 4));
+        q[j - 4] = (uint8_t)((q[j - 4] & 0x3F) | ((ls >> 4) << 6));
+        q[j - 0] = (uint8_t)((q[j - 0] & 0x3F) | ((lm >> 4) << 6));
+    }
+}
+/* Q4_K: x = d*sc_j*q - dmin*m_j, 8 sub-blocks of 32, q in 0..15, (sc_j, m_j) six-bit.  Encoder: per sub-block min/max
+ * fit (min clamped to <= 0 like upstream so that m_j >= 0), super-block scales from the largest sub-block values. */
+static void quantize_row_q4_K(const float *x, block_q4_K *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        float scales[8], mins[8], max_scale = 0.0f, max_min = 0.0f;
+        for (int j = 0; j < 8; j++) {
+            float lo = 0.0f, hi = 0.0f;
+            for (int l = 0; l < 32; l++) {
+                const float v = x[i * QK_K + 32 * j + l];
+                if (v < lo) lo = v;
+                if (v > hi) hi = v;
+            }
+            scales[j] = (hi - lo) / 15.0f;
+            mins[j] = -lo;
+            if (scales[j] > max_scale) max_scale = scales[j];
+            if (mins[j] > max_min) max_min = mins[j];
+        }
+        const float inv_scale = max_scale > 0 ? 63.0f / max_scale : 0.0f, inv_min = max_min > 0 ? 63.0f / max_min : 0.0f;
+        memset(y[i].scales, 0, 12);
+        for (int j = 0; j < 8; j++) {
+            const int ls = MIN(63, nearest_int(inv_scale * scales[j])), lm = MIN(63, nearest_int(inv_min * mins[j]));
+            set_scale_min_k4(j, y[i].scales, (uint8_t)ls, (uint8_t)lm);
+        }
+        y[i].d = fp32_to_fp16(max_scale / 63.0f);
+        y[i].dmin = fp32_to_fp16(max_min / 63.0f);
+        uint8_t L[QK_K];
+        for (int j = 0; j < 8; j++) {
+            uint8_t sc, m;
+            get_scale_min_k4(j, y[i].scales, &sc, &m);
+            const float d = fp16_to_fp32(y[i].d) * sc, dm = fp16_to_fp32(y[i].dmin) * m;
+            for (int l = 0; l < 32; l++) {
+                int q = d != 0.0f ? nearest_int((x[i * QK_K + 32 * j + l] + dm) / d) : 0;
+                L[32 * j + l] = (uint8_t)(q < 0 ? 0 : q > 15 ? 15 : q);
+            }
+        }
+        uint8_t *q = y[i].qs;
+        for (int j = 0; j < QK_K; j += 64) {
+            for (int l = 0; l < 32; l++) q[l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 4));
+            q += 32;
+        }
+    }
+}
+static void dequantize_row_q4_K(const block_q4_K *x, float *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        const uint8_t *q = x[i].qs;
+        const float d = fp16_to_fp32(x[i].d), min = fp16_to_fp32(x[i].dmin);
+        int is = 0;
+        uint8_t sc, m;
+        for (int j = 0; j < QK_K; j += 64) {
+            get_scale_min_k4(is + 0, x[i].scales, &sc, &m);
+            const float d1 = d * sc, m1 = min * m;
+            get_scale_min_k4(is + 1, x[i].scales, &sc, &m);
+            const float d2 = d * sc, m2 = min * m;
+            for (int l = 0; l < 32; ++l) *y++ = d1 * (q[l] & 0xF) - m1;
+            for (int l = 0; l < 32; ++l) *y++ = d2 * (q[l] >> 4) - m2;
+            q += 32;
+            is += 2;
+        }
+    }
+}
+/* Q6_K: x = d*sc_j*q, 16 sub-blocks of 16, q in -32..31 (low 4 bits in ql, high 2 in qh), sc_j int8.  Encoder: abs-max
+ * fit per sub-block, super-block scale from the largest sub-block scale. */
+static void quantize_row_q6_K(const float *x, block_q6_K *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        float scales[16], max_abs_scale = 0.0f, max_scale = 0.0f;
+        for (int ib = 0; ib < 16; ib++) {
+            float amax = 0.0f, vmax = 0.0f;
+            for (int l = 0; l < 16; l++) {
+                const float v = x[i * QK_K + 16 * ib + l];
+                if (fabsf(v) > amax) { amax = fabsf(v); vmax = v; }
+            }
+            scales[ib] = amax > 0 ? vmax / -32.0f : 0.0f; /* upstream make_qx_quants: the extreme value maps to -32 */
+            if (fabsf(scales[ib]) > max_abs_scale) { max_abs_scale = fabsf(scales[ib]); max_scale = scales[ib]; }
+        }
+        if (max_abs_scale == 0.0f) {
+            memset(&y[i], 0, sizeof(block_q6_K));
+            continue;
+        }
+        const float iscale = -128.0f / max_scale;
+        y[i].d = fp32_to_fp16(1.0f / iscale);
+        for (int ib = 0; ib < 16; ib++) y[i].scales[ib] = (int8_t)MIN(127, nearest_int(iscale * scales[ib]));
+        uint8_t L[QK_K];
+        for (int j = 0; j < 16; j++) {
+            const float d = fp16_to_fp32(y[i].d) * y[i].scales[j];
+            for (int ii = 0; ii < 16; ii++) {
+                int l = d != 0.0f ? nearest_int(x[i * QK_K + 16 * j + ii] / d) : 0;
+                l = l < -32 ? -32 : l > 31 ? 31 : l;
+                L[16 * j + ii] = (uint8_t)(l + 32);
+            }
+        }
+        uint8_t *ql = y[i].ql, *qh = y[i].qh;
+        for (int j = 0; j < QK_K; j += 128) {
+            for (int l = 0; l < 32; l++) {
+                const uint8_t q1 = L[j + l + 0] & 0xF, q2 = L[j + l + 32] & 0xF, q3 = L[j + l + 64] & 0xF, q4 = L[j + l + 96] & 0xF;
+                ql[l + 0] = (uint8_t)(q1 | (q3 << 4));
+                ql[l + 32] = (uint8_t)(q2 | (q4 << 4));
+                qh[l] = (uint8_t)((L[j + l] >> 4) | ((L[j + l + 32] >> 4) << 2) | ((L[j + l + 64] >> 4) << 4) |
+                                  ((L[j + l + 96] >> 4) << 6));
+            }
+            ql += 64;
+            qh += 32;
+        }
+    }
+}
+static void dequantize_row_q6_K(const block_q6_K *x, float *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        const float d = fp16_to_fp32(x[i].d);
+        const uint8_t *ql = x[i].ql, *qh = x[i].qh;
+        const int8_t *sc = x[i].scales;
+        for (int n = 0; n < QK_K; n += 128) {
+            for (int l = 0; l < 32; ++l) {
+                const int is = l / 16;
+                const int8_t q1 = (int8_t)((ql[l + 0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                const int8_t q2 = (int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                const int8_t q3 = (int8_t)((ql[l + 0] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                const int8_t q4 = (int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                y[l + 0] = d * sc[is + 0] * q1;
+                y[l + 32] = d * sc[is + 2] * q2;
+                y[l + 64] = d * sc[is + 4] * q3;
+                y[l + 96] = d * sc[is + 6] * q4;
+            }
+            y += 128;
+            ql += 64;
+            qh += 32;
+            sc += 8;
+        }
+    }
+}
+/* quantize_row_q8_K_reference (k_quants.c): the activation side of every K-quant dot product — f32 scale, the extreme
+ * value maps to -128 (clamped to 127 on the other side), 16-element partial sums kept for the `min` terms */
+static void quantize_row_q8_K(const float *x, block_q8_K *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        float max = 0.0f, amax = 0.0f;
+        for (int j = 0; j < QK_K; ++j) {
+            const float ax = fabsf(x[j]);
+            if (ax > amax) { amax = ax; max = x[j]; }
+        }
+        if (!amax) {
+            y[i].d = 0;
+            memset(y[i].qs, 0, QK_K);
+            memset(y[i].bsums, 0, sizeof(y[i].bsums));
+            x += QK_K;
+            continue;
+        }
+        const float iscale = -128.f / max;
+        for (int j = 0; j < QK_K; ++j) y[i].qs[j] = (int8_t)MIN(127, nearest_int(iscale * x[j]));
+        for (int j = 0; j < QK_K / 16; ++j) {
+            int sum = 0;
+            for (int ii = 0; ii < 16; ++ii) sum += y[i].qs[j * 16 + ii];
+            y[i].bsums[j] = (int16_t)sum;
+        }
+        y[i].d = 1 / iscale;
+        x += QK_K;
+    }
+}
+static void dequantize_row_q8_K(const block_q8_K *x, float *y, int k) {
+    for (int i = 0; i < k / QK_K; i++)
+        for (int j = 0; j < QK_K; ++j) *y++ = x[i].d * x[i].qs[j];
+}
+/* ggml_vec_dot_q4_K_q8_K, scalar branch: sumf = sum_i d8*d*(sum_j sc_j * <q4_j, q8_j>) - d8*dmin*(sum_j m_j * bsum_j) */
+static float vec_dot_q4_K_q8_K(int n, const block_q4_K *x, const block_q8_K *y) {
+    const int nb = n / QK_K;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        const uint8_t *q4 = x[i].qs;
+        const int8_t *q8 = y[i].qs;
+        int32_t isum = 0, msum = 0;
+        for (int j = 0; j < QK_K / 64; j++) {
+            uint8_t sc1, m1, sc2, m2;
+            get_scale_min_k4(2 * j + 0, x[i].scales, &sc1, &m1);
+            get_scale_min_k4(2 * j + 1, x[i].scales, &sc2, &m2);
+            int32_t s1 = 0, s2 = 0;
+            for (int l = 0; l < 32; l++) s1 += (q4[l] & 0xF) * q8[l];
+            for (int l = 0; l < 32; l++) s2 += (q4[l] >> 4) * q8[l + 32];
+            isum += sc1 * s1 + sc2 * s2;
+            msum += m1 * (y[i].bsums[4 * j + 0] + y[i].bsums[4 * j + 1]) + m2 * (y[i].bsums[4 * j + 2] + y[i].bsums[4 * j + 3]);
+            q4 += 32;
+            q8 += 64;
+        }
+        const float d = fp16_to_fp32(x[i].d) * y[i].d, dmin = fp16_to_fp32(x[i].dmin) * y[i].d;
+        sumf += d * (float)isum - dmin * (float)msum;
+    }
+    return sumf;
+}
+/* ggml_vec_dot_q6_K_q8_K, scalar branch: sumf = sum_i d8*d * sum_{16-blocks} sc * <q6, q8> */
+static float vec_dot_q6_K_q8_K(int n, const block_q6_K *x, const block_q8_K *y) {
+    const int nb = n / QK_K;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        int8_t a[QK_K];
+        const uint8_t *ql = x[i].ql, *qh = x[i].qh;
+        for (int j = 0, o = 0; j < QK_K; j += 128, o += 128) {
+            for (int l = 0; l < 32; ++l) {
+                a[o + l + 0] = (int8_t)((ql[l + 0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                a[o + l + 32] = (int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                a[o + l + 64] = (int8_t)((ql[l + 0] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                a[o + l + 96] = (int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+            }
+            ql += 64;
+            qh += 32;
+        }
+        int32_t isum = 0;
+        for (int j = 0; j < QK_K / 16; j++) {
+            int32_t s = 0;
+            for (int l = 0; l < 16; l++) s += a[16 * j + l] * y[i].qs[16 * j + l];
+            isum += x[i].scales[j] * s;
+        }
+        sumf += fp16_to_fp32(x[i].d) * y[i].d * (float)isum;
+    }
+    return sumf;
+}
+
 EXPORT void orc_quantize_row(int type, const float *x, void *y, int k) {
     switch (type) {
         case T_Q4_0: quantize_row_q4_0(x, (block_q4_0 *)y, k); break;
@@ -310,6 +574,9 @@ EXPORT void orc_quantize_row(int type, const float *x, void *y, int k) {
         case T_Q5_1: quantize_row_q5_1(x, (block_q5_1 *)y, k); break;
         case T_Q8_0: quantize_row_q8_0(x, (block_q8_0 *)y, k); break;
         case T_Q8_1: quantize_row_q8_1(x, (block_q8_1 *)y, k); break;
+        case T_Q4_K: quantize_row_q4_K(x, (block_q4_K *)y, k); break;
+        case T_Q6_K: quantize_row_q6_K(x, (block_q6_K *)y, k); break;
+        case T_Q8_K: quantize_row_q8_K(x, (block_q8_K *)y, k); break;
         case T_F16: orc_fp32_to_fp16_row(x, (fp16_t *)y, k); break;
         case T_F32: memcpy(y, x, (size_t)k * 4); break;
         default: fprintf(stderr, "orc_quantize_row: bad type %d\n", type); abort();
@@ -321,6 +588,9 @@ EXPORT void orc_quantize_row(int type, const float *x, void *y, int k) {
 EXPORT void orc_dequantize_row(int type, const void *vx, float *y, int k) {
     const int nb = k / QK;
     switch (type) {
+        case T_Q4_K: dequantize_row_q4_K((const block_q4_K *)vx, y, k); return;
+        case T_Q6_K: dequantize_row_q6_K((const block_q6_K *)vx, y, k); return;
+        case T_Q8_K: dequantize_row_q8_K((const block_q8_K *)vx, y, k); return;
         case T_Q4_0: {
             const block_q4_0 *x = (const block_q4_0 *)vx;
             for (int i = 0; i < nb; i++) {
@@ -396,10 +666,11 @@ EXPORT void orc_dequantize_row(int type, const void *vx, float *y, int k) {
 EXPORT size_t orc_quantize(int type, const float *src, void *dst, int n, int k, int64_t *hist) {
     const int nb = k / QK;
     const size_t bs = (size_t)orc_type_size(type);
+    const int blck = orc_blck_size(type);
     for (int b = 0; b < n; b += k) {
-        uint8_t *y = (uint8_t *)dst + (size_t)(b / QK) * bs;
+        uint8_t *y = (uint8_t *)dst + (size_t)(b / blck) * bs;
         orc_quantize_row(type, src + b, y, k);
-        if (!hist) continue;
+        if (!hist || blck != QK) continue; /* no histogram for the K-quant groundwork */
         for (int i = 0; i < nb; i++) {
             const uint8_t *blk = y + (size_t)i * bs;
             switch (type) {
@@ -435,7 +706,7 @@ EXPORT size_t orc_quantize(int type, const float *src, void *dst, int n, int k, 
             }
         }
     }
-    return (size_t)(n / QK) * bs;
+    return (size_t)(n / blck) * bs;
 }
 
 /* ---- vec_dot (upstream ggml_vec_dot_q*_q8_*, scalar branch).  The heart of
@@ -528,6 +799,8 @@ EXPORT float orc_vec_dot(int type, int n, const void *x, const void *y) {
         case T_Q5_0: return vec_dot_q5_0_q8_0(n, (const block_q5_0 *)x, (const block_q8_0 *)y);
         case T_Q5_1: return vec_dot_q5_1_q8_1(n, (const block_q5_1 *)x, (const block_q8_1 *)y);
         case T_Q8_0: return vec_dot_q8_0_q8_0(n, (const block_q8_0 *)x, (const block_q8_0 *)y);
+        case T_Q4_K: return vec_dot_q4_K_q8_K(n, (const block_q4_K *)x, (const block_q8_K *)y);
+        case T_Q6_K: return vec_dot_q6_K_q8_K(n, (const block_q6_K *)x, (const block_q8_K *)y);
     }
     fprintf(stderr, "orc_vec_dot: bad type %d\n", type);
     abort();
