@@ -478,7 +478,7 @@ GGML_API void ggml_hip_timing_end(void);
 GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes);
 /* Execution mode knobs: "fuse" (peephole fusion in the generic executor), "plan" (fused LLaMA decode plan),
  * "graph" (hipGraph replay of the plan), "mmvq_rows", "big", "mmq_min", "mmq_splitk", "mmq_dma", "plan_multi",
- * "xsrc", "attn_split" (decode attention split over positions: 0 off, 1 = from 512 positions on (default), n = from n on),
+ * "xsrc", "probe" (measurement only: the decode mat-vec returns early), "attn_split" (decode attention split over positions: 0 off, 1 = from 512 positions on (default), n = from n on),
  * "timeline" (1 = 4 sampled workgroups per launch, n > 1 = n of them), "prefetch" (MB of w1|w3 that the idle
  * CUs of the decode attention launch pull into the Infinity Cache, 0 = off, measured slower: DESIGN.md section 4);
  * also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH / GGML_HIP_BIG / GGML_HIP_PREFETCH / GGML_HIP_MMQ_*. */
@@ -489,6 +489,11 @@ GGML_API void ggml_hip_set_option(const char *key, int value);
 #define GGML_HIP_KKIND_BASE 16
 GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
                                        double *algo_bytes_per_replay);
+/* Launch-floor probe (measurement only, tests/tools/launch_probe.py): a linear hipGraph of n_launch launches of a
+ * kernel that only stamps the device wall clock, with the given launch shape.  out[3] = {us per launch, us from one
+ * launch's end to the next launch's first instruction, us first instruction -> last kernel argument usable}. */
+GGML_API int ggml_hip_bench_empty(int wgs, int threads, int lds_bytes, int kernarg_bytes, int n_launch, int replays,
+                                  double *out);
 /* Counters for tests: "plan_tokens" (tokens run by the fused decode plan), "attn_split_tokens", "graph_replays", "plans",
  * "generic_graphs".  -1 for an unknown key. */
 GGML_API int64_t ggml_hip_get_stat(const char *key);

@@ -131,7 +131,9 @@ struct Backend {
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
-    int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
+    int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h); 2 = its EARLY
+                            // variant (whole weight ring requested before the activation is staged)
+    int opt_probe = 0;      // measurement only: k_mmvq_big returns early (BigArgs::probe), tests/tools/launch_probe.py
     int num_cus = 256;
     long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
     size_t timeline_bytes = 0;
@@ -1704,6 +1706,10 @@ void ggml_hip_set_option(const char *key, int value) {
         if (g.opt_big != value) drop_all_plans();
         g.opt_big = value;
     }
+    else if (k == "probe") {
+        if (g.opt_probe != value) drop_all_plans();
+        g.opt_probe = value;
+    }
     else if (k == "mmvq_rows")
         g.opt_mmvq_rows = value;
     else if (!strcmp(key, "mmq_min"))
@@ -1771,6 +1777,95 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     if (ms_total) *ms_total = ms;
     if (launches_per_replay) *launches_per_replay = st.launches[kclass];
     if (algo_bytes_per_replay) *algo_bytes_per_replay = st.bytes[kclass];
+    return 0;
+}
+
+// Launch-floor probe (tests/tools/launch_probe.py): a linear hipGraph of `n_launch` launches of a kernel that does
+// nothing but stamp the 100 MHz wall clock — at its very first instruction, again once its LAST kernel argument has
+// arrived, and at its end — with the launch shape of the decode mat-vecs (threads per workgroup, dynamic LDS, size
+// of the kernarg segment).  Separates what a kernel boundary costs by itself, and how long the kernel arguments
+// take to arrive, from what the mat-vec kernels add.  out[0] = us per launch (HIP events around `replays` replays),
+// out[1] = us from one launch's end stamp to the next launch's first instruction, out[2] = us first instruction ->
+// last kernel argument usable (workgroup 0 of each launch).
+}  // extern "C"
+namespace {
+template <int NARG>
+struct EmptyArgs {
+    long long *ts;
+    int idx;
+    int pad[(NARG - 12) / 4];
+};
+template <int NARG>
+__global__ void __launch_bounds__(1024) k_empty(const EmptyArgs<NARG> a, int last_arg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long t0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+    const int v = a.pad[(NARG - 12) / 4 - 1] + last_arg;  // the far end of the kernarg segment
+    long long t1 = v != 0x7fffffff ? (long long)wall_clock64() : 0;
+    if (v == 0x12345678) smem[threadIdx.x] = 1;  // keeps the dynamic LDS allocation referenced
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        a.ts[a.idx * 4] = t0;
+        a.ts[a.idx * 4 + 1] = t1;
+        a.ts[a.idx * 4 + 2] = (long long)wall_clock64();
+    }
+}
+template <int NARG>
+void empty_launch(int wgs, int threads, int lds, long long *ts, int idx) {
+    EmptyArgs<NARG> a;
+    memset(&a, 0, sizeof(a));
+    a.ts = ts;
+    a.idx = idx;
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_empty<NARG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL(k_empty<NARG>, dim3(wgs), dim3(threads), (size_t)lds, g.stream, a, 0);
+}
+}  // namespace
+extern "C" {
+int ggml_hip_bench_empty(int wgs, int threads, int lds_bytes, int kernarg_bytes, int n_launch, int replays, double *out) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    if (n_launch < 2 || n_launch > 512 || replays < 1 || threads < 64 || threads > 1024 || lds_bytes > 160 * 1024) return -1;
+    long long *ts = nullptr;
+    HIP_CHECK(hipMalloc((void **)&ts, (size_t)n_launch * 32));
+    HIP_CHECK(hipMemsetAsync(ts, 0, (size_t)n_launch * 32, g.stream));
+    hipGraph_t gr = nullptr;
+    hipGraphExec_t ex = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < n_launch; i++) {
+        if (kernarg_bytes <= 64) empty_launch<64>(wgs, threads, lds_bytes, ts, i);
+        else if (kernarg_bytes <= 192) empty_launch<192>(wgs, threads, lds_bytes, ts, i);
+        else empty_launch<448>(wgs, threads, lds_bytes, ts, i);
+    }
+    HIP_CHECK(hipStreamEndCapture(g.stream, &gr));
+    HIP_CHECK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphLaunch(ex, g.stream));
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, g.stream));
+    for (int i = 0; i < replays; i++) HIP_CHECK(hipGraphLaunch(ex, g.stream));
+    HIP_CHECK(hipEventRecord(b, g.stream));
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    std::vector<long long> h((size_t)n_launch * 4);
+    HIP_CHECK(hipMemcpy(h.data(), ts, (size_t)n_launch * 32, hipMemcpyDeviceToHost));
+    double gap = 0, karg = 0;
+    for (int i = 1; i < n_launch; i++) {
+        gap += (double)(h[i * 4] - h[(i - 1) * 4 + 2]) / 100.0;
+        karg += (double)(h[i * 4 + 1] - h[i * 4]) / 100.0;
+    }
+    out[0] = (double)ms * 1e3 / ((double)n_launch * replays);
+    out[1] = gap / (n_launch - 1);
+    out[2] = karg / (n_launch - 1);
+    HIP_CHECK(hipEventDestroy(a));
+    HIP_CHECK(hipEventDestroy(b));
+    HIP_CHECK(hipGraphExecDestroy(ex));
+    HIP_CHECK(hipGraphDestroy(gr));
+    HIP_CHECK(hipFree(ts));
     return 0;
 }
 

@@ -220,6 +220,7 @@ PROTOTYPES.update({
     "ggml_hip_graph_compute_end": (None, []),
     "ggml_hip_bench_plan_class": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_double)]),
+    "ggml_hip_bench_empty": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "ggml_hip_version": (C.c_char_p, []),
 })
 
@@ -442,6 +443,15 @@ def bench_plan_class(kclass, replays):
     if rc != 0:
         raise RuntimeError("no fused decode plan to benchmark (the decode graph was not recognised)")
     return ms.value, n.value, b.value
+
+
+def bench_empty(wgs, threads, lds_bytes, kernarg_bytes, n_launch=64, replays=20):
+    """(us per launch, us end -> next first instruction, us first instruction -> kernel arguments) of a do-nothing
+    kernel with the given launch shape (ggml_hip_bench_empty)."""
+    out = (C.c_double * 3)()
+    if lib().ggml_hip_bench_empty(wgs, threads, lds_bytes, kernarg_bytes, n_launch, replays, out) != 0:
+        raise ValueError("bench_empty: bad launch shape")
+    return tuple(out)
 
 
 def timing_query(kclass):
