@@ -19,11 +19,21 @@
  * vec_dot_type table shape (lib.rs:2900-2906), eps (sys/src/llama.rs:15), and the op wiring of
  * the LLaMA graph.  Each function cites the reference call site it serves.
  *
- * Two modes for every matmul-bearing function:
+ * Three modes for every matmul-bearing function (0 and 2 are both "ggml CPU semantics": they differ only where
+ * upstream's scalar code and its AVX2 intrinsics code differ; mode 2 = what crates/ggml/sys/build.rs:46-62
+ * (-mavx2 -mfma -mf16c on x86-64) actually selects):
  *   mode 0 "exact": ggml CPU semantics — activations re-quantized to the weight type's
  *           vec_dot_type (Q8_0 / Q8_1), integer block dot products, f32 accumulate across blocks;
  *           F16 matmuls round src1 to f16; softmax / SiLU through f16 rounding (ggml's lookup
  *           tables table_exp_f16 / table_silu_f16).
+ *   mode 2 "avx2-order": mode 0 with (a) the activation quantizers of upstream's AVX2 branch — id = 127/amax
+ *                  instead of 1/(amax/127), round-half-to-even (_mm256_round_ps NEAREST) instead of roundf's
+ *                  half-away-from-zero; (b) the vec_dot accumulation of that branch — 8 f32 lanes, lane l =
+ *                  fma(d, sum of elements 4l..4l+3 of the block, lane l), horizontal sum at the end
+ *                  (hsum_float_8: (x[i+4]+x[i]), then (0+2),(1+3), then +), Q4_1/Q5_1's m*s term in a
+ *                  separate scalar float; (c) ggml_vec_dot_f16's F16C branch for the two attention
+ *                  products — 4 accumulators of 8 f32 lanes, fma, pairwise reduce.  Everything else (rms_norm,
+ *                  rope, soft_max, silu table, adds) is scalar code in both builds.
  *   mode 1 "math":  dequantized weights × f32 activations, f64 accumulation, exact expf — the
  *           yardstick that says how much of a difference is activation-quantization noise.
  *
@@ -326,6 +336,43 @@ static void quantize_row_q8_1(const float *x, block_q8_1 *y, int k) {
     }
 }
 
+/* upstream quantize_row_q8_0 / q8_1, `#elif defined(__AVX2__)` branch: same amax and d, but the multiplier is
+ * 127/amax (not 1/d) and the rounding is round-half-to-even (_mm256_round_ps(v, _MM_ROUND_NEAREST) followed by
+ * cvtps_epi32); Q8_1's s = d * (int sum of the quants). */
+static inline float rne_f32(float v) { return nearbyintf(v); } /* default rounding mode = to nearest even */
+static void quantize_row_q8_0_avx2(const float *x, block_q8_0 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = fabsf(x[i * QK + j]);
+            amax = amax > v ? amax : v;
+        }
+        const float d = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        y[i].d = fp32_to_fp16(d);
+        for (int j = 0; j < QK; ++j) y[i].qs[j] = (int8_t)(int)rne_f32(x[i * QK + j] * id);
+    }
+}
+static void quantize_row_q8_1_avx2(const float *x, block_q8_1 *y, int k) {
+    const int nb = k / QK;
+    for (int i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = fabsf(x[i * QK + j]);
+            amax = amax > v ? amax : v;
+        }
+        const float d = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        y[i].d = d;
+        int sum = 0;
+        for (int j = 0; j < QK; ++j) {
+            y[i].qs[j] = (int8_t)(int)rne_f32(x[i * QK + j] * id);
+            sum += y[i].qs[j];
+        }
+        y[i].s = d * (float)sum;
+    }
+}
 
 /* ---- K-quant codecs ---------------------------------------------------------------------------- */
 static inline int nearest_int(float f) { return (int)lrintf(f); }
@@ -792,6 +839,106 @@ static float vec_dot_q8_0_q8_0(int n, const block_q8_0 *x, const block_q8_0 *y) 
     }
     return sumf;
 }
+/* ---- the same dot products in the order of upstream's AVX2 branch (mode 2) ---------------------------------- */
+static inline float hsum_float_8(const float *x) { /* upstream hsum_float_8 */
+    const float r0 = x[4] + x[0], r1 = x[5] + x[1], r2 = x[6] + x[2], r3 = x[7] + x[3];
+    const float s0 = r0 + r2, s1 = r1 + r3;
+    return s0 + s1;
+}
+/* w[j], j = 0..31: the block's weights as integers in the order of y.qs (low nibbles 0..15, high nibbles 16..31) */
+static inline void lanes_fma(const int *w, const int8_t *yq, float d, float *acc) {
+    for (int l = 0; l < 8; l++) {
+        int q = 0;
+        for (int e = 0; e < 4; e++) q += w[4 * l + e] * yq[4 * l + e]; /* maddubs + madd: exact int */
+        acc[l] = fmaf(d, (float)q, acc[l]);
+    }
+}
+static float vec_dot_simd(int type, int n, const void *vx, const void *vy) {
+    const int nb = n / QK;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float summs = 0.0f;
+    int w[QK];
+    for (int i = 0; i < nb; i++) {
+        switch (type) {
+            case T_Q4_0: {
+                const block_q4_0 *x = (const block_q4_0 *)vx;
+                const block_q8_0 *y = (const block_q8_0 *)vy;
+                for (int j = 0; j < QK / 2; j++) {
+                    w[j] = (x[i].qs[j] & 0x0F) - 8;
+                    w[j + QK / 2] = (x[i].qs[j] >> 4) - 8;
+                }
+                lanes_fma(w, y[i].qs, fp16_to_fp32(x[i].d) * fp16_to_fp32(y[i].d), acc);
+            } break;
+            case T_Q4_1: {
+                const block_q4_1 *x = (const block_q4_1 *)vx;
+                const block_q8_1 *y = (const block_q8_1 *)vy;
+                summs += fp16_to_fp32(x[i].m) * y[i].s;
+                for (int j = 0; j < QK / 2; j++) {
+                    w[j] = (x[i].qs[j] & 0x0F);
+                    w[j + QK / 2] = (x[i].qs[j] >> 4);
+                }
+                lanes_fma(w, y[i].qs, fp16_to_fp32(x[i].d) * y[i].d, acc);
+            } break;
+            case T_Q5_0: {
+                const block_q5_0 *x = (const block_q5_0 *)vx;
+                const block_q8_0 *y = (const block_q8_0 *)vy;
+                uint32_t qh;
+                memcpy(&qh, x[i].qh, sizeof(qh));
+                for (int j = 0; j < QK / 2; j++) {
+                    w[j] = (int)((x[i].qs[j] & 0x0F) | (((qh >> j) & 1u) << 4)) - 16;
+                    w[j + QK / 2] = (int)((x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4)) - 16;
+                }
+                lanes_fma(w, y[i].qs, fp16_to_fp32(x[i].d) * fp16_to_fp32(y[i].d), acc);
+            } break;
+            case T_Q5_1: {
+                const block_q5_1 *x = (const block_q5_1 *)vx;
+                const block_q8_1 *y = (const block_q8_1 *)vy;
+                uint32_t qh;
+                memcpy(&qh, x[i].qh, sizeof(qh));
+                summs += fp16_to_fp32(x[i].m) * y[i].s;
+                for (int j = 0; j < QK / 2; j++) {
+                    w[j] = (int)((x[i].qs[j] & 0x0F) | (((qh >> j) & 1u) << 4));
+                    w[j + QK / 2] = (int)((x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4));
+                }
+                lanes_fma(w, y[i].qs, fp16_to_fp32(x[i].d) * y[i].d, acc);
+            } break;
+            case T_Q8_0: {
+                const block_q8_0 *x = (const block_q8_0 *)vx;
+                const block_q8_0 *y = (const block_q8_0 *)vy;
+                for (int j = 0; j < QK; j++) w[j] = x[i].qs[j];
+                lanes_fma(w, y[i].qs, fp16_to_fp32(x[i].d) * fp16_to_fp32(y[i].d), acc);
+            } break;
+            default: fprintf(stderr, "vec_dot_simd: bad type %d\n", type); abort();
+        }
+    }
+    return hsum_float_8(acc) + summs; /* summs == 0 for the Q8_0-activation types, x + 0.0f == x */
+}
+/* ggml_vec_dot_f16, GGML_SIMD branch with F16C/AVX2: GGML_F16_STEP = 32, four 8-lane f32 accumulators,
+ * sum[j] = fma(ax[j], ay[j], sum[j]); GGML_F16_VEC_REDUCE (x0+x2, x1+x3, x0+x1, then lanes (l + l+4), hadd, hadd);
+ * leftovers (n % 32) added in ggml_float (double). */
+static float vec_dot_f16_simd(int64_t n, const float *x /* f16 values as f32 */, const float *y) {
+    float sum[4][8];
+    memset(sum, 0, sizeof(sum));
+    const int64_t np = n & ~(int64_t)31;
+    for (int64_t i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; j++)
+            for (int l = 0; l < 8; l++) sum[j][l] = fmaf(x[i + j * 8 + l], y[i + j * 8 + l], sum[j][l]);
+    float t[8];
+    for (int l = 0; l < 8; l++) t[l] = (sum[0][l] + sum[2][l]) + (sum[1][l] + sum[3][l]);
+    const float u0 = t[0] + t[4], u1 = t[1] + t[5], u2 = t[2] + t[6], u3 = t[3] + t[7];
+    const float h0 = u0 + u1, h1 = u2 + u3; /* _mm_hadd_ps(t0, t0) */
+    double sumf = (double)(h0 + h1);
+    for (int64_t i = np; i < n; i++) sumf += (double)(x[i] * y[i]);
+    return (float)sumf;
+}
+EXPORT float orc_vec_dot_simd(int type, int n, const void *x, const void *y) { return vec_dot_simd(type, n, x, y); }
+EXPORT void orc_quantize_row(int type, const float *x, void *y, int k);
+EXPORT void orc_quantize_row_simd(int type, const float *x, void *y, int k) {
+    if (type == T_Q8_0) quantize_row_q8_0_avx2(x, (block_q8_0 *)y, k);
+    else if (type == T_Q8_1) quantize_row_q8_1_avx2(x, (block_q8_1 *)y, k);
+    else orc_quantize_row(type, x, y, k);
+}
+
 EXPORT float orc_vec_dot(int type, int n, const void *x, const void *y) {
     switch (type) {
         case T_Q4_0: return vec_dot_q4_0_q8_0(n, (const block_q4_0 *)x, (const block_q8_0 *)y);
@@ -813,11 +960,13 @@ EXPORT float orc_vec_dot(int type, int n, const void *x, const void *y) {
 EXPORT void orc_mul_mat(int type, const void *A, int64_t M, int64_t K, const float *B, int64_t N, int64_t ldb,
                         float *dst, int mode) {
     const size_t row_bytes = (size_t)(K / orc_blck_size(type)) * (size_t)orc_type_size(type);
-    if (mode == 0 && type != T_F32) {
+    if (mode != 1 && type != T_F32) {
+        const int simd = mode == 2 && type != T_F16 && type != T_Q4_K && type != T_Q6_K;
         const int vdt = orc_vec_dot_type(type);
         const size_t qrow = (size_t)(K / orc_blck_size(vdt)) * (size_t)orc_type_size(vdt);
         uint8_t *wdata = (uint8_t *)malloc(qrow * (size_t)N); /* ggml: cplan.work_data, INIT phase */
-        for (int64_t n = 0; n < N; n++) orc_quantize_row(vdt, B + n * ldb, wdata + (size_t)n * qrow, (int)K);
+        for (int64_t n = 0; n < N; n++)
+            (simd ? orc_quantize_row_simd : orc_quantize_row)(vdt, B + n * ldb, wdata + (size_t)n * qrow, (int)K);
 #pragma omp parallel for schedule(static)
         for (int64_t m = 0; m < M; m++) {
             const uint8_t *a = (const uint8_t *)A + (size_t)m * row_bytes;
@@ -831,7 +980,7 @@ EXPORT void orc_mul_mat(int type, const void *A, int64_t M, int64_t K, const flo
                     for (int64_t k = 0; k < K; k++) s += (double)(fp16_to_fp32(x[k]) * fp16_to_fp32(y[k]));
                     r = (float)s;
                 } else {
-                    r = orc_vec_dot(type, (int)K, a, b);
+                    r = simd ? vec_dot_simd(type, (int)K, a, b) : orc_vec_dot(type, (int)K, a, b);
                 }
                 dst[n * M + m] = r;
             }
@@ -886,7 +1035,7 @@ EXPORT void orc_mul(const float *a, const float *b, float *y, int64_t n) {
  * table_silu_f16[i] = f16(silu_f32(f32(i))), silu_f32(x) = x/(1+expf(-x)).  models/llama:328 */
 EXPORT void orc_silu(const float *x, float *y, int64_t n, int mode) {
     for (int64_t i = 0; i < n; i++) {
-        if (mode == 0) {
+        if (mode != 1) {
             const float xf = fp16_to_fp32(fp32_to_fp16(x[i]));
             y[i] = fp16_to_fp32(fp32_to_fp16(xf / (1.0f + expf(-xf))));
         } else {
@@ -902,7 +1051,7 @@ static inline float gelu_f32(float x) {
 }
 EXPORT void orc_gelu(const float *x, float *y, int64_t n, int mode) {
     for (int64_t i = 0; i < n; i++) {
-        if (mode == 0) {
+        if (mode != 1) {
             const float xf = fp16_to_fp32(fp32_to_fp16(x[i]));
             y[i] = fp16_to_fp32(fp32_to_fp16(gelu_f32(xf)));
         } else {
@@ -971,7 +1120,7 @@ EXPORT void orc_scale_mask_softmax(float *x, int64_t nc, int64_t N, int64_t n_he
             for (int64_t i = 0; i < nc; i++) {
                 if (row[i] == -INFINITY) {
                     row[i] = 0.0f;
-                } else if (mode == 0) {
+                } else if (mode != 1) {
                     const fp16_t s = fp32_to_fp16(row[i] - max);
                     const float val = fp16_to_fp32(fp32_to_fp16(expf(fp16_to_fp32(s))));
                     sum += (double)val;
@@ -997,7 +1146,7 @@ EXPORT void orc_soft_max(float *x, int64_t nc, int64_t nrows, int mode) {
         for (int64_t i = 0; i < nc; i++) {
             if (row[i] == -INFINITY) {
                 row[i] = 0.0f;
-            } else if (mode == 0) {
+            } else if (mode != 1) {
                 const fp16_t s = fp32_to_fp16(row[i] - max);
                 const float val = fp16_to_fp32(fp32_to_fp16(expf(fp16_to_fp32(s))));
                 sum += (double)val;
@@ -1093,11 +1242,15 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
                 const int64_t hk = h / (H / Hkv);
                 const float *qrow = q + ((size_t)n * H + h) * D;
                 float qh[512]; /* D <= 512 */
-                for (int64_t d = 0; d < D; d++) qh[d] = mode == 0 ? fp16_to_fp32(fp32_to_fp16(qrow[d])) : qrow[d];
+                for (int64_t d = 0; d < D; d++) qh[d] = mode != 1 ? fp16_to_fp32(fp32_to_fp16(qrow[d])) : qrow[d];
                 for (int64_t t = 0; t < T; t++) {
                     const fp16_t *krow = m->memory_k + ((size_t)il * C + t) * Egqa + hk * D;
                     double s = 0.0;
-                    if (mode == 0) {
+                    if (mode == 2) {
+                        float kf[512];
+                        for (int64_t d = 0; d < D; d++) kf[d] = fp16_to_fp32(krow[d]);
+                        s = (double)vec_dot_f16_simd(D, kf, qh);
+                    } else if (mode != 1) {
                         for (int64_t d = 0; d < D; d++) s += (double)(fp16_to_fp32(krow[d]) * qh[d]);
                     } else {
                         for (int64_t d = 0; d < D; d++) s += (double)fp16_to_fp32(krow[d]) * (double)qh[d];
@@ -1118,7 +1271,15 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
                 for (int64_t d = 0; d < D; d++) {
                     const fp16_t *vrow = m->memory_v + (size_t)il * C * Egqa + (size_t)(hk * D + d) * C;
                     double s = 0.0;
-                    if (mode == 0) {
+                    if (mode == 2) {
+                        float *vf = (float *)malloc((size_t)T * 8), *pf = vf + T;
+                        for (int64_t t = 0; t < T; t++) {
+                            vf[t] = fp16_to_fp32(vrow[t]);
+                            pf[t] = fp16_to_fp32(fp32_to_fp16(prow[t]));
+                        }
+                        s = (double)vec_dot_f16_simd(T, vf, pf);
+                        free(vf);
+                    } else if (mode != 1) {
                         for (int64_t t = 0; t < T; t++)
                             s += (double)(fp16_to_fp32(vrow[t]) * fp16_to_fp32(fp32_to_fp16(prow[t])));
                     } else {

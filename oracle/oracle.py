@@ -1,5 +1,8 @@
 """ctypes loader for the CPU oracle (oracle/ggml_oracle.c) — TEST INFRASTRUCTURE.
 
+Modes of every matmul-bearing call: 0 = ggml's scalar code, 2 = the same in the arithmetic order of ggml's AVX2
+branch (what the reference's build selects on x86-64), 1 = "math" (dequantized weights, f64 accumulation).
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
 PARITY UNPINNED: see the header of ggml_oracle.c.
 """
@@ -51,6 +54,9 @@ def lib():
         L.orc_dequantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_vec_dot.restype = C.c_float
         L.orc_vec_dot.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_vec_dot_simd.restype = C.c_float
+        L.orc_vec_dot_simd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_quantize_row_simd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_mul_mat.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_int]
         L.orc_rms_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float]
@@ -105,11 +111,16 @@ def quantize(t, x, k=None):
     return out
 
 
-def quantize_row(t, x):
+def quantize_row(t, x, simd=False):
+    """quantize_row_q*; simd=True: the AVX2 branch's arithmetic for Q8_0 / Q8_1 (id = 127/amax, round-half-even),
+    i.e. the activation quantizer of oracle mode 2."""
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
     out = np.zeros(row_bytes(t, x.size), dtype=np.uint8)
-    lib().orc_quantize_row(t, _p(x), _p(out), x.size)
+    (lib().orc_quantize_row_simd if simd else lib().orc_quantize_row)(t, _p(x), _p(out), x.size)
     return out
+
+
+MODE_SCALAR, MODE_MATH, MODE_AVX2 = 0, 1, 2  # see the header of ggml_oracle.c
 
 
 def dequantize(t, raw, n):
