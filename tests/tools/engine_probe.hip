@@ -1,0 +1,592 @@
+// engine_probe.hip — stand-alone prototype of the persistent decode engine (measurement tool, not product code):
+// ONE launch walks a chain of quantized mat-vecs (Q4_0 weights x Q8 activations, the arithmetic of kernels/mmvq.h);
+// per CU one LOADER wave streams that CU's slice of every matrix into an LDS ring by LDS-DMA (never waits for an
+// activation), NC CONSUMER waves dot the rows out of the ring, publish each output element as an 8-byte
+// {tag, value} granule, and gather the next activation from all 256 CUs' granules (no kernel boundary, no grid
+// barrier).  Prints: us per op, the gather latency, the streaming rate, and checks every intermediate vector
+// bit-for-bit against the same chain run as ordinary launches.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I. -o /tmp/engine_probe tests/tools/engine_probe.hip
+//   /tmp/engine_probe [chain] [nops] [NC]     chain: wo | ffn | layer
+#include "../../llm_amd/csrc/kernels/decode.h"
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef unsigned long long u64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define ACQ_WG __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP
+#define REL_WG __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP
+#define RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
+
+constexpr int NCH = 96;          // ring chunks of 1 KiB
+constexpr int RING_B = NCH * 1024;
+constexpr int NBP_MAX = 384;     // padded blocks of the widest activation (11008 / 32 = 344 -> 384)
+constexpr int XQ_B = NBP_MAX * 40;
+constexpr int CTL_OFF = RING_B + XQ_B;
+constexpr int OPS_OFF = CTL_OFF + 256;
+constexpr int MAX_OPS = 256;
+constexpr int LDS_B = OPS_OFF + MAX_OPS * 24;  // op descriptors live in LDS: a global load of one in the loader's loop
+                                               // would make hipcc wait vmcnt(0) = drain the DMA pipe at every op
+constexpr unsigned SPIN_LIMIT = 4000000;
+
+struct Op {
+    int K, M;            // input width, output rows
+    long long qs_off;    // byte offset of this matrix's qs plane in the weight buffer (16 B per block)
+    long long d_off;     // element offset of its d plane (f16 per block)
+};
+struct Args {
+    const uint8_t *wqs;
+    const __half *wd;
+    const Op *ops;
+    int nops;
+    u64 *gran;           // [2][GMAX] granules, ping-pong by op parity
+    int gmax;
+    const float *x0;     // input of op 0 (f32, K0 wide)
+    float *vecs;         // [nops][GMAX] plain copy of every op's output (for the check)
+    unsigned *err;
+    long long *ts;       // [nops][4] wall clock of workgroup 0: gather start, x staged, dots done, published
+    long long *lts;      // [G][4] loader: start, end, stall polls, chunks
+    unsigned epoch0;
+    int mode;            // 0 = full chain; 1 = stream only (consumers free chunks without computing)
+};
+
+struct Ctl {
+    unsigned filled;     // chunks landed in the ring (loader -> consumers)
+    unsigned err;
+    unsigned bar;        // arrivals at the consumers' barrier (monotonic)
+    unsigned pad;
+    unsigned done[12];   // per consumer: first chunk index it still needs (consumers -> loader)
+};
+
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// chunk bookkeeping of one op for one CU: rows [r0, r0 + nrows) in groups of RS rows; a group = its rows' qs chunks
+// (nbl each) followed by ONE scale chunk (the scales of RS consecutive rows are contiguous: RS * nb * 2 <= 1024 B)
+struct OpGeo {
+    int nb, nbl, RS, r0, nrows, ng, cpg;  // cpg: chunks of a full group
+    __device__ __forceinline__ void init(const Op &o, int cu, int ncu) {
+        nb = o.K >> 5;
+        nbl = (nb + 63) >> 6;
+        RS = nb <= 512 ? (512 / nb > 0 ? 512 / nb : 1) : 1;
+        if (RS > 8) RS = 8;
+        const int per = o.M / ncu, rem = o.M % ncu;  // rows dealt contiguously, the first `rem` CUs get one more
+        r0 = cu * per + (cu < rem ? cu : rem);
+        nrows = per + (cu < rem ? 1 : 0);
+        ng = (nrows + RS - 1) / RS;
+        cpg = RS * nbl + 1;
+    }
+    __device__ __forceinline__ int rows_of(int g) const { return g == ng - 1 ? nrows - g * RS : RS; }
+    __device__ __forceinline__ int chunks_of(int g) const { return rows_of(g) * nbl + 1; }
+    __device__ __forceinline__ int total() const { return ng == 0 ? 0 : (ng - 1) * cpg + chunks_of(ng - 1); }
+};
+
+template <int NC>
+__global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctl *ctl = (Ctl *)(smem + CTL_OFF);
+    i32x4 *s_lo = (i32x4 *)(smem + RING_B);
+    i32x4 *s_hi = s_lo + NBP_MAX;
+    float *s_d = (float *)(s_hi + NBP_MAX);
+    int *s_sum = (int *)(s_d + NBP_MAX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cu = blockIdx.x, ncu = gridDim.x;
+    const unsigned lds0 = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
+
+    const Op *s_ops = (const Op *)(smem + OPS_OFF);
+    for (int i = tid; i < a.nops * 6; i += blockDim.x) ((int *)(smem + OPS_OFF))[i] = ((const int *)a.ops)[i];
+    if (tid < 64) {  // control words
+        if (lane == 0) { ctl->filled = 0; ctl->err = 0; ctl->bar = 0; }
+        if (lane < 12) ctl->done[lane] = 0;
+    }
+    __syncthreads();
+
+    if (wave == NC) {
+        // ================================ LOADER ================================
+        const long long t_start = wall_clock64();
+        unsigned issued = 0, since = 0, min_done = 0;
+        long long stalls = 0;
+        bool dead = false;
+        for (int oi = 0; oi < a.nops && !dead; oi++) {
+            const Op o = s_ops[oi];
+            OpGeo ge;
+            ge.init(o, cu, ncu);
+            const uint8_t *qs = a.wqs + o.qs_off;
+            const __half *wd = a.wd + o.d_off;
+            for (int g = 0; g < ge.ng && !dead; g++) {
+                const int rows = ge.rows_of(g), row0 = ge.r0 + g * ge.RS;
+                const int nchunks = rows * ge.nbl + 1;
+                for (int c = 0; c < nchunks; c++) {
+                    // ring space: chunk `issued` may overwrite slot issued % NCH once every consumer is past issued - NCH
+                    auto read_min = [&]() {
+                        unsigned m = 0xffffffffu;
+#pragma unroll
+                        for (int w = 0; w < NC; w++) {
+                            const unsigned v = __hip_atomic_load(&ctl->done[w], ACQ_WG);
+                            m = v < m ? v : m;
+                        }
+                        return m;
+                    };
+                    if (issued >= min_done + NCH) min_done = read_min();
+                    if (issued >= min_done + NCH) {
+                        // blocked anyway: let everything in flight land and publish it
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&ctl->filled, issued, REL_WG);
+                        since = 0;
+                        unsigned spins = 0;
+                        for (;;) {
+                            unsigned m = 0xffffffffu;
+#pragma unroll
+                            for (int w = 0; w < NC; w++) {
+                                const unsigned v = __hip_atomic_load(&ctl->done[w], ACQ_WG);
+                                m = v < m ? v : m;
+                            }
+                            min_done = m;
+                            if (issued < min_done + NCH) break;
+                            stalls++;
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
+                        }
+                        if (dead) break;
+                    }
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (issued % NCH) * 1024);
+                    if (c < nchunks - 1) {  // a row's column step: 64 blocks x 16 B (lanes past the row end re-read its last block)
+                        const int r = c / ge.nbl, j = c - r * ge.nbl;
+                        int b = j * 64 + lane;
+                        b = b < ge.nb ? b : ge.nb - 1;
+                        dma16(qs + ((size_t)(row0 + r) * ge.nb + b) * 16, dst);
+                    } else {  // the group's scales: rows * nb f16, contiguous; 8 per lane
+                        const int n16 = (rows * ge.nb) >> 3;
+                        if (lane < n16) dma16((const char *)(wd + (size_t)row0 * ge.nb) + lane * 16, dst);
+                    }
+                    issued++;
+                    if (++since == 8) {  // keep <= 40 DMA instructions in flight; publish what has landed
+                        since = 0;
+                        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                        if (issued > 32) __hip_atomic_store(&ctl->filled, issued - 32, REL_WG);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ctl->filled, issued, REL_WG);
+        if (dead) {
+            __hip_atomic_store(&ctl->err, 1u, RLX_WG);
+            if (lane == 0) atomicOr(a.err, 1u);
+        }
+        if (lane == 0) {
+            a.lts[cu * 4 + 0] = t_start;
+            a.lts[cu * 4 + 1] = wall_clock64();
+            a.lts[cu * 4 + 2] = stalls;
+            a.lts[cu * 4 + 3] = issued;
+        }
+        return;
+    }
+
+    // ================================ CONSUMERS ================================
+    const int w = wave;  // 0..NC-1
+    unsigned bar_target = 0;
+    bool dead = false;
+    auto cbarrier = [&]() {  // barrier among the NC consumer waves (the loader never joins one)
+        bar_target += NC;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&ctl->bar, 1u, REL_WG);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&ctl->bar, ACQ_WG) < bar_target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
+        }
+    };
+    unsigned kbase = 0;  // chunk index of the current op's first chunk
+    for (int oi = 0; oi < a.nops; oi++) {
+        const Op o = s_ops[oi];
+        OpGeo ge;
+        ge.init(o, cu, ncu);
+        const int nb = ge.nb, nbp = ge.nbl * 64;
+        const unsigned tag = a.epoch0 + (unsigned)oi;
+        const bool rec = cu == 0 && w == 0 && lane == 0;
+        if (rec) a.ts[oi * 4 + 0] = wall_clock64();
+        // ---- 1. the activation: gather the previous op's granules (or x0), re-quantize to Q8 into LDS ----
+        if (a.mode == 0) {
+            // zero the padded blocks
+            for (int i = nb + w * 64 + lane; i < nbp; i += NC * 64) {
+                s_lo[i] = i32x4{0, 0, 0, 0};
+                s_hi[i] = i32x4{0, 0, 0, 0};
+                s_d[i] = 0.0f;
+                s_sum[i] = 0;
+            }
+            const int npass = (o.K + 255) >> 8;  // a pass = 64 lanes x 4 consecutive elements = 8 blocks
+            const u64 *src = a.gran + (size_t)((oi + 1) & 1) * a.gmax;  // written by op oi-1 with tag - 1
+            if (oi == 0) {  // the chain's input is a plain f32 row
+                for (int p = w; p < npass; p += NC) {
+                    const int e = (p * 64 + lane) * 4;
+                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (e < o.K) v = *(const f32x4 *)(a.x0 + e);
+                    quant4_to_lds<true>(v, (int64_t)p * 64 + lane, nb, lane, s_lo, s_hi, s_d, s_sum);
+                }
+            } else {
+                for (int p0 = w; p0 < npass && !dead; p0 += NC * 4) {
+                    // up to 4 passes of this wave per batch (p0, p0+NC, p0+2NC, p0+3NC): 16 granule loads per lane in
+                    // flight, re-read until every tag of the batch carries the producer op's tag
+                    u64 gr[4][4];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int p = p0 + q * NC;
+                            int e = (p * 64 + lane) * 4;
+                            e = (p < npass && e < o.K) ? e : 0;  // clamped: the loads are unconditional
+#pragma unroll
+                            for (int k = 0; k < 4; k++) gr[q][k] = __hip_atomic_load(src + e + k, RLX_AGENT);
+                        }
+                        bool ok = true;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) ok &= (unsigned)(gr[q][k] >> 32) == tag - 1;
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
+                    }
+                    if (dead) break;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int p = p0 + q * NC;
+                        const int e = (p * 64 + lane) * 4;
+                        f32x4 v;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[k] = (p < npass && e < o.K) ? __builtin_bit_cast(float, (unsigned)gr[q][k]) : 0.0f;
+                        if (p < npass) quant4_to_lds<true>(v, (int64_t)p * 64 + lane, nb, lane, s_lo, s_hi, s_d, s_sum);
+                    }
+                }
+            }
+            cbarrier();
+        }
+        if (rec) a.ts[oi * 4 + 1] = wall_clock64();
+        // ---- 2. this wave's row groups ----
+        u64 *dstg = a.gran + (size_t)(oi & 1) * a.gmax;
+        for (int g = w; g < ge.ng && !dead; g += NC) {
+            const unsigned k0 = kbase + (unsigned)g * ge.cpg;
+            const int rows = ge.rows_of(g), nchunks = rows * ge.nbl + 1;
+            {  // wait until the group has landed
+                unsigned spins = 0;
+                while (__hip_atomic_load(&ctl->filled, ACQ_WG) < k0 + nchunks) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
+                }
+                if (dead) break;
+            }
+            float myv = 0.0f;
+            if (a.mode == 0) {
+                const char *sc = smem + ((k0 + rows * ge.nbl) % NCH) * 1024;
+                for (int r = 0; r < rows; r++) {
+                    float acc = 0.0f;
+                    for (int j = 0; j < ge.nbl; j++) {
+                        const int b = j * 64 + lane;
+                        const char *ch = smem + ((k0 + r * ge.nbl + j) % NCH) * 1024;
+                        if (b < nb) {
+                            const u32x4 q = *(const u32x4 *)(ch + lane * 16);
+                            const float dw = __half2float(*(const __half *)(sc + (r * nb + b) * 2));
+                            acc += block_dot<QT_Q4_0>(q, q, 0u, dw, 0.0f, s_lo[b], s_hi[b], s_d[b], s_sum[b]);
+                        }
+                    }
+                    const float v = wave_sum_f32(acc);
+                    myv = lane == r ? v : myv;
+                }
+            }
+            // this wave needs nothing below its next group any more
+            {
+                unsigned nxt;
+                if (g + NC < ge.ng) {
+                    nxt = kbase + (unsigned)(g + NC) * ge.cpg;
+                } else {  // first group of this wave in a later op
+                    nxt = 0xffffffffu;
+                    unsigned kb = kbase + (unsigned)ge.total();
+                    for (int oj = oi + 1; oj < a.nops; oj++) {
+                        OpGeo gj;
+                        gj.init(s_ops[oj], cu, ncu);
+                        if (w < gj.ng) { nxt = kb + (unsigned)w * gj.cpg; break; }
+                        kb += (unsigned)gj.total();
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&ctl->done[w], nxt, REL_WG);
+            }
+            // publish: lane r holds row r of the group
+            if (a.mode == 0 && lane < rows) {
+                const int m = ge.r0 + g * ge.RS + lane;
+                __hip_atomic_store(dstg + m, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, myv), RLX_AGENT);
+                a.vecs[(size_t)oi * a.gmax + m] = myv;
+            }
+        }
+        if (w >= ge.ng && !dead) {  // a wave without a group in this op still has to release the ring
+            // (its done[] already points at its next group or beyond: set when it finished its last group, or 0 at start)
+            if (__hip_atomic_load(&ctl->done[w], RLX_WG) < kbase + (unsigned)ge.total()) {
+                unsigned nxt = 0xffffffffu, kb = kbase + (unsigned)ge.total();
+                for (int oj = oi + 1; oj < a.nops; oj++) {
+                    OpGeo gj;
+                    gj.init(s_ops[oj], cu, ncu);
+                    if (w < gj.ng) { nxt = kb + (unsigned)w * gj.cpg; break; }
+                    kb += (unsigned)gj.total();
+                }
+                if (lane == 0) __hip_atomic_store(&ctl->done[w], nxt, REL_WG);
+            }
+        }
+        if (rec) a.ts[oi * 4 + 2] = wall_clock64();
+        kbase += (unsigned)ge.total();
+        if (dead) break;
+        // the activation area is rewritten by the next op's gather: every wave must be done reading it
+        if (a.mode == 0) cbarrier();
+        if (rec) a.ts[oi * 4 + 3] = wall_clock64();
+    }
+    if (dead) {
+        __hip_atomic_store(&ctl->err, 1u, RLX_WG);
+        if (lane == 0) atomicOr(a.err, 2u);
+        // unblock the loader
+        if (lane == 0) __hip_atomic_store(&ctl->done[w], 0xffffffffu, REL_WG);
+    }
+}
+
+// ---- the same chain as ordinary launches (reference for the bit-exact check and for the launch-based time) ----
+__global__ void __launch_bounds__(1024) k_ref_quant(const float *x, int K, int8_t *lo, int8_t *hi, float *dq, int *sumq) {
+    // same arithmetic as quant4_to_lds: 8 lanes per block, 4 consecutive elements per lane
+    const int t = blockIdx.x * 1024 + threadIdx.x;
+    const int nb = K >> 5;
+    if (t * 4 >= ((K + 255) & ~255)) return;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (t * 4 < K) v = *(const f32x4 *)(x + t * 4);
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = g8_max_f32(amax);
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const int q0 = (int)roundf(v[0] * id), q1 = (int)roundf(v[1] * id), q2 = (int)roundf(v[2] * id), q3 = (int)roundf(v[3] * id);
+    int sq = (q0 + q1) + (q2 + q3);
+    sq = g8_sum_i32(sq);
+    const int b = t >> 3, j = t & 7;
+    if (b >= nb) return;
+    const int packed = (q0 & 0xFF) | ((q1 & 0xFF) << 8) | ((q2 & 0xFF) << 16) | ((int)((unsigned)q3 << 24));
+    ((int *)(j < 4 ? lo : hi))[b * 4 + (j & 3)] = packed;
+    if (j == 0) {
+        dq[b] = round_f16(d);
+        sumq[b] = sq;
+    }
+}
+__global__ void __launch_bounds__(256) k_ref_mv(const uint8_t *qs, const __half *wd, int K, int M, const i32x4 *lo,
+                                                const i32x4 *hi, const float *dq, const int *sumq, float *out) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nb = K >> 5;
+    float acc = 0.0f;
+    for (int b = lane; b < nb; b += 64) {
+        const u32x4 q = __builtin_nontemporal_load((const u32x4 *)(qs + ((size_t)m * nb + b) * 16));
+        const float dw = __half2float(wd[(size_t)m * nb + b]);
+        acc += block_dot<QT_Q4_0>(q, q, 0u, dw, 0.0f, lo[b], hi[b], dq[b], sumq[b]);
+    }
+    const float v = wave_sum_f32(acc);
+    if (lane == 0) out[m] = v;
+}
+__global__ void k_fill(uint8_t *qs, __half *wd, size_t nblk, unsigned seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    unsigned s = (unsigned)(i * 2654435761u) ^ seed;
+    u32x4 q;
+    for (int k = 0; k < 4; k++) {
+        s = s * 1664525u + 1013904223u;
+        q[k] = s;
+    }
+    ((u32x4 *)qs)[i] = q;
+    s = s * 1664525u + 1013904223u;
+    wd[i] = __float2half(0.0015f + 0.001f * (float)(s >> 24) / 256.0f);
+}
+
+template <int NC>
+static void run_engine(const Args &a, int G, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        CK(hipFuncSetAttribute((const void *)k_engine<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+    }
+    hipLaunchKernelGGL(k_engine<NC>, dim3(G), dim3((NC + 1) * 64), LDS_B, st, a);
+}
+
+int main(int argc, char **argv) {
+    const char *chain = argc > 1 ? argv[1] : "ffn";
+    const int nops = std::min(argc > 2 ? atoi(argv[2]) : 64, MAX_OPS);
+    const int NC = argc > 3 ? atoi(argv[3]) : 3;
+    hipDeviceProp_t pr;
+    CK(hipGetDeviceProperties(&pr, 0));
+    const int G = pr.multiProcessorCount;
+    // op shapes
+    std::vector<Op> ops(nops);
+    std::vector<std::pair<int, int>> shapes;  // (K, M) cycle
+    if (!strcmp(chain, "wo")) shapes = {{4096, 4096}};
+    else if (!strcmp(chain, "ffn")) shapes = {{4096, 11008}, {11008, 4096}};
+    else shapes = {{4096, 4096}, {4096, 4096}, {4096, 11008}, {11008, 4096}};  // "layer": ~qkv-ish, wo, gate-ish, down
+    const int GMAX = 11008;
+    size_t blk = 0;
+    const size_t WBLK = (size_t)1 << 27;  // 128 Mi blocks = 2 GiB of qs: every op reads fresh HBM
+    for (int i = 0; i < nops; i++) {
+        const auto sh = shapes[i % shapes.size()];
+        ops[i].K = sh.first;
+        ops[i].M = sh.second;
+        const size_t n = (size_t)sh.first / 32 * sh.second;
+        if (blk + n > WBLK) blk = 0;
+        ops[i].qs_off = (long long)blk * 16;
+        ops[i].d_off = (long long)blk;
+        blk += n;
+    }
+    double total_bytes = 0;
+    for (auto &o : ops) total_bytes += (double)o.K / 32 * o.M * 18;
+    printf("device %s CUs %d | chain %s, %d ops, NC %d, %.1f MB of weights per run\n", pr.gcnArchName, G, chain, nops, NC,
+           total_bytes / 1e6);
+    uint8_t *wqs;
+    __half *wd;
+    CK(hipMalloc(&wqs, WBLK * 16));
+    CK(hipMalloc(&wd, WBLK * 2));
+    k_fill<<<(unsigned)((WBLK + 255) / 256), 256>>>(wqs, wd, WBLK, 12345u);
+    CK(hipDeviceSynchronize());
+    Args a;
+    memset(&a, 0, sizeof(a));
+    a.wqs = wqs;
+    a.wd = wd;
+    Op *dops;
+    CK(hipMalloc(&dops, nops * sizeof(Op)));
+    CK(hipMemcpy(dops, ops.data(), nops * sizeof(Op), hipMemcpyHostToDevice));
+    a.ops = dops;
+    a.nops = nops;
+    a.gmax = GMAX;
+    CK(hipMalloc(&a.gran, 2 * GMAX * 8));
+    CK(hipMemset(a.gran, 0, 2 * GMAX * 8));
+    std::vector<float> x0(GMAX);
+    for (int i = 0; i < GMAX; i++) x0[i] = sinf(0.37f * i) + 0.25f * cosf(0.011f * i);
+    float *dx0;
+    CK(hipMalloc(&dx0, GMAX * 4));
+    CK(hipMemcpy(dx0, x0.data(), GMAX * 4, hipMemcpyHostToDevice));
+    a.x0 = dx0;
+    CK(hipMalloc(&a.vecs, (size_t)nops * GMAX * 4));
+    CK(hipMalloc(&a.err, 4));
+    CK(hipMemset(a.err, 0, 4));
+    CK(hipMalloc(&a.ts, nops * 32));
+    CK(hipMalloc(&a.lts, G * 32));
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+
+    // ---- reference chain: ordinary launches ----
+    int8_t *rlo, *rhi;
+    float *rd, *rvecs;
+    int *rs;
+    CK(hipMalloc(&rlo, NBP_MAX * 16));
+    CK(hipMalloc(&rhi, NBP_MAX * 16));
+    CK(hipMalloc(&rd, NBP_MAX * 4));
+    CK(hipMalloc(&rs, NBP_MAX * 4));
+    CK(hipMalloc(&rvecs, (size_t)nops * GMAX * 4));
+    auto ref_chain = [&]() {
+        for (int i = 0; i < nops; i++) {
+            const float *src = i == 0 ? dx0 : rvecs + (size_t)(i - 1) * GMAX;
+            const int K = ops[i].K, M = ops[i].M;
+            hipLaunchKernelGGL(k_ref_quant, dim3((K / 4 + 1023) / 1024), dim3(1024), 0, st, src, K, rlo, rhi, rd, rs);
+            hipLaunchKernelGGL(k_ref_mv, dim3((M + 3) / 4), dim3(256), 0, st, wqs + ops[i].qs_off, wd + ops[i].d_off, K, M,
+                               (const i32x4 *)rlo, (const i32x4 *)rhi, rd, rs, rvecs + (size_t)i * GMAX);
+        }
+    };
+    ref_chain();
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    ref_chain();
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float ref_ms;
+    CK(hipEventElapsedTime(&ref_ms, e0, e1));
+    printf("reference (2 plain launches per op, eager): %.1f us per op\n", ref_ms * 1e3 / nops);
+
+    auto launch = [&](int mode, unsigned epoch) {
+        a.mode = mode;
+        a.epoch0 = epoch;
+        switch (NC) {
+            case 3: run_engine<3>(a, G, st); break;
+            case 5: run_engine<5>(a, G, st); break;
+            case 7: run_engine<7>(a, G, st); break;
+            case 11: run_engine<11>(a, G, st); break;
+            default: printf("NC must be 3, 5, 7 or 11\n"); exit(1);
+        }
+        CK(hipGetLastError());
+    };
+    unsigned epoch = 1000;
+    for (int mode : {1, 0}) {
+        for (int rep = 0; rep < 3; rep++) {
+            epoch += 4096;
+            CK(hipMemsetAsync(a.err, 0, 4, st));
+            CK(hipEventRecord(e0, st));
+            launch(mode, epoch);
+            CK(hipEventRecord(e1, st));
+            CK(hipStreamSynchronize(st));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned err;
+            CK(hipMemcpy(&err, a.err, 4, hipMemcpyDeviceToHost));
+            std::vector<long long> lts(G * 4), ts(nops * 4);
+            CK(hipMemcpy(lts.data(), a.lts, G * 32, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(ts.data(), a.ts, nops * 32, hipMemcpyDeviceToHost));
+            double lmax = 0, stalls = 0;
+            for (int c = 0; c < G; c++) {
+                lmax = std::max(lmax, (double)(lts[c * 4 + 1] - lts[c * 4]) / 100.0);
+                stalls += (double)lts[c * 4 + 2];
+            }
+            printf("%s rep %d: %8.1f us total, %6.2f us per op, %7.1f GB/s | loader span max %.1f us, ring-full polls/CU %.0f | err %u\n",
+                   mode == 1 ? "stream-only" : "full chain ", rep, ms * 1e3, ms * 1e3 / nops, total_bytes / 1e3 / (ms * 1e3), lmax,
+                   stalls / G, err);
+            if (mode == 0 && rep == 2) {
+                double g = 0, d = 0, p = 0, per = 0;
+                int n = 0;
+                for (int i = 2; i < nops; i++) {
+                    g += (double)(ts[i * 4 + 1] - ts[i * 4]) / 100.0;
+                    d += (double)(ts[i * 4 + 2] - ts[i * 4 + 1]) / 100.0;
+                    p += (double)(ts[i * 4 + 3] - ts[i * 4 + 2]) / 100.0;
+                    per += (double)(ts[i * 4] - ts[(i - 1) * 4]) / 100.0;
+                    n++;
+                }
+                printf("  workgroup 0, wave 0, per op: gather+quantize %.2f us, dots %.2f us, end barrier %.2f us, period %.2f us\n",
+                       g / n, d / n, p / n, per / n);
+                // per-shape split
+                for (size_t s = 0; s < shapes.size(); s++) {
+                    double gg = 0, dd = 0;
+                    int nn = 0;
+                    for (int i = 2 + (int)s; i < nops; i += (int)shapes.size())
+                        if (i % (int)shapes.size() == (int)s) {
+                            gg += (double)(ts[i * 4 + 1] - ts[i * 4]) / 100.0;
+                            dd += (double)(ts[i * 4 + 2] - ts[i * 4 + 1]) / 100.0;
+                            nn++;
+                        }
+                    if (nn) printf("    shape K=%d M=%d: gather %.2f us, dots %.2f us\n", shapes[s].first, shapes[s].second, gg / nn, dd / nn);
+                }
+                // bit-exact check of every intermediate vector
+                std::vector<float> ev((size_t)nops * GMAX), rv((size_t)nops * GMAX);
+                CK(hipMemcpy(ev.data(), a.vecs, ev.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(rv.data(), rvecs, rv.size() * 4, hipMemcpyDeviceToHost));
+                long long bad = 0;
+                int first_bad_op = -1;
+                for (int i = 0; i < nops; i++)
+                    for (int m = 0; m < ops[i].M; m++)
+                        if (memcmp(&ev[(size_t)i * GMAX + m], &rv[(size_t)i * GMAX + m], 4)) {
+                            bad++;
+                            if (first_bad_op < 0) first_bad_op = i;
+                        }
+                printf("  check vs plain launches: %lld mismatching elements (first bad op %d) -> %s\n", bad, first_bad_op,
+                       bad == 0 && err == 0 ? "BIT-EXACT" : "MISMATCH");
+            }
+        }
+    }
+    return 0;
+}

@@ -2,12 +2,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python tests/tools/launch_probe.py 7b > gpurun_out/r02_probe1.txt 2>&1; echo "probe rc=$?"
-GGML_HIP_BIG=2 timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > gpurun_out/r02_pytest_big2.txt; cat gpurun_out/r02_pytest_big2.txt
-timeout 300 python tests/tools/timeline.py 7b 256 > gpurun_out/r02_timeline_big1.txt 2>&1
-GGML_HIP_BIG=2 timeout 300 python tests/tools/timeline.py 7b 256 > gpurun_out/r02_timeline_big2.txt 2>&1
-GGML_HIP_BIG=2 timeout 300 python tests/tools/timeline.py 7b > gpurun_out/r02_timeline4_big2.txt 2>&1
-HIP_FORCE_DEV_KERNARG=0 timeout 300 python bench.py --no-cpu-baseline --steps 64 > gpurun_out/r02_bench_kernarg0.json 2>/dev/null
-HIP_FORCE_DEV_KERNARG=1 timeout 300 python bench.py --no-cpu-baseline --steps 64 > gpurun_out/r02_bench_kernarg1.json 2>/dev/null
-GGML_HIP_BIG=2 timeout 300 python bench.py --no-cpu-baseline --steps 64 > gpurun_out/r02_bench_big2.json 2>/dev/null
-tail -40 gpurun_out/r02_probe1.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I. -o /tmp/engine_probe tests/tools/engine_probe.hip 2>&1 | grep -E "error" 
+for cfg in "ffn 64 3" "ffn 64 7" "ffn 64 11" "layer 64 7" "wo 64 7" "wo 64 3"; do
+  echo "=== $cfg" >> gpurun_out/r02_engine1.txt
+  timeout 90 /tmp/engine_probe $cfg >> gpurun_out/r02_engine1.txt 2>&1; echo "rc=$?" >> gpurun_out/r02_engine1.txt
+done
+cat gpurun_out/r02_engine1.txt
