@@ -112,69 +112,86 @@ __global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
 
     if (wave == NC) {
         // ================================ LOADER ================================
+        // One wave; its whole job is to keep LDS-DMA requests in flight, so the loop is kept to a few instructions per
+        // 1 KiB request: the row's address lives in a scalar register pair (advanced by scalar adds), every lane
+        // contributes a constant 32-bit offset (lane * 16; the last column step of a row whose length is not a
+        // multiple of 64 blocks clamps to the row's last block), the ring slot is a counter, space and pacing are
+        // checked once per row group.
         const long long t_start = wall_clock64();
-        unsigned issued = 0, since = 0, min_done = 0;
+        unsigned issued = 0, slot = 0, min_done = 0;
         long long stalls = 0;
         bool dead = false;
+        const unsigned v_lane16 = (unsigned)lane * 16u;
+        auto read_min = [&]() {
+            unsigned m = 0xffffffffu;
+#pragma unroll
+            for (int w = 0; w < NC; w++) {
+                const unsigned v = __hip_atomic_load(&ctl->done[w], ACQ_WG);
+                m = v < m ? v : m;
+            }
+            return m;
+        };
         for (int oi = 0; oi < a.nops && !dead; oi++) {
             const Op o = s_ops[oi];
             OpGeo ge;
             ge.init(o, cu, ncu);
-            const uint8_t *qs = a.wqs + o.qs_off;
-            const __half *wd = a.wd + o.d_off;
+            const int last = (ge.nbl - 1) * 64 + lane;
+            const unsigned v_last16 = (unsigned)((last < ge.nb ? last : ge.nb - 1) - (ge.nbl - 1) * 64) * 16u;  // may be "negative": 32-bit wrap + 64-bit base is fine only if >= 0
+            // (nb - 1 >= (nbl - 1) * 64 always, so the clamped offset is never below the step's base)
+            const uint8_t *row_qs = a.wqs + o.qs_off + (size_t)ge.r0 * ge.nb * 16;   // wave-uniform
+            const char *grp_d = (const char *)(a.wd + o.d_off + (size_t)ge.r0 * ge.nb);
+            const unsigned row_bytes = (unsigned)ge.nb * 16u, row_dbytes = (unsigned)ge.nb * 2u;
             for (int g = 0; g < ge.ng && !dead; g++) {
-                const int rows = ge.rows_of(g), row0 = ge.r0 + g * ge.RS;
-                const int nchunks = rows * ge.nbl + 1;
-                for (int c = 0; c < nchunks; c++) {
-                    // ring space: chunk `issued` may overwrite slot issued % NCH once every consumer is past issued - NCH
-                    auto read_min = [&]() {
-                        unsigned m = 0xffffffffu;
-#pragma unroll
-                        for (int w = 0; w < NC; w++) {
-                            const unsigned v = __hip_atomic_load(&ctl->done[w], ACQ_WG);
-                            m = v < m ? v : m;
-                        }
-                        return m;
-                    };
-                    if (issued >= min_done + NCH) min_done = read_min();
-                    if (issued >= min_done + NCH) {
-                        // blocked anyway: let everything in flight land and publish it
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_store(&ctl->filled, issued, REL_WG);
-                        since = 0;
-                        unsigned spins = 0;
-                        for (;;) {
-                            unsigned m = 0xffffffffu;
-#pragma unroll
-                            for (int w = 0; w < NC; w++) {
-                                const unsigned v = __hip_atomic_load(&ctl->done[w], ACQ_WG);
-                                m = v < m ? v : m;
-                            }
-                            min_done = m;
-                            if (issued < min_done + NCH) break;
-                            stalls++;
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
-                        }
-                        if (dead) break;
+                const int rows = ge.rows_of(g);
+                const unsigned nchunks = (unsigned)(rows * ge.nbl + 1);
+                // ring space for the whole group
+                if (issued + nchunks > min_done + NCH) min_done = read_min();
+                if (issued + nchunks > min_done + NCH) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // blocked anyway: publish everything in flight
+                    __hip_atomic_store(&ctl->filled, issued, REL_WG);
+                    unsigned spins = 0;
+                    for (;;) {
+                        min_done = read_min();
+                        if (issued + nchunks <= min_done + NCH) break;
+                        stalls++;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
                     }
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (issued % NCH) * 1024);
-                    if (c < nchunks - 1) {  // a row's column step: 64 blocks x 16 B (lanes past the row end re-read its last block)
-                        const int r = c / ge.nbl, j = c - r * ge.nbl;
-                        int b = j * 64 + lane;
-                        b = b < ge.nb ? b : ge.nb - 1;
-                        dma16(qs + ((size_t)(row0 + r) * ge.nb + b) * 16, dst);
-                    } else {  // the group's scales: rows * nb f16, contiguous; 8 per lane
-                        const int n16 = (rows * ge.nb) >> 3;
-                        if (lane < n16) dma16((const char *)(wd + (size_t)row0 * ge.nb) + lane * 16, dst);
-                    }
-                    issued++;
-                    if (++since == 8) {  // keep <= 40 DMA instructions in flight; publish what has landed
-                        since = 0;
-                        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-                        if (issued > 32) __hip_atomic_store(&ctl->filled, issued - 32, REL_WG);
-                    }
+                    if (dead) break;
                 }
+                for (int r = 0; r < rows; r++) {
+                    unsigned long long base;
+                    {  // provably wave-uniform for the compiler: an "s" operand needs it
+                        const unsigned long long bq = (unsigned long long)(uintptr_t)row_qs;
+                        base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bq >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bq);
+                    }
+                    for (int j = 0; j < ge.nbl; j++) {
+                        const unsigned voff = j == ge.nbl - 1 ? v_last16 : v_lane16;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * 1024u);
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                                     :: "v"(voff), "s"(base), "s"(dst) : "memory");
+                        base += 1024;
+                        slot = slot + 1 == NCH ? 0 : slot + 1;
+                    }
+                    row_qs += row_bytes;
+                }
+                {  // the group's scales: rows * nb f16, contiguous; 8 per lane
+                    const int n16 = (rows * ge.nb) >> 3;
+                    const unsigned dst = lds0 + slot * 1024u;
+                    const unsigned long long bq = (unsigned long long)(uintptr_t)grp_d;
+                    const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bq >> 32)) << 32) |
+                                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bq);
+                    if (lane < n16)
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                                     :: "v"(v_lane16), "s"(base), "s"(dst) : "memory");
+                    slot = slot + 1 == NCH ? 0 : slot + 1;
+                    grp_d += (unsigned)rows * row_dbytes;
+                }
+                issued += nchunks;
+                // at most 48 + a group of DMA instructions in flight; publish what has landed
+                asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+                if (issued > 48) __hip_atomic_store(&ctl->filled, issued - 48, REL_WG);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
