@@ -7,13 +7,14 @@
 // bit-for-bit against the same chain run as ordinary launches.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I. -o /tmp/engine_probe tests/tools/engine_probe.hip
-//   /tmp/engine_probe [chain] [nops] [NC]     chain: wo | ffn | layer
+//   /tmp/engine_probe [chain] [nops] [NC] [NL]     chain: wo | ffn | layer; NC consumer + NL loader waves per CU
 #include "../../llm_amd/csrc/kernels/decode.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -27,8 +28,8 @@ constexpr int NCH = 96;          // ring chunks of 1 KiB
 constexpr int RING_B = NCH * 1024;
 constexpr int NBP_MAX = 384;     // padded blocks of the widest activation (11008 / 32 = 344 -> 384)
 constexpr int XQ_B = NBP_MAX * 40;
-constexpr int CTL_OFF = RING_B + XQ_B;
-constexpr int OPS_OFF = CTL_OFF + 256;
+constexpr int CTL_OFF = RING_B + 2 * XQ_B;  // the activation is double-buffered by op parity (see the consumers)
+constexpr int OPS_OFF = CTL_OFF + 512;
 constexpr int MAX_OPS = 256;
 constexpr int LDS_B = OPS_OFF + MAX_OPS * 24;  // op descriptors live in LDS: a global load of one in the loader's loop
                                                // would make hipcc wait vmcnt(0) = drain the DMA pipe at every op
@@ -56,18 +57,13 @@ struct Args {
 };
 
 struct Ctl {
-    unsigned filled;     // chunks landed in the ring (loader -> consumers)
+    unsigned landed[4];  // per loader: how many of ITS groups have landed in the ring (loader -> consumers)
     unsigned err;
     unsigned bar;        // arrivals at the consumers' barrier (monotonic)
-    unsigned pad;
-    unsigned done[12];   // per consumer: first chunk index it still needs (consumers -> loader)
+    unsigned pad[2];
+    unsigned done[12];   // per consumer: first chunk index it still needs (consumers -> loaders)
+    unsigned fifo[4][16];  // per loader: cumulative DMA-instruction count at the end of each group in flight
 };
-
-__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 
 // chunk bookkeeping of one op for one CU: rows [r0, r0 + nrows) in groups of RS rows; a group = its rows' qs chunks
 // (nbl each) followed by ONE scale chunk (the scales of RS consecutive rows are contiguous: RS * nb * 2 <= 1024 B)
@@ -88,15 +84,39 @@ struct OpGeo {
     __device__ __forceinline__ int chunks_of(int g) const { return rows_of(g) * nbl + 1; }
     __device__ __forceinline__ int total() const { return ng == 0 ? 0 : (ng - 1) * cpg + chunks_of(ng - 1); }
 };
+// Walks the op list forward: groups are numbered globally (gg) across ops, chunks likewise (k).
+struct Cursor {
+    int oi;
+    unsigned gg0, kbase;  // first global group / first chunk of op oi
+    OpGeo ge;
+    __device__ __forceinline__ void start(const Op *ops, int nops, int cu, int ncu) {
+        oi = 0; gg0 = 0; kbase = 0;
+        if (nops > 0) ge.init(ops[0], cu, ncu);
+    }
+    // positions the cursor on the op that holds global group gg; false past the end
+    __device__ __forceinline__ bool seek(const Op *ops, int nops, int cu, int ncu, unsigned gg) {
+        while (oi < nops && gg >= gg0 + (unsigned)ge.ng) {
+            gg0 += (unsigned)ge.ng;
+            kbase += (unsigned)ge.total();
+            oi++;
+            if (oi < nops) ge.init(ops[oi], cu, ncu);
+        }
+        return oi < nops;
+    }
+    __device__ __forceinline__ unsigned k0(unsigned gg) const { return kbase + (gg - gg0) * (unsigned)ge.cpg; }
+};
 
-template <int NC>
-__global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
+template <int NBL>
+struct XFrag {  // this lane's activation blocks lane, lane + 64, ... held in registers for the whole op
+    i32x4 lo[NBL], hi[NBL];
+    float d[NBL];
+    int s[NBL];
+};
+
+template <int NC, int NL>
+__global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctl *ctl = (Ctl *)(smem + CTL_OFF);
-    i32x4 *s_lo = (i32x4 *)(smem + RING_B);
-    i32x4 *s_hi = s_lo + NBP_MAX;
-    float *s_d = (float *)(s_hi + NBP_MAX);
-    int *s_sum = (int *)(s_d + NBP_MAX);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cu = blockIdx.x, ncu = gridDim.x;
@@ -104,21 +124,19 @@ __global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
 
     const Op *s_ops = (const Op *)(smem + OPS_OFF);
     for (int i = tid; i < a.nops * 6; i += blockDim.x) ((int *)(smem + OPS_OFF))[i] = ((const int *)a.ops)[i];
-    if (tid < 64) {  // control words
-        if (lane == 0) { ctl->filled = 0; ctl->err = 0; ctl->bar = 0; }
-        if (lane < 12) ctl->done[lane] = 0;
-    }
+    for (int i = tid; i < (int)(sizeof(Ctl) / 4); i += blockDim.x) ((unsigned *)ctl)[i] = 0;
     __syncthreads();
 
-    if (wave == NC) {
-        // ================================ LOADER ================================
-        // One wave; its whole job is to keep LDS-DMA requests in flight, so the loop is kept to a few instructions per
-        // 1 KiB request: the row's address lives in a scalar register pair (advanced by scalar adds), every lane
-        // contributes a constant 32-bit offset (lane * 16; the last column step of a row whose length is not a
-        // multiple of 64 blocks clamps to the row's last block), the ring slot is a counter, space and pacing are
-        // checked once per row group.
+    if (wave >= NC) {
+        // ================================ LOADERS ================================
+        // NL waves; wave l streams the groups gg = l, l + NL, ...  Its whole job is to keep LDS-DMA requests in flight:
+        // the row's address lives in a scalar register pair, every lane contributes a constant 32-bit offset (lane * 16;
+        // the last column step of a row whose length is not a multiple of 64 blocks clamps to the row's last block),
+        // space and pacing are checked once per group.  vmcnt counts only this wave's requests, in order, so "at most 32
+        // newer requests outstanding" tells which of its groups have landed.
+        const int l = wave - NC;
         const long long t_start = wall_clock64();
-        unsigned issued = 0, slot = 0, min_done = 0;
+        unsigned instrs = 0, min_done = 0, own = 0 /* groups issued */, landed = 0, fhead = 0;
         long long stalls = 0;
         bool dead = false;
         const unsigned v_lane16 = (unsigned)lane * 16u;
@@ -131,80 +149,76 @@ __global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
             }
             return m;
         };
-        for (int oi = 0; oi < a.nops && !dead; oi++) {
-            const Op o = s_ops[oi];
-            OpGeo ge;
-            ge.init(o, cu, ncu);
-            const int last = (ge.nbl - 1) * 64 + lane;
-            const unsigned v_last16 = (unsigned)((last < ge.nb ? last : ge.nb - 1) - (ge.nbl - 1) * 64) * 16u;  // may be "negative": 32-bit wrap + 64-bit base is fine only if >= 0
-            // (nb - 1 >= (nbl - 1) * 64 always, so the clamped offset is never below the step's base)
-            const uint8_t *row_qs = a.wqs + o.qs_off + (size_t)ge.r0 * ge.nb * 16;   // wave-uniform
-            const char *grp_d = (const char *)(a.wd + o.d_off + (size_t)ge.r0 * ge.nb);
-            const unsigned row_bytes = (unsigned)ge.nb * 16u, row_dbytes = (unsigned)ge.nb * 2u;
-            for (int g = 0; g < ge.ng && !dead; g++) {
-                const int rows = ge.rows_of(g);
-                const unsigned nchunks = (unsigned)(rows * ge.nbl + 1);
-                // ring space for the whole group
-                if (issued + nchunks > min_done + NCH) min_done = read_min();
-                if (issued + nchunks > min_done + NCH) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // blocked anyway: publish everything in flight
-                    __hip_atomic_store(&ctl->filled, issued, REL_WG);
-                    unsigned spins = 0;
-                    for (;;) {
-                        min_done = read_min();
-                        if (issued + nchunks <= min_done + NCH) break;
-                        stalls++;
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
-                    }
-                    if (dead) break;
+        auto retire = [&](unsigned upto) {  // groups whose last request is among the first `upto` have landed
+            while (fhead != own && ctl->fifo[l][fhead & 15] <= upto) { fhead++; landed++; }
+            __hip_atomic_store(&ctl->landed[l], landed, REL_WG);
+        };
+        Cursor cur;
+        cur.start(s_ops, a.nops, cu, ncu);
+        for (unsigned gg = (unsigned)l; !dead; gg += NL) {
+            if (!cur.seek(s_ops, a.nops, cu, ncu, gg)) break;
+            const Op o = s_ops[cur.oi];
+            const OpGeo &ge = cur.ge;
+            const int g = (int)(gg - cur.gg0);
+            const int rows = ge.rows_of(g), row0 = ge.r0 + g * ge.RS;
+            const unsigned nchunks = (unsigned)(rows * ge.nbl + 1), k0 = cur.k0(gg);
+            // ring space for the whole group
+            if (k0 + nchunks > min_done + NCH) min_done = read_min();
+            if (k0 + nchunks > min_done + NCH || own - fhead >= 15) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // blocked anyway: everything in flight lands
+                retire(instrs);
+                unsigned spins = 0;
+                for (;;) {
+                    min_done = read_min();
+                    if (k0 + nchunks <= min_done + NCH) break;
+                    stalls++;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
                 }
-                for (int r = 0; r < rows; r++) {
-                    unsigned long long base;
-                    {  // provably wave-uniform for the compiler: an "s" operand needs it
-                        const unsigned long long bq = (unsigned long long)(uintptr_t)row_qs;
-                        base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bq >> 32)) << 32) |
-                               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bq);
-                    }
-                    for (int j = 0; j < ge.nbl; j++) {
-                        const unsigned voff = j == ge.nbl - 1 ? v_last16 : v_lane16;
-                        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * 1024u);
-                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-                                     :: "v"(voff), "s"(base), "s"(dst) : "memory");
-                        base += 1024;
-                        slot = slot + 1 == NCH ? 0 : slot + 1;
-                    }
-                    row_qs += row_bytes;
-                }
-                {  // the group's scales: rows * nb f16, contiguous; 8 per lane
-                    const int n16 = (rows * ge.nb) >> 3;
-                    const unsigned dst = lds0 + slot * 1024u;
-                    const unsigned long long bq = (unsigned long long)(uintptr_t)grp_d;
-                    const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bq >> 32)) << 32) |
-                                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bq);
-                    if (lane < n16)
-                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-                                     :: "v"(v_lane16), "s"(base), "s"(dst) : "memory");
-                    slot = slot + 1 == NCH ? 0 : slot + 1;
-                    grp_d += (unsigned)rows * row_dbytes;
-                }
-                issued += nchunks;
-                // at most 48 + a group of DMA instructions in flight; publish what has landed
-                asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-                if (issued > 48) __hip_atomic_store(&ctl->filled, issued - 48, REL_WG);
+                if (dead) break;
             }
+            unsigned slot = k0 % NCH;
+            const int last = (ge.nbl - 1) * 64 + lane;
+            const unsigned v_last16 = (unsigned)((last < ge.nb ? last : ge.nb - 1) - (ge.nbl - 1) * 64) * 16u;
+            const unsigned long long q0 = (unsigned long long)(uintptr_t)(a.wqs + o.qs_off + (size_t)row0 * ge.nb * 16);
+            unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q0 >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q0);
+            for (int r = 0; r < rows; r++) {
+                for (int j = 0; j < ge.nbl; j++) {
+                    const unsigned voff = j == ge.nbl - 1 ? v_last16 : v_lane16;
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * 1024u);
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(dst) : "memory");
+                    base += 1024;
+                    slot = slot + 1 == NCH ? 0 : slot + 1;
+                }
+                base += (unsigned long long)(unsigned)(ge.nb * 16 - ge.nbl * 1024);  // next row (rows are nb * 16 B apart)
+            }
+            {  // the group's scales: rows * nb f16, contiguous; 8 per lane
+                const int n16 = (rows * ge.nb) >> 3;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * 1024u);
+                const unsigned long long d0 = (unsigned long long)(uintptr_t)(a.wd + o.d_off + (size_t)row0 * ge.nb);
+                const unsigned long long dbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(d0 >> 32)) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)d0);
+                if (lane < n16)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(v_lane16), "s"(dbase), "s"(dst) : "memory");
+            }
+            instrs += nchunks;
+            ctl->fifo[l][own & 15] = instrs;
+            own++;
+            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            if (instrs > 40) retire(instrs - 40);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&ctl->filled, issued, REL_WG);
+        retire(instrs);
         if (dead) {
             __hip_atomic_store(&ctl->err, 1u, RLX_WG);
             if (lane == 0) atomicOr(a.err, 1u);
         }
-        if (lane == 0) {
+        if (lane == 0 && l == 0) {
             a.lts[cu * 4 + 0] = t_start;
             a.lts[cu * 4 + 1] = wall_clock64();
             a.lts[cu * 4 + 2] = stalls;
-            a.lts[cu * 4 + 3] = issued;
+            a.lts[cu * 4 + 3] = instrs;
         }
         return;
     }
@@ -213,7 +227,7 @@ __global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
     const int w = wave;  // 0..NC-1
     unsigned bar_target = 0;
     bool dead = false;
-    auto cbarrier = [&]() {  // barrier among the NC consumer waves (the loader never joins one)
+    auto cbarrier = [&]() {  // barrier among the NC consumer waves (the loaders never join one)
         bar_target += NC;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(&ctl->bar, 1u, REL_WG);
@@ -223,19 +237,77 @@ __global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
             if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
         }
     };
-    unsigned kbase = 0;  // chunk index of the current op's first chunk
+    Cursor cur, nxt;
+    cur.start(s_ops, a.nops, cu, ncu);
+    nxt.start(s_ops, a.nops, cu, ncu);
+    unsigned gg = (unsigned)w;  // this wave's next global group
+    // rows of one group out of the ring: rows in pairs, all LDS reads of a pair issued before its arithmetic
+    auto group_rows = [&](auto nbl_tag, const OpGeo &ge, unsigned k0, int rows, const auto &xf) -> float {
+        constexpr int NBL = decltype(nbl_tag)::value;
+        const int nb = ge.nb;
+        float myv = 0.0f;
+        const unsigned ssl = (k0 + (unsigned)(rows * NBL)) % NCH;
+        const char *sc = smem + ssl * 1024;
+        unsigned sl = k0 % NCH;
+        for (int r = 0; r < rows; r += 2) {
+            const bool two = r + 1 < rows;
+            u32x4 q[2][NBL];
+            float dw[2][NBL];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int j = 0; j < NBL; j++) {
+                    unsigned s2 = sl + (unsigned)(rr * NBL + j);
+                    s2 = s2 >= NCH ? s2 - NCH : s2;
+                    s2 = (rr == 1 && !two) ? sl : s2;  // no second row: re-read a valid slot, result unused
+                    const int b = j * 64 + lane, bc = b < nb ? b : nb - 1;
+                    q[rr][j] = *(const u32x4 *)(smem + s2 * 1024 + lane * 16);
+                    dw[rr][j] = __half2float(*(const __half *)(sc + (((rr == 1 && !two) ? r : r + rr) * nb + bc) * 2));
+                }
+            float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int j = 0; j < NBL; j++) {
+                    const int b = j * 64 + lane;
+                    const float t = block_dot<QT_Q4_0>(q[rr][j], q[rr][j], 0u, dw[rr][j], 0.0f, xf.lo[j], xf.hi[j], xf.d[j], xf.s[j]);
+                    acc[rr] += b < nb ? t : 0.0f;  // x blocks past the row end are zero, but the weight bytes there are not this row's
+                }
+            const float v0 = wave_sum_f32(acc[0]);
+            myv = lane == r ? v0 : myv;
+            if (two) {
+                const float v1 = wave_sum_f32(acc[1]);
+                myv = lane == r + 1 ? v1 : myv;
+            }
+            sl += 2 * NBL;
+            sl = sl >= NCH ? sl - NCH : sl;
+        }
+        return myv;
+    };
     for (int oi = 0; oi < a.nops; oi++) {
         const Op o = s_ops[oi];
-        OpGeo ge;
-        ge.init(o, cu, ncu);
+        cur.seek(s_ops, a.nops, cu, ncu, cur.gg0);  // no-op; cur follows oi below
+        while (cur.oi < oi) {
+            cur.gg0 += (unsigned)cur.ge.ng;
+            cur.kbase += (unsigned)cur.ge.total();
+            cur.oi++;
+            cur.ge.init(s_ops[cur.oi], cu, ncu);
+        }
+        const OpGeo &ge = cur.ge;
         const int nb = ge.nb, nbp = ge.nbl * 64;
+        // The Q8 activation of op oi lives in buffer oi & 1: a wave that is already gathering for op oi + 1 writes the
+        // other buffer while a slower wave may still be loading its fragments of op oi; the gather barrier of op oi + 1
+        // is passed by every wave before anyone writes buffer oi & 1 again.
+        i32x4 *s_lo = (i32x4 *)(smem + RING_B + (oi & 1) * XQ_B);
+        i32x4 *s_hi = s_lo + NBP_MAX;
+        float *s_d = (float *)(s_hi + NBP_MAX);
+        int *s_sum = (int *)(s_d + NBP_MAX);
         const unsigned tag = a.epoch0 + (unsigned)oi;
         const bool rec = cu == 0 && w == 0 && lane == 0;
         if (rec) a.ts[oi * 4 + 0] = wall_clock64();
         // ---- 1. the activation: gather the previous op's granules (or x0), re-quantize to Q8 into LDS ----
         if (a.mode == 0) {
-            // zero the padded blocks
-            for (int i = nb + w * 64 + lane; i < nbp; i += NC * 64) {
+            for (int i = nb + w * 64 + lane; i < nbp; i += NC * 64) {  // zero the padded blocks
                 s_lo[i] = i32x4{0, 0, 0, 0};
                 s_hi[i] = i32x4{0, 0, 0, 0};
                 s_d[i] = 0.0f;
@@ -289,87 +361,61 @@ __global__ void __launch_bounds__((NC + 1) * 64) k_engine(const Args a) {
             cbarrier();
         }
         if (rec) a.ts[oi * 4 + 1] = wall_clock64();
-        // ---- 2. this wave's row groups ----
+        // ---- 2. this wave's row groups of this op ----
         u64 *dstg = a.gran + (size_t)(oi & 1) * a.gmax;
-        for (int g = w; g < ge.ng && !dead; g += NC) {
-            const unsigned k0 = kbase + (unsigned)g * ge.cpg;
-            const int rows = ge.rows_of(g), nchunks = rows * ge.nbl + 1;
-            {  // wait until the group has landed
-                unsigned spins = 0;
-                while (__hip_atomic_load(&ctl->filled, ACQ_WG) < k0 + nchunks) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
-                }
-                if (dead) break;
-            }
-            float myv = 0.0f;
+        auto run_groups = [&](auto nbl_tag) {
+            constexpr int NBL = decltype(nbl_tag)::value;
+            XFrag<NBL> xf;
             if (a.mode == 0) {
-                const char *sc = smem + ((k0 + rows * ge.nbl) % NCH) * 1024;
-                for (int r = 0; r < rows; r++) {
-                    float acc = 0.0f;
-                    for (int j = 0; j < ge.nbl; j++) {
-                        const int b = j * 64 + lane;
-                        const char *ch = smem + ((k0 + r * ge.nbl + j) % NCH) * 1024;
-                        if (b < nb) {
-                            const u32x4 q = *(const u32x4 *)(ch + lane * 16);
-                            const float dw = __half2float(*(const __half *)(sc + (r * nb + b) * 2));
-                            acc += block_dot<QT_Q4_0>(q, q, 0u, dw, 0.0f, s_lo[b], s_hi[b], s_d[b], s_sum[b]);
-                        }
-                    }
-                    const float v = wave_sum_f32(acc);
-                    myv = lane == r ? v : myv;
+#pragma unroll
+                for (int j = 0; j < NBL; j++) {
+                    const int b = j * 64 + lane;  // < nbp: padded blocks are zero
+                    xf.lo[j] = s_lo[b]; xf.hi[j] = s_hi[b]; xf.d[j] = s_d[b]; xf.s[j] = s_sum[b];
                 }
             }
-            // this wave needs nothing below its next group any more
-            {
-                unsigned nxt;
-                if (g + NC < ge.ng) {
-                    nxt = kbase + (unsigned)(g + NC) * ge.cpg;
-                } else {  // first group of this wave in a later op
-                    nxt = 0xffffffffu;
-                    unsigned kb = kbase + (unsigned)ge.total();
-                    for (int oj = oi + 1; oj < a.nops; oj++) {
-                        OpGeo gj;
-                        gj.init(s_ops[oj], cu, ncu);
-                        if (w < gj.ng) { nxt = kb + (unsigned)w * gj.cpg; break; }
-                        kb += (unsigned)gj.total();
+            for (; gg < cur.gg0 + (unsigned)ge.ng && !dead; gg += NC) {
+                const int g = (int)(gg - cur.gg0);
+                const unsigned k0 = cur.k0(gg);
+                const int rows = ge.rows_of(g);
+                {  // wait until the group has landed
+                    const unsigned ld = gg % NL, need = gg / NL + 1;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&ctl->landed[ld], ACQ_WG) < need) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
                     }
+                    if (dead) break;
                 }
+                float myv = 0.0f;
+                if (a.mode == 0) myv = group_rows(nbl_tag, ge, k0, rows, xf);
+                // this wave needs nothing below its next group any more
+                unsigned nk = 0xffffffffu;
+                if (nxt.seek(s_ops, a.nops, cu, ncu, gg + NC)) nk = nxt.k0(gg + NC);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&ctl->done[w], nxt, REL_WG);
-            }
-            // publish: lane r holds row r of the group
-            if (a.mode == 0 && lane < rows) {
-                const int m = ge.r0 + g * ge.RS + lane;
-                __hip_atomic_store(dstg + m, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, myv), RLX_AGENT);
-                a.vecs[(size_t)oi * a.gmax + m] = myv;
-            }
-        }
-        if (w >= ge.ng && !dead) {  // a wave without a group in this op still has to release the ring
-            // (its done[] already points at its next group or beyond: set when it finished its last group, or 0 at start)
-            if (__hip_atomic_load(&ctl->done[w], RLX_WG) < kbase + (unsigned)ge.total()) {
-                unsigned nxt = 0xffffffffu, kb = kbase + (unsigned)ge.total();
-                for (int oj = oi + 1; oj < a.nops; oj++) {
-                    OpGeo gj;
-                    gj.init(s_ops[oj], cu, ncu);
-                    if (w < gj.ng) { nxt = kb + (unsigned)w * gj.cpg; break; }
-                    kb += (unsigned)gj.total();
+                if (lane == 0) __hip_atomic_store(&ctl->done[w], nk, REL_WG);
+                // publish: lane r holds row r of the group
+                if (a.mode == 0 && lane < rows) {
+                    const int m = ge.r0 + g * ge.RS + lane;
+                    __hip_atomic_store(dstg + m, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, myv), RLX_AGENT);
+                    a.vecs[(size_t)oi * a.gmax + m] = myv;
                 }
-                if (lane == 0) __hip_atomic_store(&ctl->done[w], nxt, REL_WG);
             }
+        };
+        switch (ge.nbl) {
+            case 2: run_groups(std::integral_constant<int, 2>{}); break;
+            case 6: run_groups(std::integral_constant<int, 6>{}); break;
+            default: dead = true; break;  // probe: only the 7B row widths
         }
         if (rec) a.ts[oi * 4 + 2] = wall_clock64();
-        kbase += (unsigned)ge.total();
         if (dead) break;
-        // the activation area is rewritten by the next op's gather: every wave must be done reading it
-        if (a.mode == 0) cbarrier();
+        // the activation area is rewritten by the next op's gather: every wave must be done reading it (x lives in
+        // registers during the dots, so this is only the loads of XFrag) — one barrier per op suffices with the one above
         if (rec) a.ts[oi * 4 + 3] = wall_clock64();
     }
     if (dead) {
         __hip_atomic_store(&ctl->err, 1u, RLX_WG);
         if (lane == 0) atomicOr(a.err, 2u);
-        // unblock the loader
-        if (lane == 0) __hip_atomic_store(&ctl->done[w], 0xffffffffu, REL_WG);
+        if (lane == 0) __hip_atomic_store(&ctl->done[w], 0xffffffffu, REL_WG);  // unblock the loaders
     }
 }
 
@@ -425,20 +471,21 @@ __global__ void k_fill(uint8_t *qs, __half *wd, size_t nblk, unsigned seed) {
     wd[i] = __float2half(0.0015f + 0.001f * (float)(s >> 24) / 256.0f);
 }
 
-template <int NC>
+template <int NC, int NL>
 static void run_engine(const Args &a, int G, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         attr = true;
-        CK(hipFuncSetAttribute((const void *)k_engine<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        CK(hipFuncSetAttribute((const void *)k_engine<NC, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
     }
-    hipLaunchKernelGGL(k_engine<NC>, dim3(G), dim3((NC + 1) * 64), LDS_B, st, a);
+    hipLaunchKernelGGL((k_engine<NC, NL>), dim3(G), dim3((NC + NL) * 64), LDS_B, st, a);
 }
 
 int main(int argc, char **argv) {
     const char *chain = argc > 1 ? argv[1] : "ffn";
     const int nops = std::min(argc > 2 ? atoi(argv[2]) : 64, MAX_OPS);
-    const int NC = argc > 3 ? atoi(argv[3]) : 3;
+    const int NC = argc > 3 ? atoi(argv[3]) : 6;
+    const int NL = argc > 4 ? atoi(argv[4]) : 2;
     hipDeviceProp_t pr;
     CK(hipGetDeviceProperties(&pr, 0));
     const int G = pr.multiProcessorCount;
@@ -463,7 +510,7 @@ int main(int argc, char **argv) {
     }
     double total_bytes = 0;
     for (auto &o : ops) total_bytes += (double)o.K / 32 * o.M * 18;
-    printf("device %s CUs %d | chain %s, %d ops, NC %d, %.1f MB of weights per run\n", pr.gcnArchName, G, chain, nops, NC,
+    printf("device %s CUs %d | chain %s, %d ops, NC %d NL %d, %.1f MB of weights per run\n", pr.gcnArchName, G, chain, nops, NC, NL,
            total_bytes / 1e6);
     uint8_t *wqs;
     __half *wd;
@@ -531,12 +578,14 @@ int main(int argc, char **argv) {
     auto launch = [&](int mode, unsigned epoch) {
         a.mode = mode;
         a.epoch0 = epoch;
-        switch (NC) {
-            case 3: run_engine<3>(a, G, st); break;
-            case 5: run_engine<5>(a, G, st); break;
-            case 7: run_engine<7>(a, G, st); break;
-            case 11: run_engine<11>(a, G, st); break;
-            default: printf("NC must be 3, 5, 7 or 11\n"); exit(1);
+        switch (NC * 10 + NL) {
+            case 31: run_engine<3, 1>(a, G, st); break;
+            case 71: run_engine<7, 1>(a, G, st); break;
+            case 62: run_engine<6, 2>(a, G, st); break;
+            case 42: run_engine<4, 2>(a, G, st); break;
+            case 63: run_engine<6, 3>(a, G, st); break;
+            case 93: run_engine<9, 3>(a, G, st); break;
+            default: printf("(NC, NL) must be one of (3,1) (7,1) (4,2) (6,2) (6,3) (9,3)\n"); exit(1);
         }
         CK(hipGetLastError());
     };
