@@ -128,15 +128,15 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
     __syncthreads();
 
     if (wave >= NC) {
-        // ================================ LOADERS ================================
-        // NL waves; wave l streams the groups gg = l, l + NL, ...  Its whole job is to keep LDS-DMA requests in flight:
-        // the row's address lives in a scalar register pair, every lane contributes a constant 32-bit offset (lane * 16;
-        // the last column step of a row whose length is not a multiple of 64 blocks clamps to the row's last block),
-        // space and pacing are checked once per group.  vmcnt counts only this wave's requests, in order, so "at most 32
-        // newer requests outstanding" tells which of its groups have landed.
-        const int l = wave - NC;
+        // ================================ LOADER ================================
+        // One wave (NL must be 1 in this version) whose whole job is to keep LDS-DMA requests in flight, so the loop is a
+        // handful of scalar instructions per 1 KiB request: a row is one asm statement (M0 = ring slot, the row's address in
+        // a scalar register pair, every lane a constant 32-bit offset: lane * 16, clamped to the row's last block in the last
+        // column step), a group's ring slots are contiguous (a group that would wrap skips to slot 0: consumers apply the
+        // same rule), and the number of requests still outstanding is READ (s_getreg IB_STS.VM_CNT), not waited for, so
+        // what has landed is published at once.
         const long long t_start = wall_clock64();
-        unsigned instrs = 0, min_done = 0, own = 0 /* groups issued */, landed = 0, fhead = 0;
+        unsigned issued = 0 /* chunk index incl. skipped slots */, slot = 0, min_done = 0, req = 0 /* requests issued */;
         long long stalls = 0;
         bool dead = false;
         const unsigned v_lane16 = (unsigned)lane * 16u;
@@ -149,76 +149,98 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
             }
             return m;
         };
-        auto retire = [&](unsigned upto) {  // groups whose last request is among the first `upto` have landed
-            while (fhead != own && ctl->fifo[l][fhead & 15] <= upto) { fhead++; landed++; }
-            __hip_atomic_store(&ctl->landed[l], landed, REL_WG);
+        // chunk index up to which everything has landed: requests land in order, `outstanding` of them are in flight,
+        // and request number -> chunk index is kept for the last 64 requests in an LDS table (skips make it non-trivial)
+        unsigned *rq2k = ctl->fifo[0];  // [64]: chunk index AFTER request r (r mod 64)
+        auto publish = [&](unsigned outstanding) {
+            const unsigned r = req - outstanding;  // requests landed
+            if (r == 0) return;
+            const unsigned k = rq2k[(r - 1) & 63];
+            __hip_atomic_store(&ctl->landed[0], k, REL_WG);
         };
-        Cursor cur;
-        cur.start(s_ops, a.nops, cu, ncu);
-        for (unsigned gg = (unsigned)l; !dead; gg += NL) {
-            if (!cur.seek(s_ops, a.nops, cu, ncu, gg)) break;
-            const Op o = s_ops[cur.oi];
-            const OpGeo &ge = cur.ge;
-            const int g = (int)(gg - cur.gg0);
-            const int rows = ge.rows_of(g), row0 = ge.r0 + g * ge.RS;
-            const unsigned nchunks = (unsigned)(rows * ge.nbl + 1), k0 = cur.k0(gg);
-            // ring space for the whole group
-            if (k0 + nchunks > min_done + NCH) min_done = read_min();
-            if (k0 + nchunks > min_done + NCH || own - fhead >= 15) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // blocked anyway: everything in flight lands
-                retire(instrs);
-                unsigned spins = 0;
-                for (;;) {
-                    min_done = read_min();
-                    if (k0 + nchunks <= min_done + NCH) break;
-                    stalls++;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
-                }
-                if (dead) break;
-            }
-            unsigned slot = k0 % NCH;
+        for (int oi = 0; oi < a.nops && !dead; oi++) {
+            const Op o = s_ops[oi];
+            OpGeo ge;
+            ge.init(o, cu, ncu);
             const int last = (ge.nbl - 1) * 64 + lane;
-            const unsigned v_last16 = (unsigned)((last < ge.nb ? last : ge.nb - 1) - (ge.nbl - 1) * 64) * 16u;
-            const unsigned long long q0 = (unsigned long long)(uintptr_t)(a.wqs + o.qs_off + (size_t)row0 * ge.nb * 16);
+            // second request of a pair: + 1024 relative to the pair's base; in the row's last step clamped to its last block
+            const unsigned v_lane16p = v_lane16 + 1024u;
+            const unsigned v_last16p = (unsigned)((last < ge.nb ? last : ge.nb - 1) - (ge.nbl - 1) * 64) * 16u + 1024u;
+            const unsigned long long q0 = (unsigned long long)(uintptr_t)(a.wqs + o.qs_off + (size_t)ge.r0 * ge.nb * 16);
             unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q0 >> 32)) << 32) |
                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q0);
-            for (int r = 0; r < rows; r++) {
-                for (int j = 0; j < ge.nbl; j++) {
-                    const unsigned voff = j == ge.nbl - 1 ? v_last16 : v_lane16;
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * 1024u);
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(dst) : "memory");
-                    base += 1024;
-                    slot = slot + 1 == NCH ? 0 : slot + 1;
+            const unsigned long long d0 = (unsigned long long)(uintptr_t)(a.wd + o.d_off + (size_t)ge.r0 * ge.nb);
+            unsigned long long dbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(d0 >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)d0);
+            const unsigned row_bytes = (unsigned)ge.nb * 16u;
+            for (int g = 0; g < ge.ng && !dead; g++) {
+                const int rows = ge.rows_of(g);
+                const unsigned nchunks = (unsigned)(rows * ge.nbl + 1);
+                if (slot + nchunks > NCH) {  // the group's slots are contiguous: skip the tail of the ring
+                    issued += NCH - slot;
+                    slot = 0;
                 }
-                base += (unsigned long long)(unsigned)(ge.nb * 16 - ge.nbl * 1024);  // next row (rows are nb * 16 B apart)
+                if (issued + nchunks > min_done + NCH) min_done = read_min();
+                if (issued + nchunks > min_done + NCH) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // blocked anyway: everything in flight lands
+                    publish(0);
+                    unsigned spins = 0;
+                    for (;;) {
+                        min_done = read_min();
+                        if (issued + nchunks <= min_done + NCH) break;
+                        stalls++;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
+                    }
+                    if (dead) break;
+                }
+                unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * 1024u);
+                for (int r = 0; r < rows; r++) {
+                    // column steps in pairs (nbl is even for the probe's shapes): requests j and j + 1 of the row
+                    unsigned long long b2 = base;
+                    for (int j = 0; j < ge.nbl; j += 2) {
+                        const unsigned vb = j + 2 == ge.nbl ? v_last16p : v_lane16p;
+                        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt\n\t"
+                                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
+                                     ::"v"(v_lane16), "v"(vb), "s"(b2), "s"(dst) : "memory");
+                        b2 += 2048;
+                        dst += 2048;
+                    }
+                    base += row_bytes;
+                }
+                {  // the group's scales: rows * nb f16, contiguous; 8 per lane
+                    const int n16 = (rows * ge.nb) >> 3;
+                    if (lane < n16)
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(v_lane16), "s"(dbase), "s"(dst) : "memory");
+                    dbase += (unsigned)(rows * ge.nb * 2);
+                }
+                // request -> chunk table (one entry per request; only the group's last one is ever looked up precisely,
+                // the others point at the group start so that a partially landed group is not published)
+                for (unsigned i = lane; i < nchunks; i += 64) rq2k[(req + i) & 63] = i == nchunks - 1 ? issued + nchunks : issued;
+                req += nchunks;
+                issued += nchunks;
+                slot += nchunks;
+                unsigned vm_lo, vm_hi;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_IB_STS, 0, 4)\n\ts_getreg_b32 %1, hwreg(HW_REG_IB_STS, 22, 2)" : "=s"(vm_lo), "=s"(vm_hi));
+                unsigned vm = vm_lo | (vm_hi << 4);
+                if (vm > 44) {
+                    asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+                    vm = 36;
+                }
+                publish(vm);
             }
-            {  // the group's scales: rows * nb f16, contiguous; 8 per lane
-                const int n16 = (rows * ge.nb) >> 3;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * 1024u);
-                const unsigned long long d0 = (unsigned long long)(uintptr_t)(a.wd + o.d_off + (size_t)row0 * ge.nb);
-                const unsigned long long dbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(d0 >> 32)) << 32) |
-                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)d0);
-                if (lane < n16)
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(v_lane16), "s"(dbase), "s"(dst) : "memory");
-            }
-            instrs += nchunks;
-            ctl->fifo[l][own & 15] = instrs;
-            own++;
-            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-            if (instrs > 40) retire(instrs - 40);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        retire(instrs);
+        publish(0);
         if (dead) {
             __hip_atomic_store(&ctl->err, 1u, RLX_WG);
             if (lane == 0) atomicOr(a.err, 1u);
         }
-        if (lane == 0 && l == 0) {
+        if (lane == 0) {
             a.lts[cu * 4 + 0] = t_start;
             a.lts[cu * 4 + 1] = wall_clock64();
             a.lts[cu * 4 + 2] = stalls;
-            a.lts[cu * 4 + 3] = instrs;
+            a.lts[cu * 4 + 3] = req;
         }
         return;
     }
@@ -227,7 +249,7 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
     const int w = wave;  // 0..NC-1
     unsigned bar_target = 0;
     bool dead = false;
-    auto cbarrier = [&]() {  // barrier among the NC consumer waves (the loaders never join one)
+    auto cbarrier = [&]() {  // barrier among the NC consumer waves (the loader never joins one)
         bar_target += NC;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(&ctl->bar, 1u, REL_WG);
@@ -237,18 +259,40 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
             if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
         }
     };
-    Cursor cur, nxt;
-    cur.start(s_ops, a.nops, cu, ncu);
-    nxt.start(s_ops, a.nops, cu, ncu);
-    unsigned gg = (unsigned)w;  // this wave's next global group
+    // The loader's ring walk, replayed: position in front of group (oi, g); k = chunk index, slot = k mod NCH.
+    struct Walk {
+        int oi, g;
+        unsigned k, slot, gg;
+        OpGeo ge;
+    };
+    auto walk_init = [&](Walk &x) {
+        x.oi = 0; x.g = 0; x.k = 0; x.slot = 0; x.gg = 0;
+        x.ge.init(s_ops[0], cu, ncu);
+        while (x.oi < a.nops && x.ge.ng == 0) { x.oi++; if (x.oi < a.nops) x.ge.init(s_ops[x.oi], cu, ncu); }
+    };
+    auto walk_k0 = [&](const Walk &x) -> unsigned {  // first chunk of the group in front (after the wrap skip)
+        const unsigned n = (unsigned)x.ge.chunks_of(x.g);
+        return x.slot + n > NCH ? x.k + (NCH - x.slot) : x.k;
+    };
+    auto walk_step = [&](Walk &x) {  // pass the group in front
+        const unsigned n = (unsigned)x.ge.chunks_of(x.g);
+        if (x.slot + n > NCH) { x.k += NCH - x.slot; x.slot = 0; }
+        x.k += n; x.slot += n; x.gg++;
+        if (++x.g == x.ge.ng) {
+            x.g = 0;
+            do { x.oi++; if (x.oi < a.nops) x.ge.init(s_ops[x.oi], cu, ncu); } while (x.oi < a.nops && x.ge.ng == 0);
+        }
+    };
+    Walk cur, nx;
+    walk_init(cur);
+    walk_init(nx);
     // rows of one group out of the ring: rows in pairs, all LDS reads of a pair issued before its arithmetic
-    auto group_rows = [&](auto nbl_tag, const OpGeo &ge, unsigned k0, int rows, const auto &xf) -> float {
+    auto group_rows = [&](auto nbl_tag, const OpGeo &ge, unsigned slot0, int rows, const auto &xf) -> float {
         constexpr int NBL = decltype(nbl_tag)::value;
         const int nb = ge.nb;
         float myv = 0.0f;
-        const unsigned ssl = (k0 + (unsigned)(rows * NBL)) % NCH;
-        const char *sc = smem + ssl * 1024;
-        unsigned sl = k0 % NCH;
+        const char *sc = smem + (slot0 + (unsigned)(rows * NBL)) * 1024;  // the group's slots are contiguous
+        const char *rowp = smem + slot0 * 1024;
         for (int r = 0; r < rows; r += 2) {
             const bool two = r + 1 < rows;
             u32x4 q[2][NBL];
@@ -257,12 +301,10 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
             for (int rr = 0; rr < 2; rr++)
 #pragma unroll
                 for (int j = 0; j < NBL; j++) {
-                    unsigned s2 = sl + (unsigned)(rr * NBL + j);
-                    s2 = s2 >= NCH ? s2 - NCH : s2;
-                    s2 = (rr == 1 && !two) ? sl : s2;  // no second row: re-read a valid slot, result unused
+                    const int ro = (rr == 1 && !two) ? 0 : rr;  // no second row: re-read the first, result unused
                     const int b = j * 64 + lane, bc = b < nb ? b : nb - 1;
-                    q[rr][j] = *(const u32x4 *)(smem + s2 * 1024 + lane * 16);
-                    dw[rr][j] = __half2float(*(const __half *)(sc + (((rr == 1 && !two) ? r : r + rr) * nb + bc) * 2));
+                    q[rr][j] = *(const u32x4 *)(rowp + (ro * NBL + j) * 1024 + lane * 16);
+                    dw[rr][j] = __half2float(*(const __half *)(sc + ((r + ro) * nb + bc) * 2));
                 }
             float acc[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -271,7 +313,7 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
                 for (int j = 0; j < NBL; j++) {
                     const int b = j * 64 + lane;
                     const float t = block_dot<QT_Q4_0>(q[rr][j], q[rr][j], 0u, dw[rr][j], 0.0f, xf.lo[j], xf.hi[j], xf.d[j], xf.s[j]);
-                    acc[rr] += b < nb ? t : 0.0f;  // x blocks past the row end are zero, but the weight bytes there are not this row's
+                    acc[rr] += b < nb ? t : 0.0f;  // the weight bytes past the row end are not this row's
                 }
             const float v0 = wave_sum_f32(acc[0]);
             myv = lane == r ? v0 : myv;
@@ -279,21 +321,14 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
                 const float v1 = wave_sum_f32(acc[1]);
                 myv = lane == r + 1 ? v1 : myv;
             }
-            sl += 2 * NBL;
-            sl = sl >= NCH ? sl - NCH : sl;
+            rowp += 2 * NBL * 1024;
         }
         return myv;
     };
     for (int oi = 0; oi < a.nops; oi++) {
         const Op o = s_ops[oi];
-        cur.seek(s_ops, a.nops, cu, ncu, cur.gg0);  // no-op; cur follows oi below
-        while (cur.oi < oi) {
-            cur.gg0 += (unsigned)cur.ge.ng;
-            cur.kbase += (unsigned)cur.ge.total();
-            cur.oi++;
-            cur.ge.init(s_ops[cur.oi], cu, ncu);
-        }
-        const OpGeo &ge = cur.ge;
+        OpGeo ge;
+        ge.init(o, cu, ncu);
         const int nb = ge.nb, nbp = ge.nbl * 64;
         // The Q8 activation of op oi lives in buffer oi & 1: a wave that is already gathering for op oi + 1 writes the
         // other buffer while a slower wave may still be loading its fragments of op oi; the gather barrier of op oi + 1
@@ -373,32 +408,34 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
                     xf.lo[j] = s_lo[b]; xf.hi[j] = s_hi[b]; xf.d[j] = s_d[b]; xf.s[j] = s_sum[b];
                 }
             }
-            for (; gg < cur.gg0 + (unsigned)ge.ng && !dead; gg += NC) {
-                const int g = (int)(gg - cur.gg0);
-                const unsigned k0 = cur.k0(gg);
+            while (cur.oi == oi && !dead) {
+                const int g = cur.g;
+                const unsigned gg = cur.gg, k0 = walk_k0(cur), n = (unsigned)ge.chunks_of(g);
                 const int rows = ge.rows_of(g);
-                {  // wait until the group has landed
-                    const unsigned ld = gg % NL, need = gg / NL + 1;
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(&ctl->landed[ld], ACQ_WG) < need) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
+                if (gg % NC == (unsigned)w) {
+                    {  // wait until the group has landed
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(&ctl->landed[0], ACQ_WG) < k0 + n) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl->err, RLX_WG)) { dead = true; break; }
+                        }
+                        if (dead) break;
                     }
-                    if (dead) break;
+                    float myv = 0.0f;
+                    if (a.mode == 0) myv = group_rows(nbl_tag, ge, k0 % NCH, rows, xf);
+                    // this wave needs nothing below its next group (gg + NC) any more
+                    while (nx.oi < a.nops && nx.gg < gg + NC) walk_step(nx);
+                    const unsigned nk = nx.oi < a.nops ? walk_k0(nx) : 0xffffffffu;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&ctl->done[w], nk, REL_WG);
+                    // publish: lane r holds row r of the group
+                    if (a.mode == 0 && lane < rows) {
+                        const int m = ge.r0 + g * ge.RS + lane;
+                        __hip_atomic_store(dstg + m, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, myv), RLX_AGENT);
+                        a.vecs[(size_t)oi * a.gmax + m] = myv;
+                    }
                 }
-                float myv = 0.0f;
-                if (a.mode == 0) myv = group_rows(nbl_tag, ge, k0, rows, xf);
-                // this wave needs nothing below its next group any more
-                unsigned nk = 0xffffffffu;
-                if (nxt.seek(s_ops, a.nops, cu, ncu, gg + NC)) nk = nxt.k0(gg + NC);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&ctl->done[w], nk, REL_WG);
-                // publish: lane r holds row r of the group
-                if (a.mode == 0 && lane < rows) {
-                    const int m = ge.r0 + g * ge.RS + lane;
-                    __hip_atomic_store(dstg + m, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, myv), RLX_AGENT);
-                    a.vecs[(size_t)oi * a.gmax + m] = myv;
-                }
+                walk_step(cur);
             }
         };
         switch (ge.nbl) {
@@ -408,14 +445,12 @@ __global__ void __launch_bounds__((NC + NL) * 64) k_engine(const Args a) {
         }
         if (rec) a.ts[oi * 4 + 2] = wall_clock64();
         if (dead) break;
-        // the activation area is rewritten by the next op's gather: every wave must be done reading it (x lives in
-        // registers during the dots, so this is only the loads of XFrag) — one barrier per op suffices with the one above
         if (rec) a.ts[oi * 4 + 3] = wall_clock64();
     }
     if (dead) {
         __hip_atomic_store(&ctl->err, 1u, RLX_WG);
         if (lane == 0) atomicOr(a.err, 2u);
-        if (lane == 0) __hip_atomic_store(&ctl->done[w], 0xffffffffu, REL_WG);  // unblock the loaders
+        if (lane == 0) __hip_atomic_store(&ctl->done[w], 0xffffffffu, REL_WG);  // unblock the loader
     }
 }
 
@@ -484,8 +519,8 @@ static void run_engine(const Args &a, int G, hipStream_t st) {
 int main(int argc, char **argv) {
     const char *chain = argc > 1 ? argv[1] : "ffn";
     const int nops = std::min(argc > 2 ? atoi(argv[2]) : 64, MAX_OPS);
-    const int NC = argc > 3 ? atoi(argv[3]) : 6;
-    const int NL = argc > 4 ? atoi(argv[4]) : 2;
+    const int NC = argc > 3 ? atoi(argv[3]) : 7;
+    const int NL = argc > 4 ? atoi(argv[4]) : 1;
     hipDeviceProp_t pr;
     CK(hipGetDeviceProperties(&pr, 0));
     const int G = pr.multiProcessorCount;
@@ -580,12 +615,9 @@ int main(int argc, char **argv) {
         a.epoch0 = epoch;
         switch (NC * 10 + NL) {
             case 31: run_engine<3, 1>(a, G, st); break;
+            case 51: run_engine<5, 1>(a, G, st); break;
             case 71: run_engine<7, 1>(a, G, st); break;
-            case 62: run_engine<6, 2>(a, G, st); break;
-            case 42: run_engine<4, 2>(a, G, st); break;
-            case 63: run_engine<6, 3>(a, G, st); break;
-            case 93: run_engine<9, 3>(a, G, st); break;
-            default: printf("(NC, NL) must be one of (3,1) (7,1) (4,2) (6,2) (6,3) (9,3)\n"); exit(1);
+            default: printf("(NC, NL) must be one of (3,1) (5,1) (7,1)\n"); exit(1);
         }
         CK(hipGetLastError());
     };
