@@ -42,7 +42,7 @@ struct DmaCtl {
     double part[8];    // sum of squares of the 8 virtual staging waves (XSRC_NORM)
 };
 __device__ unsigned g_dma_err;  // set when an intra-workgroup wait gave up (a logic error, never expected): ggml_hip_get_stat("dma_err")
-#define DMA_SPIN_LIMIT 20000000u
+#define DMA_SPIN_LIMIT 400000u  // polls of ~0.1 us: tens of ms, orders of magnitude above any legitimate wait
 
 // geometry of one launch for one CU
 struct DmaGeo {
@@ -357,6 +357,15 @@ __global__ void __launch_bounds__(DMA_T) k_mmvq_dma(const BigArgs ba) {
     const int st = wave - 1;  // 0..6
     const int c = wave < 4 ? wave - 1 : wave - 2;  // consumer index 0..5 (wave 4 has none)
     bool dead = false;
+    if (wave != 4) {
+        // what this consumer needs first: the loader may recycle everything below it.  (Left at 0, a consumer whose first
+        // group lies beyond the first trip around the ring would stop the loader before it ever requests that group.)
+        DmaWalk w0;
+        w0.init(ge);
+        while (!w0.end(ge) && (int)(w0.gi % DMA_NC) != c) w0.step(ge);
+        const unsigned first = w0.end(ge) ? 0xffffffffu : w0.k0(ge);
+        if (lane == 0) __hip_atomic_store(&ctl->done[c], first, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     unsigned bar_target = 0;
     auto sbarrier = [&]() {  // among the 7 staging waves
         bar_target += 7;
