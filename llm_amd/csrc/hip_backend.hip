@@ -37,7 +37,6 @@
 #include "kernels/ops.h"
 #include "kernels/decode.h"
 #include "kernels/decode_big.h"
-#include "kernels/decode_dma.h"
 #include "kernels/decode_big8.h"
 #include "kernels/decode_attn_split.h"
 
@@ -132,9 +131,7 @@ struct Backend {
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
-    int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h); 2 = its EARLY
-                            // variant (whole weight ring requested before the activation is staged); 3 = loader wave +
-                            // LDS-DMA ring + consumer waves (kernels/decode_dma.h, Q4_0)
+    int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
     int opt_probe = 0;      // measurement only: k_mmvq_big returns early (BigArgs::probe), tests/tools/launch_probe.py
     int num_cus = 256;
     long long *timeline = nullptr;  // device buffer of in-kernel timestamps (option "timeline")
@@ -1887,14 +1884,6 @@ int64_t ggml_hip_get_stat(const char *key) {
         return n;
     }
     if (k == "plans") return (int64_t)g_plans.size();
-    if (k == "dma_err") {  // nonzero: an intra-workgroup wait of k_mmvq_dma gave up (never expected)
-        unsigned v = 0;
-        if (g.inited) {
-            HIP_CHECK(hipStreamSynchronize(g.stream));
-            HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_dma_err), sizeof(v)));
-        }
-        return (int64_t)v;
-    }
     if (k == "generic_graphs") return (int64_t)g.stat_generic_graphs;  // graphs run node by node
     if (k == "ns_match") return (int64_t)g.ns_match;      // host ns spent recognising decode graphs
     if (k == "ns_launch") return (int64_t)g.ns_launch;    // ... enqueueing (param upload, graph launch, read-back queue)

@@ -63,36 +63,6 @@ __device__ __forceinline__ long long big_now() { return (long long)wall_clock64(
 // The activation's global loads, issued as the FIRST memory operations of the kernel: a wave's loads return in
 // order, so anything issued after the weight prefetch would only become usable after the whole prefetch landed
 // (measured: norm staging behind the prefetch made the kernels additive, 16.6 us for wq|wk|wv instead of ~8).
-// Loads hipcc does not count (EARLY variant): the activation group is requested with these, the weight ring with
-// ordinary loads AFTER it, and one hand-placed `s_waitcnt vmcnt(<ring loads>)` (big_wait_x) makes the group usable
-// while the whole ring stays in flight.  Loads return in order, so hipcc's own counted waits for the ring stay exact:
-// everything older than a ring load has landed when that load has.
-__device__ __forceinline__ f32x4 asm_ld_f4(const void *p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ i32x4 asm_ld_i4(const void *p) {
-    i32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ f32x2 asm_ld_f2(const void *p) {
-    f32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ float asm_ld_f1(const void *p) {
-    float v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ int asm_ld_i1(const void *p) {
-    int v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
 template <int XSRC>
 struct BigX;
 template <>
@@ -100,43 +70,25 @@ struct BigX<XSRC_Q8> {
     i32x4 lo, hi;
     float d;
     int sum;
-    template <bool ASM>
     __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
         const int64_t i = tid < nb ? tid : 0;  // nb <= T (checked by the launcher)
-        if constexpr (ASM) {
-            lo = asm_ld_i4(a.d.x.lo + i);
-            hi = asm_ld_i4(a.d.x.hi + i);
-            d = asm_ld_f1(a.d.x.d + i);
-            sum = asm_ld_i1(a.d.x.sum + i);
-        } else {
-            lo = a.d.x.lo[i];
-            hi = a.d.x.hi[i];
-            d = a.d.x.d[i];
-            sum = a.d.x.sum[i];
-        }
-    }
-    template <int N>
-    __device__ __forceinline__ void wait() {  // the group has landed once at most N younger loads are outstanding
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lo), "+v"(hi), "+v"(d), "+v"(sum) : "n"(N) : "memory");
+        lo = a.d.x.lo[i];
+        hi = a.d.x.hi[i];
+        d = a.d.x.d[i];
+        sum = a.d.x.sum[i];
     }
 };
 template <>
 struct BigX<XSRC_F32> {
     static constexpr int MAXIT = 6;  // rows up to 24 * T wide (24576 at 1024 threads; checked by the launcher)
     f32x4 v[MAXIT];
-    template <bool ASM>
     __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
         const int64_t n4 = nb * 8;
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
             const int64_t i4 = (int64_t)it * T + tid;
-            const f32x4 *p = (const f32x4 *)a.d.xf + (i4 < n4 ? i4 : 0);
-            if constexpr (ASM) v[it] = asm_ld_f4(p); else v[it] = *p;
+            v[it] = ((const f32x4 *)a.d.xf)[i4 < n4 ? i4 : 0];
         }
-    }
-    template <int N>
-    __device__ __forceinline__ void wait() {
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : "n"(N) : "memory");
     }
 };
 template <>
@@ -147,27 +99,15 @@ struct BigX<XSRC_NORM> {
     // number of (single-address) loads so that every wave's load queue has the same compile-time shape.
     static constexpr int NT = 512, MAXIT = 4;  // rows up to 8192 wide
     f32x4 v[MAXIT], w[MAXIT];
-    template <bool ASM>
     __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
         const int64_t n4 = nb * 8;
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
             const int64_t i4 = (int64_t)it * NT + tid;
             const int64_t ic = (tid < NT && i4 < n4) ? i4 : 0;
-            if constexpr (ASM) {
-                v[it] = asm_ld_f4((const f32x4 *)a.d.xf + ic);
-                w[it] = asm_ld_f4((const f32x4 *)a.d.xw + ic);
-            } else {
-                v[it] = ((const f32x4 *)a.d.xf)[ic];
-                w[it] = ((const f32x4 *)a.d.xw)[ic];
-            }
+            v[it] = ((const f32x4 *)a.d.xf)[ic];
+            w[it] = ((const f32x4 *)a.d.xw)[ic];
         }
-    }
-    template <int N>
-    __device__ __forceinline__ void wait() {
-        asm volatile("s_waitcnt vmcnt(%8)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
-                     : "n"(N) : "memory");
     }
 };
 
@@ -242,14 +182,7 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
     }
 }
 
-// EARLY (option "big" = 2): the WHOLE ring is requested before the activation is staged.  What made that lose when it
-// was first tried (x queued behind the weight requests) is avoided by ordering, not by
-// holding the ring back: every wave issues its activation loads, the waves meet at a bare s_barrier (which waits for
-// the ISSUE of those loads, not for their data), and only then do the weight requests go out — so the activation is
-// ahead of every weight request of this CU in the memory pipeline.  The activation loads are inline asm (hipcc does
-// not count them) and become usable at a hand-placed `s_waitcnt vmcnt(<ring loads>)`: the staging arithmetic then
-// runs under the full ring instead of under 2 of its 6..8 steps.
-template <int QT, int EPI, int XSRC, bool EARLY = false>
+template <int QT, int EPI, int XSRC>
 __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     const DecMmvqArgs &a = ba.d;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,12 +191,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
     constexpr int RU = EPI == EPI_QKV ? 2 : 1, NW = EPI == EPI_GATE ? 2 : 1, NR = RU * NW;
     constexpr int PF = big_pf<QT>(NR);
-    constexpr int PF0 = EARLY ? PF : (PF < 2 ? PF : 2);  // steps requested before x is staged (see step 2)
-    // vector-memory instructions of one step / of the ring (the count the hand-placed wait of EARLY leaves in flight)
-    constexpr int LPS = NR * (2 + (QT == QT_Q8_0 ? 1 : 0) + ((QT == QT_Q5_0 || QT == QT_Q5_1) ? 1 : 0) +
-                              ((QT == QT_Q4_1 || QT == QT_Q5_1) ? 1 : 0));
-    constexpr int NRING = PF * LPS;
-    static_assert(NRING <= 60, "vmcnt is a 6-bit counter");
+    constexpr int PF0 = PF < 2 ? PF : 2;  // steps requested before x is staged (see step 2)
     // all index arithmetic is 32-bit (rows <= 2^17, blocks per matrix < 2^27): 64-bit divides and multiplies in
     // the prologue cost ~1 us of VALU time per launch
     const int nb = (int)a.nb;
@@ -286,14 +214,13 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     int n_past = 0;
     if constexpr (EPI == EPI_QKV) n_past = a.prm->n_past;
     BigX<XSRC> xr;
-    xr.template load<EARLY>(ba, nb, tid, T);
+    xr.load(ba, nb, tid, T);
     // EPI_QKV: the last two waves fetch the token's RoPE table (k_rope_table); every wave issues the load so that all
     // load queues keep one compile-time shape
     f32x2 rope_pre = {0.0f, 0.0f};
     if constexpr (EPI == EPI_QKV) {
         const int kk = tid - (T - 128);
-        const f32x2 *rp = (const f32x2 *)ba.rope + ((kk >= 0 && kk < (a.D >> 1)) ? kk : 0);
-        if constexpr (EARLY) rope_pre = asm_ld_f2(rp); else rope_pre = *rp;
+        rope_pre = ((const f32x2 *)ba.rope)[(kk >= 0 && kk < (a.D >> 1)) ? kk : 0];
     }
 
     // this wave's units: ((i * G + g) * 16 + wave), i < nu — at any moment the G workgroups together stream ONE
@@ -307,11 +234,8 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     float res_pre = 0.0f;
     if constexpr (EPI == EPI_ADD) {
         const int m = u_first + u_stride * lane;
-        const float *rp = a.res + ((lane < nu && m < Utot) ? m : 0);
-        if constexpr (EARLY) res_pre = asm_ld_f1(rp); else res_pre = *rp;
+        res_pre = a.res[(lane < nu && m < Utot) ? m : 0];
     }
-    // EARLY: every wave's activation-group loads are issued before any wave requests weights
-    if constexpr (EARLY) __builtin_amdgcn_s_barrier();
 
     // unit -> (matrix, first row)
     auto resolve = [&](int i, int &sg, int &m0) {
@@ -395,11 +319,6 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     for (int k = 0; k < PF0; k++) {
         issue(ring[k], pj, k >= S);
         advance(k);
-    }
-    if constexpr (EARLY) {  // the activation group has landed when only the ring is still in flight
-        xr.template wait<NRING>();
-        if constexpr (EPI == EPI_QKV) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rope_pre) : "n"(NRING) : "memory");
-        if constexpr (EPI == EPI_ADD) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(res_pre) : "n"(NRING) : "memory");
     }
     const long long t_issued = ba.ts ? big_now() : 0;
 

@@ -74,39 +74,3 @@ def test_full_size_7b_q4_0_decode_matches_oracle(G, O):
     worst, ns, n = _run(G, O, synth.LLAMA_7B, G.TYPE_Q4_0, 4, 2, ctx=32)
     print(f"7B Q4_0 full size: worst {worst:.2e}, {ns}/{n} strict")
 
-
-@pytest.mark.parametrize("name,hp0,n_decode", [
-    ("7b-shaped", dict(n_vocab=2048, n_embd=4096, n_head=32, n_head_kv=32, n_layer=2, n_rot=128, n_ff=11008, n_mult=256), 4),
-    ("13b-shaped", dict(n_vocab=1024, n_embd=5120, n_head=40, n_head_kv=40, n_layer=2, n_rot=128, n_ff=13824, n_mult=256), 3),
-    ("gqa", dict(n_vocab=1024, n_embd=4096, n_head=32, n_head_kv=8, n_layer=2, n_rot=128, n_ff=11008, n_mult=256), 3),
-    ("odd-vocab", dict(n_vocab=1003, n_embd=2048, n_head=16, n_head_kv=16, n_layer=1, n_rot=128, n_ff=5632, n_mult=256), 3),
-])
-def test_dma_mat_vec_is_bit_identical_to_the_big_kernels(G, name, hp0, n_decode):
-    """kernels/decode_dma.h (loader wave + LDS-DMA ring + consumer waves, option big = 3) against k_mmvq_big
-    (option big = 1) on Q4_0 models of the real row widths: same block dots, same per-lane block order, same wave
-    reduction, same staging arithmetic -> identical logits and identical K/V, bit for bit; and no intra-workgroup
-    wait of the new kernel ever gave up (dma_err)."""
-    from llm_amd import llama, synth
-    hp, w = synth.make_llama_fast(hp0, G.TYPE_Q4_0)
-    toks = np.random.default_rng(5).integers(0, hp["n_vocab"], 8 + n_decode).astype(np.int32)
-    outs = {}
-    try:
-        for big in (1, 3):
-            G.set_option("big", big)
-            model = llama.Llama(hp, w, context_size=64)
-            sess = model.start_session(n_batch=8)
-            p0 = int(G.get_stat("plan_tokens"))
-            lg = [sess.evaluate(toks[:8])]
-            for i in range(n_decode):
-                lg.append(sess.evaluate(toks[8 + i:9 + i]))
-            assert int(G.get_stat("plan_tokens")) - p0 >= n_decode
-            k, v = sess.get_kv()
-            outs[big] = (np.concatenate(lg), k.copy(), v.copy())
-            sess.free()
-            model.free()
-    finally:
-        G.set_option("big", 1)
-    assert int(G.get_stat("dma_err")) == 0
-    assert np.isfinite(outs[3][0]).all()
-    for a, b in zip(outs[1], outs[3]):
-        assert np.array_equal(a, b), name

@@ -72,6 +72,30 @@ __global__ void __launch_bounds__(NW * 64) k_rate(const char *w, size_t per_cu, 
     }
 }
 
+// What does s_getreg_b32 IB_STS show while LDS-DMA requests are outstanding?  out[2i] = raw IB_STS right after issuing
+// n[i] requests, out[2i+1] = raw IB_STS after s_waitcnt vmcnt(0).
+__global__ void __launch_bounds__(64) k_ibsts(const char *w, unsigned *out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned v_lane16 = (threadIdx.x & 63) * 16u;
+    const unsigned long long b0 = (unsigned long long)(uintptr_t)w;
+    const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b0 >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b0);
+    const int counts[6] = {1, 4, 12, 20, 36, 52};
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        for (int i = 0; i < counts[t]; i++) {
+            const unsigned long long b = base + ((unsigned long long)(t * 64 + i) << 20);  // 1 MiB apart: cold lines
+            const unsigned d = (unsigned)(i & 31) * 1024u;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(v_lane16), "s"(b), "s"(d) : "memory");
+        }
+        unsigned r0, r1;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_IB_STS)" : "=s"(r0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_IB_STS)" : "=s"(r1));
+        if (threadIdx.x == 0) { out[2 * t] = r0; out[2 * t + 1] = r1; }
+    }
+}
+
 __global__ void k_fill(unsigned *p, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (unsigned)(i >> 8);  // dword i holds its KiB index (1 KiB = 256 dwords)
@@ -115,7 +139,19 @@ int main() {
                h[0], h[64], h[128], h[192], (h[0] == 0 && h[64] == 1 && h[128] == 2 && h[192] == 3) ? "the immediate offset moves the LDS address too"
                                                                                                   : "the immediate offset applies to the global address only");
     }
-    for (int depth : {48, 32}) {
+    {
+        CK(hipFuncSetAttribute((const void *)k_ibsts, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        hipLaunchKernelGGL(k_ibsts, dim3(1), dim3(64), 65536, 0, w, out);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned> h(12); CK(hipMemcpy(h.data(), out, 48, hipMemcpyDeviceToHost));
+        const int counts[6] = {1, 4, 12, 20, 36, 52};
+        for (int t = 0; t < 6; t++) {
+            const unsigned r = h[2 * t], z = h[2 * t + 1];
+            printf("IB_STS after issuing %2d requests: 0x%08x (bits 3:0 = %u, bits 23:22 = %u -> %u) | after vmcnt(0): 0x%08x\n", counts[t], r,
+                   r & 15, (r >> 22) & 3, (r & 15) | (((r >> 22) & 3) << 4), z);
+        }
+    }
+    for (int depth : {48}) {
         run<0, 1>(w, per_cu, G, nullptr, depth, "2.5 scalar instr per request (imm offsets)");
         run<1, 1>(w, per_cu, G, nullptr, depth, "~5 scalar instr per request");
         run<2, 1>(w, per_cu, G, nullptr, depth, "~13 scalar instr per request");

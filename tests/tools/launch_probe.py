@@ -43,7 +43,7 @@ def main():
     s.feed_prompt((np.arange(128, dtype=np.int32) * 7 + 5) % hp["n_vocab"])
     kinds = ["qkv", "wo", "gate_up", "down", "lm_head"]
     L = ggml.lib()
-    for big in (1, 3):
+    for big in (1,):
         ggml.set_option("big", big)
         for _ in range(4):
             s.infer_next_token()
