@@ -489,6 +489,19 @@ GGML_API void ggml_hip_set_option(const char *key, int value);
 #define GGML_HIP_KKIND_BASE 16
 GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
                                        double *algo_bytes_per_replay);
+/* Layer split over RCCL (the reference has no multi-GPU path: LLAMA_MAX_DEVICES = 1,
+ * crates/ggml/sys/src/llama.rs:3, and feeds ggml_cuda_set_tensor_split a single float, crates/ggml/src/accelerator/mod.rs:74-75).
+ * One process per GPU; rank 0 draws the id, the launcher hands it to every rank, every rank calls init.  send / recv are
+ * enqueued on the backend's stream (ordered with the kernels before and after them, no host synchronisation);
+ * sendrecv = both in one RCCL group (needed when the peer is this rank itself).  librccl.so is opened on first use. */
+#define GGML_HIP_COMM_ID_BYTES 128
+GGML_API int ggml_hip_comm_unique_id(void *id_out /* GGML_HIP_COMM_ID_BYTES */);
+GGML_API int ggml_hip_comm_init(int rank, int world, const void *id); /* returns the rank count RCCL reports */
+GGML_API void ggml_hip_comm_destroy(void);
+GGML_API int ggml_hip_comm_ranks(void); /* 0 = no communicator */
+GGML_API void ggml_hip_comm_send(const void *dev_src, size_t nbytes, int peer);
+GGML_API void ggml_hip_comm_recv(void *dev_dst, size_t nbytes, int peer);
+GGML_API void ggml_hip_comm_sendrecv(const void *dev_src, int send_peer, void *dev_dst, int recv_peer, size_t nbytes);
 /* Launch-floor probe (measurement only, tests/tools/launch_probe.py): a linear hipGraph of n_launch launches of a
  * kernel that only stamps the device wall clock, with the given launch shape.  out[3] = {us per launch, us from one
  * launch's end to the next launch's first instruction, us first instruction -> last kernel argument usable}. */

@@ -1464,6 +1464,11 @@ void ggml_hip_free_scratch(void) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     if (!g.inited) return;
     HIP_CHECK(hipStreamSynchronize(g.stream));
+    // Cached decode plans (and the plan a greedy chain may continue) hold device addresses inside these shadows
+    // (logits / embedding mirrors): they go first.
+    drop_all_plans();
+    g.chain_plan = nullptr;
+    g.chain_graph = nullptr;
     // Release the device shadows of dead arenas (freed contexts) and of every scratch buffer.  Scratch
     // registrations stay (the caller-owned Buffers may still be in use by another session); their
     // shadows hold only per-evaluation temporaries and are re-created lazily on next use.
@@ -1777,6 +1782,121 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     if (launches_per_replay) *launches_per_replay = st.launches[kclass];
     if (algo_bytes_per_replay) *algo_bytes_per_replay = st.bytes[kclass];
     return 0;
+}
+
+// ===================================================================================================
+// Layer split over RCCL: one process per GPU, the residual [n_embd x N] f32 crosses a stage
+// boundary with ncclSend / ncclRecv on the backend's own stream — stream-ordered with the kernels on either side, no
+// host synchronisation per hop, no torch tensor in the data path.  librccl.so (0.5 GB) is opened on first use, so
+// single-GPU users neither need nor load it; a missing library or any RCCL error aborts with a message.
+// ===================================================================================================
+}  // extern "C"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct Rccl {
+    void *dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = -1, world = 0;
+} rccl;
+void rccl_load() {
+    if (rccl.dl) return;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+        if ((rccl.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!rccl.dl) die("cannot open librccl.so (%s): the layer split across GPUs needs RCCL", dlerror());
+    auto sym = [&](const char *n) {
+        void *p = dlsym(rccl.dl, n);
+        if (!p) die("librccl.so lacks %s", n);
+        return p;
+    };
+    rccl.GetUniqueId = (decltype(rccl.GetUniqueId))sym("ncclGetUniqueId");
+    rccl.CommInitRank = (decltype(rccl.CommInitRank))sym("ncclCommInitRank");
+    rccl.CommDestroy = (decltype(rccl.CommDestroy))sym("ncclCommDestroy");
+    rccl.CommCount = (decltype(rccl.CommCount))sym("ncclCommCount");
+    rccl.Send = (decltype(rccl.Send))sym("ncclSend");
+    rccl.Recv = (decltype(rccl.Recv))sym("ncclRecv");
+    rccl.GroupStart = (decltype(rccl.GroupStart))sym("ncclGroupStart");
+    rccl.GroupEnd = (decltype(rccl.GroupEnd))sym("ncclGroupEnd");
+    rccl.GetErrorString = (decltype(rccl.GetErrorString))sym("ncclGetErrorString");
+}
+#define RCCL_CHECK(x)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r_ = (x);                                                                         \
+        if (r_ != ncclSuccess) die("RCCL error %s at %s:%d (%s)", rccl.GetErrorString(r_), __FILE__, __LINE__, #x); \
+    } while (0)
+void comm_need() {
+    if (!rccl.comm) die("ggml_hip_comm_*: no communicator (call ggml_hip_comm_init first)");
+}
+}  // namespace
+extern "C" {
+int ggml_hip_comm_unique_id(void *id_out) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    rccl_load();
+    ncclUniqueId id;
+    RCCL_CHECK(rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return (int)sizeof(id);
+}
+int ggml_hip_comm_init(int rank, int world, const void *id_in) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    rccl_load();
+    if (rccl.comm) die("ggml_hip_comm_init: a communicator already exists");
+    if (world < 1 || rank < 0 || rank >= world) die("ggml_hip_comm_init: bad rank %d of %d", rank, world);
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof(id));
+    HIP_CHECK(hipSetDevice(g.device));
+    RCCL_CHECK(rccl.CommInitRank(&rccl.comm, world, id, rank));
+    rccl.rank = rank;
+    rccl.world = world;
+    int n = 0;
+    RCCL_CHECK(rccl.CommCount(rccl.comm, &n));
+    return n;
+}
+void ggml_hip_comm_destroy(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (!rccl.comm) return;
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    RCCL_CHECK(rccl.CommDestroy(rccl.comm));
+    rccl.comm = nullptr;
+    rccl.rank = -1;
+    rccl.world = 0;
+}
+int ggml_hip_comm_ranks(void) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (!rccl.comm) return 0;
+    int n = 0;
+    RCCL_CHECK(rccl.CommCount(rccl.comm, &n));
+    return n;
+}
+void ggml_hip_comm_send(const void *dev_src, size_t nbytes, int peer) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    comm_need();
+    RCCL_CHECK(rccl.Send(dev_src, nbytes, ncclUint8, peer, rccl.comm, g.stream));
+}
+void ggml_hip_comm_recv(void *dev_dst, size_t nbytes, int peer) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    comm_need();
+    RCCL_CHECK(rccl.Recv(dev_dst, nbytes, ncclUint8, peer, rccl.comm, g.stream));
+}
+void ggml_hip_comm_sendrecv(const void *dev_src, int send_peer, void *dev_dst, int recv_peer, size_t nbytes) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    comm_need();
+    RCCL_CHECK(rccl.GroupStart());
+    RCCL_CHECK(rccl.Send(dev_src, nbytes, ncclUint8, send_peer, rccl.comm, g.stream));
+    RCCL_CHECK(rccl.Recv(dev_dst, nbytes, ncclUint8, recv_peer, rccl.comm, g.stream));
+    RCCL_CHECK(rccl.GroupEnd());
 }
 
 // Launch-floor probe (tests/tools/launch_probe.py): a linear hipGraph of `n_launch` launches of a kernel that does

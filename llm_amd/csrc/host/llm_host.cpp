@@ -366,6 +366,10 @@ class Llama {
             Context &ctx0 = *builder.ctx0;
             const Tensor &embd = *builder.embd;
             (void)n_layer;
+            // a stage of a layer split exchanges the residual through hand-off buffers of n_embd * n_batch floats;
+            // ggml_view_1d has no bounds check (upstream neither), so a larger batch would run past them silently
+            if ((!is_first() || !is_last()) && input_len > session.config.n_batch)
+                ggml::panic("evaluate: a layer-split stage takes at most n_batch tokens per call (hand-off buffer size)");
             Tensor input_layer = is_first()
                                      ? ctx0.op_get_rows(wte, embd)  // :170
                                      : ctx0.op_reshape_2d(ctx0.op_view_1d(session.stage_in, n_embd * input_len, 0), n_embd,
@@ -959,6 +963,47 @@ void llm_synth_blocks(int type, void *dst, int64_t nblocks, uint64_t seed, float
     for (unsigned t = 0; t < nt; t++) {
         const int64_t b0 = (int64_t)t * per, b1 = std::min<int64_t>(nblocks, b0 + per);
         if (b0 < b1) th.emplace_back(work, b0, b1);
+    }
+    for (auto &t : th) t.join();
+}
+
+// BASELINE.md section 4's synthetic weights at full size: rows of N(0, std^2) f32 quantized by ggml_quantize_q* (the
+// product's host quantizer = what the reference's quantize tool calls), written as raw GGML blocks.  The gaussians come
+// from a counter-based generator (splitmix64 + Box-Muller, deterministic in (seed, row)) instead of numpy's stream:
+// 6.6e9 numpy draws take minutes of single-thread time before a bench could start.  Rows are cut over the host's
+// threads.  `type` = a block type of 32 weights; ne0 = row length (multiple of 32); ne1 = rows.
+void llm_synth_gaussian(int type, void *dst, int64_t ne0, int64_t ne1, uint64_t seed, float std) {
+    const size_t row_bytes = (size_t)(ne0 / 32) * ggml_type_size((ggml_type)type);
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 64 ? 64 : nt);
+    auto work = [&](int64_t r0, int64_t r1) {
+        std::vector<float> row((size_t)ne0);
+        int64_t hist[16] = {0};
+        for (int64_t r = r0; r < r1; r++) {
+            uint64_t x = seed * 0x9E3779B97F4A7C15ull + (uint64_t)r * 0xD1B54A32D192ED03ull;
+            auto next = [&x]() {
+                x += 0x9E3779B97F4A7C15ull;
+                uint64_t z = x;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                return z ^ (z >> 31);
+            };
+            for (int64_t i = 0; i < ne0; i += 2) {
+                const uint64_t u = next();
+                const float u1 = ((float)(u >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+                const float u2 = (float)((u >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+                const float m = std * sqrtf(-2.0f * logf(u1));
+                row[i] = m * cosf(6.2831853071795865f * u2);
+                if (i + 1 < ne0) row[i + 1] = m * sinf(6.2831853071795865f * u2);
+            }
+            ggml_quantize_chunk((ggml_type)type, row.data(), (uint8_t *)dst + (size_t)r * row_bytes, 0, (int)ne0, hist);
+        }
+    };
+    std::vector<std::thread> th;
+    const int64_t per = (ne1 + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const int64_t r0 = (int64_t)t * per, r1 = std::min<int64_t>(ne1, r0 + per);
+        if (r0 < r1) th.emplace_back(work, r0, r1);
     }
     for (auto &t : th) t.join();
 }

@@ -115,6 +115,9 @@ GGML_API size_t llm_session_read_node(const llm_session *s, int index, const cha
                                       size_t max_bytes);
 /* synthetic GGML blocks for full-size benchmarks (deterministic in seed and block index) */
 GGML_API void llm_synth_blocks(int type, void *dst, int64_t nblocks, uint64_t seed, float d_scale);
+/* BASELINE.md section 4 weights at full size: ne1 rows of ne0 gaussians N(0, std^2) (counter-based generator, deterministic
+ * in (seed, row)), each row quantized by ggml_quantize_q* into raw GGML blocks of `type` at dst; multi-threaded. */
+GGML_API void llm_synth_gaussian(int type, void *dst, int64_t ne0, int64_t ne1, uint64_t seed, float std);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ BACKEND_CPU, BACKEND_GPU, BACKEND_GPU_SPLIT = 0, 10, 20
 OP_NONE, OP_MUL_MAT = 0, 21
 MAX_NODES, MAX_SRC, MAX_NAME, HASHTABLE = 4096, 6, 48, 8273
 KCLASS_MMVQ, KCLASS_MMQ_MFMA, KCLASS_ATTN, KCLASS_OTHER = 0, 1, 2, 3
+COMM_ID_BYTES = 128  # GGML_HIP_COMM_ID_BYTES
 KKIND_BASE = 16  # + {0 wq|wk|wv, 1 wo, 2 w1|w3, 3 w2, 4 lm_head}: one kind of decode mat-vec (bench_plan_class)
 
 TYPE_NAMES = {TYPE_F32: "f32", TYPE_F16: "f16", TYPE_Q4_0: "q4_0", TYPE_Q4_1: "q4_1", TYPE_Q5_0: "q5_0",
@@ -220,6 +221,13 @@ PROTOTYPES.update({
     "ggml_hip_graph_compute_end": (None, []),
     "ggml_hip_bench_plan_class": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_double)]),
+    "ggml_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ggml_hip_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "ggml_hip_comm_destroy": (None, []),
+    "ggml_hip_comm_ranks": (C.c_int, []),
+    "ggml_hip_comm_send": (None, [C.c_void_p, C.c_size_t, C.c_int]),
+    "ggml_hip_comm_recv": (None, [C.c_void_p, C.c_size_t, C.c_int]),
+    "ggml_hip_comm_sendrecv": (None, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t]),
     "ggml_hip_bench_empty": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "ggml_hip_version": (C.c_char_p, []),
 })

@@ -1,7 +1,11 @@
 """Layer split across the GPUs of one node: one process per GPU, rank r owns the contiguous layers
 [r·L/G, (r+1)·L/G) and their K/V memory; the only data that crosses a stage boundary is the residual [n_embd × N]
-f32, sent/received point-to-point (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" for
-the CPU tests), plus the sampled token id from the last rank back to rank 0.
+f32.  On GPUs it goes through RCCL INSIDE the library: ggml_hip_comm_recv into the session's hand-off buffer before
+the stage's graph and ggml_hip_comm_send of its output after it, both enqueued on the backend's stream (ordered with
+the kernels, no host copy, no host synchronisation for the hop, no torch tensor).  torch.distributed ("gloo") is only
+the launcher's rendezvous: it carries the RCCL unique id, the 4-byte sampled token id from the last rank back to rank
+0, and the timing barrier.  The CPU tests (gloo, stub stage) and a 1-GPU box (RCCL refuses two ranks on one device)
+move the residual through torch.distributed instead.
 
 Batch-1 decode through a layer split is a sequential pipeline: one sequence cannot be faster on G GPUs
 than on one.  The driver therefore keeps G independent sequences in flight, one per stage — the reference's
@@ -69,18 +73,22 @@ class GpuStage(Stage):
         self.G.lib().ggml_hip_memcpy(out.ctypes.data, out_dev, out.nbytes, 1)
         return out
 
-    # device-resident variant used with the NCCL backend: no host round trip of the residual
-    def evaluate_device(self, s, tokens, recv_ptr, send_ptr):
+    # the hop inside the library (RCCL on the backend stream): ggml_hip_comm_init must have been called
+    comm_ready = False
+
+    def evaluate_comm(self, s, tokens, prev, nxt):
         sess = self.sessions[s]
         n = len(tokens)
+        assert n <= self.n_batch, "the hand-off buffers hold n_batch tokens"
         in_dev, out_dev, _ = sess.stage_buffers()
         nbytes = n * self.n_embd * 4
+        L = self.G.lib()
         if not self.is_first:
-            self.G.lib().ggml_hip_memcpy(in_dev, recv_ptr, nbytes, 2)
+            L.ggml_hip_comm_recv(in_dev, nbytes, prev)  # enqueued: the stage's first kernel reads it in stream order
         logits = sess.evaluate(tokens, want_all_logits=self.is_last)
         if self.is_last:
             return int(np.argmax(logits[-1]))
-        self.G.lib().ggml_hip_memcpy(send_ptr, out_dev, nbytes, 2)
+        L.ggml_hip_comm_send(out_dev, nbytes, nxt)  # the session's next evaluate is ordered behind it on the stream
         return None
 
     def free(self):
@@ -132,7 +140,8 @@ class Pipeline:
         send_tok = [t.zeros_like(recv_tok) for _ in range(2)]
         pending = None
         produced = [[None] * n_items for _ in range(n_seq)]
-        use_dev = self.device is not None and hasattr(stage, "evaluate_device")
+        use_lib = bool(getattr(stage, "comm_ready", False))
+        assert n_batch <= getattr(stage, "n_batch", n_batch), "stage hand-off buffers are smaller than the pipeline's batch"
         for step, row in enumerate(schedule(world, n_seq, n_items)):
             if on_timed_region is not None:
                 on_timed_region(step)
@@ -148,8 +157,9 @@ class Pipeline:
             n = 1 if toks is None else len(toks)
             need_tok = rank == 0 and toks is None and world > 1
             reqs = []
-            # (1) post this micro-step's receives first
-            if rank > 0:
+            # (1) post this micro-step's receives first (with the library transport the residual's receive is enqueued
+            #     on the backend stream by evaluate_comm; only the token id travels through torch.distributed)
+            if rank > 0 and not use_lib:
                 reqs.append(dist.irecv(recv_res[: n * E], src=prev))
             if need_tok:
                 reqs.append(dist.irecv(recv_tok, src=world - 1))
@@ -171,8 +181,8 @@ class Pipeline:
                     toks = np.zeros(1, np.int32)  # later stages only need N
             # (4) evaluate
             sb = send_res[step & 1]
-            if use_dev:
-                out = stage.evaluate_device(s, toks, recv_res.data_ptr(), sb.data_ptr())
+            if use_lib:
+                out = stage.evaluate_comm(s, toks, prev, nxt)
             else:
                 rin = recv_res[: n * E].cpu().numpy().reshape(n, E) if rank > 0 else None
                 out = stage.evaluate(s, toks, rin)
@@ -181,7 +191,8 @@ class Pipeline:
             # (5) post the sends
             pending = []
             if not stage.is_last:
-                pending.append(dist.isend(sb[: n * E], dst=nxt))
+                if not use_lib:
+                    pending.append(dist.isend(sb[: n * E], dst=nxt))
             else:
                 produced[s][j] = out
                 follow = j + 1 < n_items and items[s][j + 1] is None
@@ -210,30 +221,40 @@ def run_bench(args):
         raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with torchrun --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["GGML_HIP_DEVICE"] = str(local_rank)  # one process drives one GPU (read at backend init)
-    backend = os.environ.get("LLM_PIPELINE_BACKEND", "nccl")
-    device = None
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if backend == "nccl" and torch.cuda.device_count() < local_world:
-        # fewer visible GPUs than ranks on this node (e.g. a 1-GPU box running the 2-rank functional check): EVERY rank
-        # must take this branch, so the test is on the node's rank count, not on this rank's own ordinal
-        backend = "gloo"
-        os.environ["GGML_HIP_DEVICE"] = str(local_rank % max(torch.cuda.device_count(), 1))
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", device_id=device)
-    else:
-        dist.init_process_group(backend)
+    n_dev = torch.cuda.device_count()
+    os.environ["GGML_HIP_DEVICE"] = str(local_rank % max(n_dev, 1))  # one process drives one GPU (read at backend init)
+    # torch.distributed is the launcher's rendezvous only (unique id, token ids, barrier): gloo on host tensors.  The
+    # residual goes through RCCL inside the library when every rank of the node has its own GPU (decided per node so
+    # that all ranks agree); RCCL refuses two ranks on one device, so a 1-GPU box falls back to host copies over gloo.
+    dist.init_process_group("gloo")
+    device = None
+    use_rccl = os.environ.get("LLM_PIPELINE_BACKEND", "rccl") == "rccl" and n_dev >= local_world
     from . import ggml, synth
     hp0 = {"7b": synth.LLAMA_7B, "13b": synth.LLAMA_13B, "65b": synth.LLAMA_65B, "tiny": synth.TINY}[args.model]
     wtype = {"q4_0": ggml.TYPE_Q4_0, "q4_1": ggml.TYPE_Q4_1, "q5_0": ggml.TYPE_Q5_0, "q5_1": ggml.TYPE_Q5_1,
              "q8_0": ggml.TYPE_Q8_0}[args.wtype]
     lb, le = layer_range(hp0["n_layer"], rank, world)
     names = synth.stage_tensor_names(hp0, lb, le)
-    hp, w = synth.make_llama_fast(hp0, wtype, only=names)
+    make = synth.make_llama_gaussian if getattr(args, "weights", "gaussian") == "gaussian" else synth.make_llama_fast
+    hp, w = make(hp0, wtype, only=names)
     ctx = 2048 if args.model != "tiny" else 256
     stage = GpuStage(hp, w, (lb, le), ctx, n_batch=8)
+    comm_ranks = 0
+    if use_rccl:
+        import ctypes
+        idb = torch.zeros(ggml.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (ctypes.c_ubyte * ggml.COMM_ID_BYTES)()
+            ggml.lib().ggml_hip_comm_unique_id(buf)
+            idb = torch.tensor(list(buf), dtype=torch.uint8)
+        dist.broadcast(idb, src=0)
+        raw = (ctypes.c_ubyte * ggml.COMM_ID_BYTES)(*idb.tolist())
+        comm_ranks = ggml.lib().ggml_hip_comm_init(rank, world, raw)
+        assert comm_ranks == world, (comm_ranks, world)
+        stage.comm_ready = True
+    backend = f"rccl inside libggml_hip.so ({comm_ranks} ranks) for the residual; gloo for token ids and the barrier" \
+        if use_rccl else "gloo (host copies: fewer GPUs than ranks on this node)"
     n_seq = world
     for s in range(n_seq):
         stage.new_sequence(s)
@@ -273,10 +294,12 @@ def run_bench(args):
                           "parallelism": f"pp{world} layer split, RCCL send/recv of the residual",
                           "sequences_in_flight": n_seq,
                           "single_stream_tokens_per_s": round(args.steps / elapsed, 2),
-                          "comm_backend": backend},
+                          "comm_backend": backend, "comm_ranks_seen_by_rccl": comm_ranks},
                "roofline": None, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     stage.free()
+    if use_rccl:
+        ggml.lib().ggml_hip_comm_destroy()
     dist.destroy_process_group()
 
 

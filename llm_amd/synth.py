@@ -97,6 +97,31 @@ def make_llama_fast(hp, wtype, seed=1234, d_scale=0.0043, only=None):
     return h, out
 
 
+def make_llama_gaussian(hp, wtype, seed=1234, std=0.02, only=None):
+    """BASELINE.md section 4 at full size: 2-D weights N(0, std^2) quantized by the product's ggml_quantize_q* (the host
+    function the reference's quantizer calls; byte-identical to the oracle's), norm weights 1 + N(0, 0.01^2).  The
+    gaussians of the big tensors come from a counter-based generator in the library (llm_synth_gaussian, threaded):
+    numpy's default_rng stream for 6.6e9 draws would take minutes before a bench could start."""
+    out = {}
+    bs, be = ggml.BLOCK_BYTES[wtype], ggml.BLOCK_ELEMS[wtype]
+    fill = ggml.lib().llm_synth_gaussian
+    fill.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float]
+    fill.restype = None
+    for name, (ne0, ne1) in tensor_shapes(hp).items():
+        if only is not None and name not in only:
+            continue
+        rng = np.random.default_rng([seed, _layer_of(name) + 1, sum(map(ord, name))])
+        if ne1 is None:
+            out[name] = (1.0 + 0.01 * rng.standard_normal(ne0)).astype(np.float32)
+            continue
+        raw = np.empty(ne1 * (ne0 // be) * bs, dtype=np.uint8)
+        fill(wtype, raw.ctypes.data, ne0, ne1, int(rng.integers(0, 2**62)), std)
+        out[name] = raw
+    h = dict(hp)
+    h["wtype"] = wtype
+    return h, out
+
+
 def write_ggjt(path, hp, w, container="ggjt", version=3, vocab=None):
     """Writes a LLaMA model file the way crates/ggml/src/format/saver.rs:86-160 does: magic (+ version), the
     hyperparameters of models/llama/src/lib.rs:449-458, the vocabulary (u32 len, bytes, f32 score — no score in the

@@ -268,3 +268,17 @@ def test_ggjt_container_reader_roundtrip_and_rejections(tmp_path):
           for k, v in w.items()}
     synth.write_ggjt(bad, hp2, w2)
     assert llama.inspect_file(bad) is None
+
+
+def test_comm_entry_points_exist_and_report_no_communicator(G):
+    """The layer-split hop lives behind the C ABI (ggml_hip_comm_*, RCCL opened lazily): without a communicator the
+    library reports 0 ranks and neither loads librccl nor needs a GPU for that answer."""
+    L = G.lib()
+    for name in ("ggml_hip_comm_unique_id", "ggml_hip_comm_init", "ggml_hip_comm_destroy", "ggml_hip_comm_ranks",
+                 "ggml_hip_comm_send", "ggml_hip_comm_recv", "ggml_hip_comm_sendrecv"):
+        assert hasattr(L, name), name
+    assert L.ggml_hip_comm_ranks() == 0
+    L.ggml_hip_comm_destroy()  # no-op without a communicator
+    assert G.COMM_ID_BYTES == 128
+    maps = open("/proc/self/maps").read()
+    assert "librccl" not in maps

@@ -544,3 +544,163 @@ def test_layer_split_stages_match_whole_model(G, O, wtype):
     st1.free()
     ws.free()
     whole.free()
+
+
+# ---- grouped-query attention (n_head_kv < n_head): n_rep = H / Hkv in the attention kernels, E_gqa-strided K/V stores of
+# the QKV epilogues, the i02 = i12 / r2 broadcast of the F16 mat-muls.  None of the LLaMA-1 shapes exercises it. ----------
+GQA = dict(n_vocab=256, n_embd=128, n_head=4, n_head_kv=2, n_layer=2, n_rot=32, n_ff=352, n_mult=32)
+
+
+@pytest.mark.parametrize("wtype", [2, 7])
+def test_gqa_prompt_plans_decode_plan_and_mfma_prefill_match_oracle(G, O, wtype):
+    """GQA model through every execution path of the N = 1..8 plans and the N >= 32 MFMA prefill, against the oracle on
+    the same K/V state (method and tolerances of test_logits_match_oracle_prompt_and_decode)."""
+    toks = np.random.default_rng(45).integers(0, 256, 60).astype(np.int32)
+    n_chunks = n_strict = 0
+    for seed in SEEDS[:2]:
+        hp, w, model = _mk(G, wtype, hp=GQA, ctx=128, seed=seed)
+        sess = model.start_session(n_batch=64)
+        orc, orc_m = O.Llama(hp, w, 128), O.Llama(hp, w, 128)
+        p0 = _stat(G, "plan_tokens")
+        chunks = (toks[:8], toks[8:13]) + tuple(toks[13 + i:14 + i] for i in range(5)) + (toks[18:58],)
+        for chunk in chunks:
+            got = sess.evaluate(chunk)
+            e0 = orc.evaluate(chunk, mode=0)
+            e1 = orc_m.evaluate(chunk, mode=1)
+            std = float(e1.std())
+            d0 = float(np.max(np.abs(got - e0))) / std
+            d1 = float(np.max(np.abs(got - e1))) / std
+            print(f"gqa type {wtype} seed {seed} N={len(chunk)}: gpu-vs-exact {d0:.2e} gpu-vs-math {d1:.2e}")
+            big = len(chunk) >= 32  # f16-rounded operands on the MFMA path: held to the math-mode bound
+            assert d0 <= (TOL_MATH if big else EDGE) and d1 <= TOL_MATH
+            n_chunks += 1
+            n_strict += d0 <= STRICT
+            k, v = sess.get_kv()
+            for o in (orc, orc_m):
+                o.memory_k[:] = k
+                o.memory_v[:] = v
+        assert _stat(G, "plan_tokens") - p0 == 18  # 8 + 5 on the multi-token plan, 5 on the decode plan
+        sess.free()
+        model.free()
+    assert n_strict >= n_chunks // 2, (n_strict, n_chunks)
+
+
+def test_gqa_split_attention_and_layer_split(G, O):
+    """GQA through the position-split decode attention (>= 512 positions) and through a two-stage layer split."""
+    from llm_amd import llama, synth
+    from llm_amd.pipeline import GpuStage
+    hp, w = synth.make_llama(GQA, 2, seed=7)
+    model = llama.Llama(hp, w, context_size=1024)
+    toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 600).astype(np.int32)
+    nxt = np.random.default_rng(10).integers(0, hp["n_vocab"], 4).astype(np.int32)
+    s = model.start_session(n_batch=8)
+    s.feed_prompt(toks)
+    orc = O.Llama(hp, w, 1024)
+    orc.evaluate(toks, mode=0)
+    before = _stat(G, "attn_split_tokens")
+    for t in nxt:
+        k, v = s.get_kv()
+        orc.memory_k[:] = k
+        orc.memory_v[:] = v
+        got = s.evaluate(np.array([t], np.int32))[-1]
+        ref = orc.evaluate(np.array([t], np.int32), mode=0)[-1]
+        assert float(np.max(np.abs(got - ref)) / ref.std()) <= EDGE
+    assert _stat(G, "attn_split_tokens") - before == len(nxt)
+    s.free()
+    model.free()
+    # two stages
+    whole = llama.Llama(hp, w, context_size=64)
+    ws = whole.start_session(n_batch=8)
+    st0 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 0, 1)}, (0, 1), 64)
+    st1 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 1, 2)}, (1, 2), 64)
+    st0.new_sequence(0)
+    st1.new_sequence(0)
+    chunk = toks[:6]
+    for step in range(4):
+        ref = ws.evaluate(chunk)
+        res = st0.evaluate(0, chunk, None)
+        st1.evaluate(0, chunk, res)
+        got = st1.sessions[0].last_logits()
+        assert float(np.max(np.abs(got - ref[-1])) / ref.std()) <= EDGE, step
+        chunk = np.array([int(np.argmax(ref[-1]))], np.int32)
+    st0.free()
+    st1.free()
+    ws.free()
+    whole.free()
+
+
+def test_decode_plan_with_a_16k_context_needs_more_than_64k_of_lds(G, O):
+    """The decode attention keeps context_size scores + probabilities in LDS: 16384 positions need 98 KB (above the
+    64 KB a kernel gets without asking).  The plan must run (not abort inside graph capture) and match the oracle;
+    a context that cannot fit the CU's LDS at all (32768) must fall back to the generic executor, not fail."""
+    toks = np.random.default_rng(46).integers(0, 256, 12).astype(np.int32)
+    for ctx, on_plan in ((16384, True), (32768, False)):
+        hp, w, model = _mk(G, 2, ctx=ctx, seed=7)
+        sess = model.start_session(n_batch=8)
+        orc = O.Llama(hp, w, 64)
+        sess.feed_prompt(toks[:8])
+        orc.evaluate(toks[:8], mode=0)
+        p0 = _stat(G, "plan_tokens")
+        for i in range(4):
+            got = sess.evaluate(toks[8 + i:9 + i])[-1]
+            ref = orc.evaluate(toks[8 + i:9 + i], mode=0)[-1]
+            assert float(np.max(np.abs(got - ref)) / ref.std()) <= EDGE, (ctx, i)
+        assert (_stat(G, "plan_tokens") - p0 == 4) == on_plan, ctx
+        sess.free()
+        model.free()
+
+
+def test_layer_split_hop_through_rccl_inside_the_library(G, O):
+    """SURVEY §8e behind the boundary: the residual crosses the stage boundary with ncclSend / ncclRecv issued by the
+    library on its own stream (ggml_hip_comm_*), no host copy and no host synchronisation for the hop.  A 1-GPU box can
+    only form a 1-rank communicator (RCCL refuses two ranks on one device), so both stages live in this process and the
+    hop is a send-to-self + receive-from-self in one RCCL group: the real RCCL point-to-point path on hardware.  The
+    result must be bit-identical to the same two stages with the hop done by a device memcpy, and within EDGE of the
+    whole model."""
+    import ctypes
+    from llm_amd import llama, synth
+    from llm_amd.pipeline import GpuStage
+    L = G.lib()
+    idb = (ctypes.c_ubyte * G.COMM_ID_BYTES)()
+    assert L.ggml_hip_comm_ranks() == 0
+    L.ggml_hip_comm_unique_id(idb)
+    assert L.ggml_hip_comm_init(0, 1, idb) == 1 and L.ggml_hip_comm_ranks() == 1
+    try:
+        hp, w = synth.make_llama(synth.TINY, 2, seed=7)
+        whole = llama.Llama(hp, w, context_size=64)
+        ws = whole.start_session(n_batch=8)
+        outs = {}
+        for mode in ("rccl", "memcpy"):
+            st0 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 0, 1)}, (0, 1), 64)
+            st1 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 1, 2)}, (1, 2), 64)
+            st0.new_sequence(0)
+            st1.new_sequence(0)
+            toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 6).astype(np.int32)
+            chunk, got = toks, []
+            for step in range(5):
+                n = len(chunk)
+                s0, s1 = st0.sessions[0], st1.sessions[0]
+                s0.evaluate(chunk, want_all_logits=False)
+                _, out_dev, _ = s0.stage_buffers()
+                in_dev, _, _ = s1.stage_buffers()
+                if mode == "rccl":
+                    L.ggml_hip_comm_sendrecv(out_dev, 0, in_dev, 0, n * hp["n_embd"] * 4)
+                else:
+                    L.ggml_hip_memcpy(in_dev, out_dev, n * hp["n_embd"] * 4, 2)
+                lg = s1.evaluate(chunk, want_all_logits=True)
+                got.append(lg[-1].copy())
+                chunk = np.array([int(np.argmax(lg[-1]))], np.int32)
+            outs[mode] = np.stack(got)
+            st0.free()
+            st1.free()
+        assert np.array_equal(outs["rccl"], outs["memcpy"])
+        chunk = toks
+        for step in range(5):
+            ref = ws.evaluate(chunk)
+            assert float(np.max(np.abs(outs["rccl"][step] - ref[-1])) / ref.std()) <= EDGE, step
+            chunk = np.array([int(np.argmax(outs["rccl"][step]))], np.int32)
+        ws.free()
+        whole.free()
+    finally:
+        L.ggml_hip_comm_destroy()
+    assert L.ggml_hip_comm_ranks() == 0
