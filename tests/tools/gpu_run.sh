@@ -3,8 +3,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | tail -15 > gpurun_out/r02_pytest.txt; cat gpurun_out/r02_pytest.txt
-timeout 600 python bench.py --steps 32 --warmup 4 > gpurun_out/r02_bench1.json 2> gpurun_out/r02_bench1.err; echo "bench rc=$?"; tail -5 gpurun_out/r02_bench1.err
-python - <<'PY'
+echo skip bench
+python - <<"PY" || true
 import json
 try:
     d=json.load(open("gpurun_out/r02_bench1.json")); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["all_matvecs_per_token"], d["config"]["prefill"], d["cpu_baseline"], d["config"]["prep"])
