@@ -33,6 +33,7 @@
 #include "kernels/mmvq.h"
 #include "kernels/mmq.h"
 #include "kernels/mmq_dma.h"
+#include "kernels/mmq_i8.h"
 #include "kernels/gemm_f16.h"
 #include "kernels/ops.h"
 #include "kernels/decode.h"
@@ -140,6 +141,8 @@ struct Backend {
     int opt_mmq_splitk = 1;
     int opt_mmq_dma = 1;    // prompt GEMM with LDS-DMA staging (kernels/mmq_dma.h) when K/32 is even; 2 = int8 activations
                             // dequantized in the kernel (13 KB instead of 20 KB per stage, 2x the VALU work: 413 vs 467 TFLOP/s)
+    int opt_mmq_i8 = 1;     // prompt GEMM on the integer matrix cores (kernels/mmq_i8.h): ggml's exact block dots; 0 = the f16
+                            // kernels below (operands rounded to f16)
     int opt_mmq_xcdn = 0;   // pin XCDs to token tiles (measured slower than the tile-id walk: 393 vs 446 TFLOP/s)
     int opt_mmq_min = 32;   // token count from which mul_mat runs on the MFMA GEMM (0 = never)
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
@@ -187,6 +190,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_PLAN_MULTI")) g.opt_plan_multi = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_I8")) g.opt_mmq_i8 = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_SPLITK")) g.opt_mmq_splitk = atoi(v);
     {
         hipDeviceProp_t prop;
@@ -751,12 +755,93 @@ void quantize_activation_q8p(const ggml_tensor *src1, bool f16_d, const int8_t *
     *dx = g_xq8.dx;
 }
 
+struct XI8Buf {  // int8 activations + f32 block scale + zero-point term of the integer prompt GEMM (kernels/mmq_i8.h)
+    const void *src_data = nullptr;
+    size_t src_bytes = 0;
+    int qt = -1;
+    int64_t nb = 0, ncols = 0;
+    const int8_t *q8 = nullptr;
+    const float *dx = nullptr, *xs = nullptr;
+    bool valid = false;
+} g_xi8;
+void quantize_activation_i8(const ggml_tensor *src1, int qt, const int8_t **q8, const float **dx, const float **xs) {
+    BK_ASSERT(src1->type == GGML_TYPE_F32 && src1->nb[0] == 4 && src1->ne[2] == 1 && src1->ne[3] == 1);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
+    const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
+    const float zp = qt == QT_Q4_0 ? 8.0f : qt == QT_Q5_0 ? 16.0f : 0.0f;
+    // Q4_0 and Q5_0 differ only in the zero point, Q4_1 and Q5_1 not at all: the cache is keyed on what was produced
+    const int key = f16_d ? (int)zp : 1000;
+    if (!(g_xi8.valid && g_xi8.src_data == src1->data && g_xi8.qt == key && g_xi8.nb == nb && g_xi8.ncols == N)) {
+        int8_t *o8 = (int8_t *)ws_alloc((size_t)N * K);
+        float *od = (float *)ws_alloc((size_t)N * nb * 4);
+        float *os = (float *)ws_alloc((size_t)N * nb * 4);
+        Timed tm(GGML_HIP_KCLASS_OTHER, (double)(K * N * 5));
+        const int64_t threads = nb * N * 32;
+        if (f16_d)
+            hipLaunchKernelGGL(k_quant_act_i8<true>, grid1(threads), dim3(256), 0, g.stream, dev_ptr(src1), (int64_t)src1->nb[1], nb,
+                               N, zp, o8, od, os);
+        else
+            hipLaunchKernelGGL(k_quant_act_i8<false>, grid1(threads), dim3(256), 0, g.stream, dev_ptr(src1), (int64_t)src1->nb[1], nb,
+                               N, zp, o8, od, os);
+        HIP_CHECK(hipGetLastError());
+        g_xi8.valid = true;
+        g_xi8.src_data = src1->data;
+        g_xi8.src_bytes = ggml_nbytes(src1);
+        g_xi8.qt = key;
+        g_xi8.nb = nb;
+        g_xi8.ncols = N;
+        g_xi8.q8 = o8;
+        g_xi8.dx = od;
+        g_xi8.xs = os;
+    }
+    *q8 = g_xi8.q8;
+    *dx = g_xi8.dx;
+    *xs = g_xi8.xs;
+}
+template <int QT>
+void launch_mmq_i8(const MmqI8Args &a, dim3 grid) {
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_i8<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS));
+    }
+    hipLaunchKernelGGL(k_mmq_i8<QT>, grid, dim3(256), I8_LDS, g.stream, a);
+}
+
 // Quantized GEMM on the f16 matrix cores (kernels/mmq.h); the `algo_bytes` slot of the MMQ_MFMA timing class
 // carries FLOPs (2*M*N*K), the unit that class is bounded by.
 void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
     const int qt = qt_of(src0->type);
     const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
     const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
+    if (g.opt_mmq_i8 && nb % 2 == 0) {  // integer matrix cores: ggml's exact block dots (kernels/mmq_i8.h)
+        MmqI8Args ia;
+        ia.w = qweight_of(src0);
+        quantize_activation_i8(src1, qt, &ia.x8, &ia.dx, &ia.xs);
+        ia.dst = (float *)dev_ptr(dst);
+        ia.ldd = (int64_t)dst->nb[1] / 4;
+        ia.M = ia.w.M;
+        ia.N = N;
+        ia.nb = nb;
+        const int tiles_m = (int)((ia.M + MMQ_TM - 1) / MMQ_TM);
+        ia.tiles_n = (int)((N + MMQ_TN - 1) / MMQ_TN);
+        const int nstage = (int)(nb / 2);
+        const int splits = (g.opt_mmq_splitk && tiles_m * ia.tiles_n * 2 <= g.num_cus * 3 && nstage >= 16 && dst->nb[0] == 4 &&
+                            ggml_is_contiguous(dst)) ? 2 : 1;  // two workgroups per CU: fewer than 1.5 tiles per slot -> split K
+        if (splits > 1) HIP_CHECK(hipMemsetAsync(ia.dst, 0, (size_t)ia.M * N * 4, g.stream));
+        const dim3 grid((unsigned)(tiles_m * ia.tiles_n), (unsigned)splits);
+        Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)ia.M * (double)N * (double)K);
+        switch (qt) {
+            case QT_Q4_0: launch_mmq_i8<QT_Q4_0>(ia, grid); break;
+            case QT_Q4_1: launch_mmq_i8<QT_Q4_1>(ia, grid); break;
+            case QT_Q5_0: launch_mmq_i8<QT_Q5_0>(ia, grid); break;
+            case QT_Q5_1: launch_mmq_i8<QT_Q5_1>(ia, grid); break;
+            case QT_Q8_0: launch_mmq_i8<QT_Q8_0>(ia, grid); break;
+            default: die("mmq: bad weight type");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     MmqArgs a;
     a.w = qweight_of(src0);
     const bool use_dma = g.opt_mmq_dma && nb % 2 == 0, use_x8 = use_dma && g.opt_mmq_dma >= 2;
@@ -1190,6 +1275,11 @@ void download_outputs(ggml_cgraph *gr) {
 
 void invalidate_xf16_if_overwritten_impl(const ggml_tensor *n);
 void invalidate_qact_if_overwritten(const ggml_tensor *n) {
+    if (g_xi8.valid && n->data != nullptr) {
+        const uintptr_t c0 = (uintptr_t)g_xi8.src_data, c1 = c0 + g_xi8.src_bytes;
+        const uintptr_t b0 = (uintptr_t)n->data, b1 = b0 + ggml_nbytes(n);
+        if (b0 < c1 && c0 < b1) g_xi8.valid = false;
+    }
     invalidate_xf16_if_overwritten_impl(n);
     if (!g_qact.valid || n->data == nullptr) return;
     const uintptr_t a0 = (uintptr_t)g_qact.src_data, a1 = a0 + g_qact.src_bytes;
@@ -1225,6 +1315,7 @@ void execute_graph(ggml_cgraph *gr) {
     g_qact.valid = false;
     g_xf16.valid = false;
     g_xq8.valid = false;
+    g_xi8.valid = false;
     if (try_decode_plan(gr)) return;  // single-token LLaMA decode: fused launches + hipGraph replay
     g.stat_generic_graphs++;
     upload_inputs(gr);
@@ -1421,6 +1512,7 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     g_qact.valid = false;
     g_xf16.valid = false;
     g_xq8.valid = false;
+    g_xi8.valid = false;
     int async = 0;
     if (try_decode_plan(cgraph, true)) {
         async = 1;
@@ -1722,6 +1814,8 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_mmq_splitk = value;
     else if (!strcmp(key, "mmq_dma"))
         g.opt_mmq_dma = value;
+    else if (!strcmp(key, "mmq_i8"))
+        g.opt_mmq_i8 = value;
     else
         die("ggml_hip_set_option: unknown key '%s'", key);
 }
