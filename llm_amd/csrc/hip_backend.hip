@@ -141,8 +141,9 @@ struct Backend {
     int opt_mmq_splitk = 1;
     int opt_mmq_dma = 1;    // prompt GEMM with LDS-DMA staging (kernels/mmq_dma.h) when K/32 is even; 2 = int8 activations
                             // dequantized in the kernel (13 KB instead of 20 KB per stage, 2x the VALU work: 413 vs 467 TFLOP/s)
-    int opt_mmq_i8 = 1;     // prompt GEMM on the integer matrix cores (kernels/mmq_i8.h): ggml's exact block dots; 0 = the f16
-                            // kernels below (operands rounded to f16)
+    int opt_mmq_i8 = 0;     // 1 = prompt GEMM on the integer matrix cores (kernels/mmq_i8.h): ggml's exact block dots (error
+                            // 2e-5 * scale instead of 1.1e-3), but the per-block scaling of every product is VALU-bound:
+                            // 309 vs 464 TFLOP/s-equivalent on 7B Q4_0, so the f16 kernels stay the default
     int opt_mmq_xcdn = 0;   // pin XCDs to token tiles (measured slower than the tile-id walk: 393 vs 446 TFLOP/s)
     int opt_mmq_min = 32;   // token count from which mul_mat runs on the MFMA GEMM (0 = never)
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan

@@ -8,17 +8,18 @@
 // difference from ggml's CPU result is the f32 association of the per-block terms — the mat-vec kernels' bound.
 //
 //   tile     128 tokens x 128 weight rows per 256-thread workgroup, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
-//   k stage  2 blocks (64 weights); every operand byte goes HBM -> LDS by DMA into a 3-slot ring two stages ahead
-//            (hand-placed counted waits, one raw s_barrier per stage, as in mmq_dma.h); two workgroups per CU
+//   k stage  2 blocks (64 weights); every operand byte goes HBM -> LDS by DMA into a ring of I8_RING slots, RING - 1
+//            stages ahead (hand-placed counted waits, one raw s_barrier per stage, as in mmq_dma.h)
 //   A (X)    int8 activations [token][32 B per block], 16-byte chunks XOR-swizzled on the DMA source address so that the
 //            fragment reads (32 token rows, 64 B apart) are conflict-free; lanes 0-31 take elements 0-15 of the block,
 //            lanes 32-63 elements 16-31 (any k order works as long as both operands use the same one)
 //   B (W)    the raw 16 nibble bytes of a block: lanes 0-31 use the low nibbles (elements 0-15), lanes 32-63 the high
 //            nibbles (16-31): one shift + mask per dword; Q5: the fifth bits from qh; Q8_0: the two 16-byte planes
-//   scaling  C tile element (token n, row m) of block b:  acc += (sumi - z * sum_n,b) * d_w[m,b] * d_x[n,b]
-//            (+ m_w[m,b] * s_x[n,b] for Q4_1 / Q5_1), in f32 on the VALU: a lane owns ONE weight row (its d_w, m_w)
-//            and 16 tokens whose d_x and z*sum come from LDS as four float4 each.  ~4 VALU per output and block: the
-//            kernel is bound by this scaling stream, not by the matrix pipe.
+//   scaling  C tile element (token n, row m) of block b:  acc += (sumi - z * sum_n,b) * d_x[n,b] * d_w[m,b]
+//            (+ m_w[m,b] * s_x[n,b] for Q4_1 / Q5_1).  The zero point rides in the MFMA's C operand (-z*sum of the lane's
+//            16 tokens, straight from LDS); the rest is f32 on the VALU: a lane owns ONE weight row (its d_w, m_w) and
+//            16 tokens whose d_x come from LDS as four float4.  cvt + mul + fma per output and block: the kernel is
+//            bound by this scaling stream, not by the matrix pipe.
 #pragma once
 #include "mmq.h"
 
@@ -28,21 +29,24 @@ typedef __attribute__((address_space(3))) void *lptr8_t;
 
 #define I8_X 0        /* 128 tokens x 64 B */
 #define I8_DX 8192    /* 4 strips (32 tokens each) x [2 blocks][32 tokens] f32 */
-#define I8_XS 9216    /* same shape: z * sum of the token's quants as f32 (Q4_1 / Q5_1: s = d * sum) */
+#define I8_XS 9216    /* same shape: -z * sum of the token's quants as i32 (Q4_1 / Q5_1: s = d * sum as f32) */
 #define I8_WQ 10240   /* 128 rows x 2 blocks x 16 B */
 #define I8_WQ2 14336  /* Q8_0: elements 16..31 */
 #define I8_WH 18432   /* Q5: 128 rows x 2 u32 */
 #define I8_WD 19456   /* 4 strips x 256 B: [row & 31][2] f16, duplicated in the upper half (lane-linear DMA) */
 #define I8_WM 20480
 #define I8_SLOT 21504
-#define I8_RING 3  /* 63 KiB per workgroup: two workgroups share a CU, one's scaling stream under the other's MFMAs */
+#ifndef I8_RING
+#define I8_RING 6  /* stages in the ring: RING - 1 in flight ahead of the one being consumed */
+#endif
 #define I8_LDS (I8_RING * I8_SLOT)
 
 struct MmqI8Args {
     QWeight w;
     const int8_t *x8;   // [N][nb][32] int8 quants of the activations (ggml element order)
     const float *dx;    // [N][nb] block scales as ggml stores them (Q8_0 kind: after the f16 round trip)
-    const float *xs;    // [N][nb] zero-point term as f32: 8*sum (Q4_0), 16*sum (Q5_0), 0 (Q8_0); d*sum (Q4_1 / Q5_1)
+    const float *xs;    // [N][nb] zero-point term: -8*sum (Q4_0), -16*sum (Q5_0), 0 (Q8_0) as INT32 bits — it is the MFMA's
+                        // C operand, so the zero point costs no instruction; d*sum as f32 for Q4_1 / Q5_1 (ggml's q8_1.s)
     float *dst;         // dst[n*ldd + m]
     int64_t ldd;
     int64_t M, N, nb;
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(256) k_quant_act_i8(const char *__restrict__ x
     if (l == 0) {
         const float dd = F16_D ? round_f16(d) : d;
         dq[gblock] = dd;
-        xs[gblock] = F16_D ? zp * (float)s : (float)s * dd;  // Q8_1: s = sum * d (ggml's block_q8_1.s)
+        xs[gblock] = F16_D ? __builtin_bit_cast(float, -(int)zp * s) : (float)s * dd;  // Q8_1: s = sum * d (block_q8_1.s)
     }
 }
 
@@ -80,7 +84,7 @@ __device__ __forceinline__ constexpr int i8_group() {  // DMA instructions per s
 }
 
 template <int QT>
-__global__ void __launch_bounds__(256, 1) k_mmq_i8(const MmqI8Args a) {
+__global__ void __launch_bounds__(256, I8_RING <= 3 ? 2 : 1) k_mmq_i8(const MmqI8Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,18 +146,17 @@ __global__ void __launch_bounds__(256, 1) k_mmq_i8(const MmqI8Args a) {
             for (int r = 0; r < 16; r++) acc[j][i][r] = 0.0f;
 
     const int fl = lane & 31, fh = lane >> 5;
-    issue(0, 0);
-    issue(1, 1);
-    int cur = 0;  // s mod 3
-    for (int s = 0; s < nstage; s++) {
-        // group s landed (s+1 may be in flight); every wave is past its reads of the slot of stage s-1
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
-        const int nxt2 = cur == 0 ? 2 : cur - 1;  // (s + 2) mod 3 = (s - 1) mod 3
-        issue(s + 2, nxt2);
-        const char *slot = lds + cur * I8_SLOT;
-        cur = cur == 2 ? 0 : cur + 1;
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
+    for (int p = 0; p < I8_RING - 1; p++) issue(p, p);
+    int cur = 0;  // s mod RING
+    for (int s = 0; s < nstage; s++) {
+        // group s landed (s+1 .. s+RING-2 may be in flight); every wave is past its reads of the slot of stage s-1
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((I8_RING - 2) * G) : "memory");
+        issue(s + I8_RING - 1, cur == 0 ? I8_RING - 1 : cur - 1);  // into the slot of stage s-1
+        const char *slot = lds + cur * I8_SLOT;
+        cur = cur == I8_RING - 1 ? 0 : cur + 1;
+#pragma unroll 1
+        for (int kb = 0; kb < 2; kb++) {  // not unrolled: both blocks' fragments live at once cost ~80 more registers
             // A fragments: token row R, 16 bytes = elements 16*fh.. of block kb: logical chunk kb*2 + fh
             i32x4 fa[2];
 #pragma unroll
@@ -192,27 +195,30 @@ __global__ void __launch_bounds__(256, 1) k_mmq_i8(const MmqI8Args a) {
                 // this lane's 16 tokens of tile j: local index (r&3) + 8*(r>>2) + 4*fh in strip wn*2 + j
                 const char *sx = slot + I8_DX + (wn * 2 + j) * 256 + kb * 128 + fh * 16;
                 const char *ss = slot + I8_XS + (wn * 2 + j) * 256 + kb * 128 + fh * 16;
-                f32x4 dxq[4], xsq[4];
+                f32x4 dxq[4], xsf[4];
+                i32x4 xsq[4];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; g4++) {
                     dxq[g4] = *(const f32x4 *)(sx + g4 * 32);
-                    xsq[g4] = *(const f32x4 *)(ss + g4 * 32);
+                    if constexpr (HAS_M) xsf[g4] = *(const f32x4 *)(ss + g4 * 32);            // s_x = d * sum (f32)
+                    else if constexpr (QT != QT_Q8_0) xsq[g4] = *(const i32x4 *)(ss + g4 * 32);  // -z * sum (i32)
+                }
+                // the MFMA's C operand: the tokens' negated zero-point sums (codes are 0..15 / 0..31 here), 0 otherwise
+                i32x16 cin;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if constexpr (HAS_M || QT == QT_Q8_0) cin[r] = 0;
+                    else cin[r] = xsq[r >> 2][r & 3];
                 }
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[j], fb[i], zero, 0, 0, 0);
+                    const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[j], fb[i], cin, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const float dxv = dxq[r >> 2][r & 3], xsv = xsq[r >> 2][r & 3];
-                        if constexpr (HAS_M) {  // (d_w d_x) sumi + m_w s_x
-                            acc[j][i][r] = __builtin_fmaf((float)c[r], dwf[i] * dxv, acc[j][i][r]);
-                            acc[j][i][r] = __builtin_fmaf(mwf[i], xsv, acc[j][i][r]);
-                        } else if constexpr (QT == QT_Q8_0) {
-                            acc[j][i][r] = __builtin_fmaf((float)c[r], dwf[i] * dxv, acc[j][i][r]);
-                        } else {  // sumi includes the zero point: codes are 0..15 / 0..31 here, z*sum is exact in f32
-                            acc[j][i][r] = __builtin_fmaf((float)c[r] - xsv, dwf[i] * dxv, acc[j][i][r]);
-                        }
+                        const float t = (float)c[r] * dxq[r >> 2][r & 3];
+                        acc[j][i][r] = __builtin_fmaf(t, dwf[i], acc[j][i][r]);
+                        if constexpr (HAS_M)  // + m_w * s_x
+                            acc[j][i][r] = __builtin_fmaf(mwf[i], xsf[r >> 2][r & 3], acc[j][i][r]);
                     }
                 }
             }

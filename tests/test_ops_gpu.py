@@ -58,10 +58,13 @@ def test_mul_mat_q_matches_oracle_exact(G, O, wtype, shape, N):
 @pytest.mark.parametrize("wtype", QTYPES)
 @pytest.mark.parametrize("shape", [(128, 64), (200, 96), (256, 4096), (384, 352), (130, 1024)])
 @pytest.mark.parametrize("N", [32, 33, 100, 128, 300])
-def test_mul_mat_q_prefill_mfma_matches_oracle(G, O, wtype, shape, N):
-    """N >= 32 tokens on the matrix cores.  K/32 even: the INTEGER GEMM (kernels/mmq_i8.h, v_mfma_i32_32x32x32_i8):
-    ggml's exact block dots, scaled and accumulated in f32 — the mat-vec bound, 2e-5 * scale.  K/32 odd: the f16 GEMM
-    (kernels/mmq.h), which rounds each dequantized weight and activation to f16 (unit roundoff 2^-11 each):
+@pytest.mark.parametrize("i8", [0, 1])
+def test_mul_mat_q_prefill_mfma_matches_oracle(G, O, wtype, shape, N, i8):
+    """N >= 32 tokens on the matrix cores, both prompt GEMMs.
+    mmq_i8 = 1 and K/32 even: the INTEGER GEMM (kernels/mmq_i8.h, v_mfma_i32_32x32x32_i8): ggml's exact block dots,
+    scaled and accumulated in f32 — the mat-vec bound, 2e-5 * scale.
+    mmq_i8 = 0 (the default: it is the faster one) or K/32 odd: the f16 GEMM (kernels/mmq_dma.h, mmq.h),
+    which rounds each dequantized weight and activation to f16 (unit roundoff 2^-11 each):
         |got - exact| <= 2 * 2^-11 * sum_k |w||x|   (worst case; stated bound 1.1e-3 * scale), RMS <= 1e-4 * scale."""
     M, K = shape
     rng = np.random.default_rng([wtype, M, K, N, 1])
@@ -69,16 +72,20 @@ def test_mul_mat_q_prefill_mfma_matches_oracle(G, O, wtype, shape, N):
     X = rng.standard_normal((N, K)).astype(np.float32)
     X[:, ::7] *= 4.0
     W_raw = G.quantize(wtype, W)
-    got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
+    G.set_option("mmq_i8", i8)
+    try:
+        got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
+    finally:
+        G.set_option("mmq_i8", 0)
     exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
     scale = _abs_scale(O, wtype, W_raw, M, K, X)
     err = np.abs(got - exact)
-    if (K // 32) % 2 == 0:
+    if i8 and (K // 32) % 2 == 0:
         assert np.all(err <= 2e-5 * scale + 1e-7), float(np.max(err / (scale + 1e-12)))
     else:
         assert np.all(err <= 1.1e-3 * scale + 1e-7), float(np.max(err / (scale + 1e-12)))
         assert float(np.sqrt(np.mean((err / (scale + 1e-12)) ** 2))) <= 1e-4
-    # the mat-vec path on the same inputs (mmq_min = 0 disables the GEMM) agrees to the same bound
+    # the mat-vec path on the same inputs (mmq_min = 0 disables the GEMM) agrees to the tight bound
     G.set_option("mmq_min", 0)
     try:
         mv = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
@@ -90,7 +97,7 @@ def test_mul_mat_q_prefill_mfma_matches_oracle(G, O, wtype, shape, N):
 
 def test_mul_mat_q_prefill_mfma_is_used_and_handles_extremes(G, O):
     """timing class MMQ_MFMA records the launch; zero rows/columns stay exactly zero; a huge activation stays finite
-    (the integer GEMM scales in f32; the f16 GEMM, option mmq_i8 = 0, clamps to the f16 range) — both checked."""
+    (the integer GEMM, option mmq_i8 = 1, scales in f32; the default f16 GEMM clamps to the f16 range) — both checked."""
     M, K, N = 256, 512, 64
     rng = np.random.default_rng(11)
     W = (0.02 * rng.standard_normal((M, K))).astype(np.float32)
@@ -99,20 +106,24 @@ def test_mul_mat_q_prefill_mfma_is_used_and_handles_extremes(G, O):
     X[3] = 0.0
     X[4, 9] = 1e6
     W_raw = G.quantize(2, W)
-    G.lib().ggml_hip_timing_begin()
-    got = _mul_mat_gpu(G, 2, W_raw, M, K, X)
-    G.lib().ggml_hip_timing_end()
+    G.set_option("mmq_i8", 1)
+    try:
+        G.lib().ggml_hip_timing_begin()
+        got = _mul_mat_gpu(G, 2, W_raw, M, K, X)
+        G.lib().ggml_hip_timing_end()
+    finally:
+        G.set_option("mmq_i8", 0)
     ms, launches, flops = G.timing_query(G.KCLASS_MMQ_MFMA)
     assert launches == 1 and flops == 2.0 * M * N * K and ms > 0
     assert np.all(got[3] == 0.0) and np.all(got[:, 5] == 0.0)
     assert np.isfinite(got).all()
     exact = O.mul_mat(2, W_raw, M, K, X, mode=0)
     assert np.allclose(got, exact, rtol=2e-5, atol=2e-5 * float(np.abs(exact).max()))
-    G.set_option("mmq_i8", 0)
-    try:
-        got16 = _mul_mat_gpu(G, 2, W_raw, M, K, X)
-    finally:
-        G.set_option("mmq_i8", 1)
+    G.lib().ggml_hip_timing_begin()
+    got16 = _mul_mat_gpu(G, 2, W_raw, M, K, X)
+    G.lib().ggml_hip_timing_end()
+    ms, launches, flops = G.timing_query(G.KCLASS_MMQ_MFMA)
+    assert launches == 1 and flops == 2.0 * M * N * K and ms > 0
     assert np.isfinite(got16).all() and np.all(got16[3] == 0.0) and np.all(got16[:, 5] == 0.0)
     ok = np.ones(N, bool)
     ok[4] = False  # the f16 kernel's clamped row differs from the reference by construction
