@@ -31,12 +31,28 @@ struct BigStep {
     __half mw[(QT == QT_Q4_1 || QT == QT_Q5_1) ? NR : 1];
 };
 
+// Ring depth = weight steps in flight per lane.  NOT "as many as the registers hold": a CU accepts only so many
+// outstanding requests, and a wave whose next load is not accepted sits in ISSUE — it reaches neither the staging
+// barrier nor its dots.  With the whole launch requested up front (6 steps of 2 rows) the barrier of w1|w3 fell at
+// 6.8 us of a 8.9 us kernel and all the integer work ran after the fetch instead of under it (in-kernel timeline,
+// tests/tools/timeline.py; halving the dots saved 1.1 us per launch).  ~6 KB per wave (x 15..16 waves per CU) keeps
+// the memory pipeline full and lets the barrier fall right after the staging: w1|w3 13.1 -> 11.6 us per launch,
+// wq|wk|wv 9.6 -> 8.5, wo 5.0 -> 4.3.
+#ifndef BIG_PF1
+#define BIG_PF1 5  // steps of 1 row  (1 KB of Q4/Q5 quants each)
+#endif
+#ifndef BIG_PF2
+#define BIG_PF2 3  // steps of 2 rows
+#endif
 template <int QT>
 __device__ __forceinline__ constexpr int big_pf(int NR) {
-    // ring depth: ~64 VGPRs of weight data in flight per lane
+    // at most ~64 VGPRs of weight data in flight per lane (Q8_0 and the 5-bit types carry more per row)
     const int per = NR * (4 + (QT == QT_Q8_0 ? 4 : 0) + ((QT == QT_Q5_0 || QT == QT_Q5_1) ? 1 : 0) + 1 +
                           ((QT == QT_Q4_1 || QT == QT_Q5_1) ? 1 : 0));
-    return 64 / per >= 8 ? 8 : 64 / per >= 2 ? 64 / per : 2;  // Q4_0: 6 steps of 2 rows, 8 steps of 1 row
+    const int fit = 64 / per >= 2 ? 64 / per : 2;
+    int pf = NR == 1 ? BIG_PF1 : NR == 2 ? BIG_PF2 : 2;
+    if (QT == QT_Q8_0) pf = (pf + 1) / 2;  // two 16-byte planes per row step
+    return pf < 2 ? 2 : pf > fit ? fit : pf;
 }
 
 #ifndef BIG_T
@@ -55,8 +71,9 @@ struct BigArgs {
     long long *ts;  // optional timeline slot (ggml_hip_set_option("timeline", n)): 8 x int64 per sampled workgroup
     int ts_wgs;     // workgroups that record: 0, G/n, 2G/n, ... (n = 4 for "timeline" = 1, else the option's value)
     const float *rope;  // EPI_QKV: (cos, sin) of this token's RoPE angle per pair of a head, from k_rope_table
-    int probe;          // measurement only (ggml_hip_set_option("probe", n), tests/tools/launch_probe.py): 1 = return at
-                        // entry, 2 = return once x is staged and the ring requested, 3 = no epilogue stores; 0 = normal
+    int probe;          // measurement only (ggml_hip_set_option("probe", n), tests/tools/launch_probe.py): 1 = return before
+                        // the first weight request, 2 = return once x is staged and the ring requested, 3 = no epilogue stores, 4 = every
+                        // other step's dots skipped, 5 = no wave reductions; 0 = normal
 };
 __device__ __forceinline__ long long big_now() { return (long long)wall_clock64(); }  // 100 MHz, chip-wide
 
@@ -208,7 +225,6 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     // those drains the whole in-order load queue at every step
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    if (ba.probe == 1) return;
     const long long t_entry = ba.ts ? big_now() : 0;
     // ---- 1. the activation's loads go first (see BigX); so does the position (needed by the QKV epilogue only)
     int n_past = 0;
@@ -227,7 +243,13 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     // contiguous window of G*16 units of the matrix.  Lane i of the wave owns unit i's epilogue.
     const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0, M2 = EPI == EPI_QKV ? (int)a.w[2].M : 0;
     const int Utot = (M0 + M1 + M2) / RU;
+#ifdef BIG_DEAL_WG_MAJOR
     const int u_first = (int)blockIdx.x * W + wave, u_stride = (int)gridDim.x * W;
+#else
+    // wave-major within a round: the units of the last, partial round go to waves 0..k of EVERY workgroup, so all CUs
+    // stream the same number of rows (11008 w1|w3 rows: 43 per CU instead of 45 on 222 CUs and 30 on 34)
+    const int u_first = wave * (int)gridDim.x + (int)blockIdx.x, u_stride = (int)gridDim.x * W;
+#endif
     const int nu = u_first < Utot ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
     const int S = nu * nbl;
     // EPI_ADD: lane i preloads the residual of unit i (a load issued in the epilogue would drain the queue)
@@ -303,6 +325,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
         }
     };
 
+    if (ba.probe == 1) return;  // here, not at entry: a check at entry costs every launch one more scalar-cache round trip
     // ---- 2. weight prologue, part 1: PF0 steps.  Enough to cover the latency of x, little enough that x is not
     //         queued behind tens of MB of weight requests in the fabric (measured with the in-kernel timeline:
     //         with the full ring requested up front x took 3..6 us to arrive)
@@ -360,6 +383,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
                 const BigStep<QT, NR> &st = ring[k];
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
+                    if (ba.probe == 4 && (k & 1)) continue;  // measurement: half the dots
                     u32x4 p2 = st.q[r];
                     uint32_t hh = 0;
                     float mw = 0.0f;
@@ -373,7 +397,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
                     cj = 0;
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
-                        const float v = wave_sum_f32(acc[r]);
+                        const float v = ba.probe == 5 ? acc[r] : wave_sum_f32(acc[r]);  // 5: measurement, no reduction
                         myv[r] = lane == ci ? v : myv[r];
                         acc[r] = 0.0f;
                     }

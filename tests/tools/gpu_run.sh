@@ -2,9 +2,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-for r in 3 4 6; do GGML_HIP_LIB=$PWD/llm_amd/libggml_hip_ring$r.so timeout 300 python bench.py --mode prefill --steps 5 --warmup 2 --weights blocks > gpurun_out/r02_prefill_ring$r.json 2>gpurun_out/r02_prefill.err; python - <<PY
-import json
-d=json.load(open("gpurun_out/r02_prefill_ring$r.json")); print("ring=$r", d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["class_ms_per_step"])
-PY
-done
-GGML_HIP_LIB=$PWD/llm_amd/libggml_hip_ring6.so timeout 600 python -m pytest tests/test_ops_gpu.py -q -x -k "prefill" 2>&1 | tail -4
+timeout 300 python tests/tools/launch_probe.py 7b q4_0 2>&1 | tail -9 | tee gpurun_out/r02_launch_probe_b.txt
+timeout 300 python tests/tools/timeline.py 7b 256 2>&1 | tail -38 | tee gpurun_out/r02_timeline_b.txt
+timeout 900 python -m pytest tests/test_llama_gpu.py tests/test_ops_gpu.py -q -x 2>&1 | tail -3

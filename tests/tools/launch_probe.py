@@ -7,6 +7,7 @@
      probe 1 = return at entry (kernel arguments read)         -> boundary + launch shape
      probe 2 = return once x is staged and the ring requested  -> + prologue
      probe 3 = everything but the epilogue stores
+     probe 4 = every other step's dots skipped;  probe 5 = no wave reductions
      probe 0 = the real kernel
    for the 2-steps-before-staging kernel ("big" = 1) and the whole-ring-first kernel ("big" = 2);
 3. decode tokens/s of both.
@@ -55,9 +56,9 @@ def main():
         L.ggml_hip_synchronize()
         dt = time.perf_counter() - t0
         print(f"== big={big}: decode {n / dt:.1f} tok/s ({dt / n * 1e3:.4f} ms/token) ==")
-        print("  kind      bytes/launch | probe1  probe2  probe3   full  (us per launch incl. boundary) | full GB/s")
+        print("  kind      bytes/launch | probe1  probe2  probe3  probe4  probe5   full  (us per launch incl. boundary) | full GB/s")
         rows = {}
-        for probe in (1, 2, 3, 0):
+        for probe in (1, 2, 3, 4, 5, 0):
             ggml.set_option("probe", probe)
             s.infer_next_token()  # rebuilds the plan with the probe level (results are garbage for probe != 0)
             for k, nm in enumerate(kinds):
@@ -65,8 +66,8 @@ def main():
                 rows.setdefault(nm, {})[probe] = (ms * 1e3 / max(kn * 20, 1), kb / max(kn, 1))
         for nm in kinds:
             r = rows[nm]
-            print(f"  {nm:8s} {int(r[0][1]):12d} | {r[1][0]:6.2f} {r[2][0]:7.2f} {r[3][0]:7.2f} {r[0][0]:6.2f}"
-                  f"                                 | {r[0][1] / 1e3 / r[0][0]:8.1f}")
+            print(f"  {nm:8s} {int(r[0][1]):12d} | {r[1][0]:6.2f} {r[2][0]:7.2f} {r[3][0]:7.2f} {r[4][0]:7.2f} {r[5][0]:7.2f} {r[0][0]:6.2f}"
+                  f"                 | {r[0][1] / 1e3 / r[0][0]:8.1f}")
         ms, kn, kb = ggml.bench_plan_class(ggml.KCLASS_MMVQ, 20)
         print(f"  all mat-vecs of a token: {ms / 20:.4f} ms, {kb * 20 / 1e9 / (ms / 1e3):.1f} GB/s incl. boundaries")
         ams, an, _ = ggml.bench_plan_class(ggml.KCLASS_ATTN, 20)
