@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "65b", "tiny"])
-    ap.add_argument("--wtype", default="q4_0", choices=["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+    ap.add_argument("--wtype", default="q4_0", choices=["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_k", "q6_k"])
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -51,7 +51,9 @@ def build_model(args, layer_range=None):
     from llm_amd import ggml, llama, synth
     hp = {"7b": synth.LLAMA_7B, "13b": synth.LLAMA_13B, "65b": synth.LLAMA_65B, "tiny": synth.TINY}[args.model]
     wtype = {"q4_0": ggml.TYPE_Q4_0, "q4_1": ggml.TYPE_Q4_1, "q5_0": ggml.TYPE_Q5_0, "q5_1": ggml.TYPE_Q5_1,
-             "q8_0": ggml.TYPE_Q8_0}[args.wtype]
+             "q8_0": ggml.TYPE_Q8_0, "q4_k": ggml.TYPE_Q4_K, "q6_k": ggml.TYPE_Q6_K}[args.wtype]
+    if wtype in ggml.K_TYPES and args.weights == "gaussian":
+        args.weights = "blocks"  # the library has no K-quant encoder
     t0 = time.perf_counter()
     hp, w = (synth.make_llama_gaussian if args.weights == "gaussian" else synth.make_llama_fast)(hp, wtype)
     t1 = time.perf_counter()
@@ -61,11 +63,11 @@ def build_model(args, layer_range=None):
     return hp, w, model, {"gen_s": t1 - t0, "upload_s": t2 - t1}
 
 
-def weight_bytes_per_token(hp, wtype_bytes):
+def weight_bytes_per_token(hp, wtype_bytes, blck=32):
     E, F, V, L = hp["n_embd"], hp["n_ff"], hp["n_vocab"], hp["n_layer"]
     Egqa = E // (hp["n_head"] // hp["n_head_kv"])
     params = L * (2 * E * E + 2 * E * Egqa + 3 * E * F) + V * E  # 7 mat-vecs per layer + lm_head
-    return params // 32 * wtype_bytes, params
+    return params // blck * wtype_bytes, params
 
 
 def cpu_baseline(args, hp, w, budget_s):
@@ -228,7 +230,7 @@ def run_single(args):
     nl = hp["n_layer"]
     dom = per_kind["gate_up"]
     achieved = dom["GBps"]
-    wb, nparams = weight_bytes_per_token(hp, ggml.BLOCK_BYTES[hp["wtype"]])
+    wb, nparams = weight_bytes_per_token(hp, ggml.BLOCK_BYTES[hp["wtype"]], ggml.BLOCK_ELEMS[hp["wtype"]])
     traffic, traffic_from = None, None
     for tp in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tp)

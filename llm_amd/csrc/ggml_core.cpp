@@ -109,7 +109,7 @@ static const type_info TYPE_INFO[GGML_TYPE_COUNT] = {
     /* Q5_1 */ {"q5_1", 32, 24, true},
     /* Q8_0 */ {"q8_0", 32, 34, true},
     /* Q8_1 */ {"q8_1", 32, 40, true},
-    /* K-quants: named by the ABI (lib.rs:61-66) but outside this path */
+    /* K-quants (lib.rs:61-66): Q4_K and Q6_K run on the device (kernels/kquant.h); the others are sized only */
     {"q2_K", 256, 84, true},
     {"q3_K", 256, 110, true},
     {"q4_K", 256, 144, true},
@@ -921,6 +921,11 @@ ggml_type_traits_t ggml_internal_get_type_traits(enum ggml_type i) {
         case GGML_TYPE_Q8_0: t.vec_dot_type = GGML_TYPE_Q8_0; break;
         case GGML_TYPE_Q4_1:
         case GGML_TYPE_Q5_1: t.vec_dot_type = GGML_TYPE_Q8_1; break;
+        case GGML_TYPE_Q2_K:
+        case GGML_TYPE_Q3_K:
+        case GGML_TYPE_Q4_K:
+        case GGML_TYPE_Q5_K:
+        case GGML_TYPE_Q6_K: t.vec_dot_type = GGML_TYPE_Q8_K; break;
         case GGML_TYPE_F16: t.vec_dot_type = GGML_TYPE_F16; break;
         default: t.vec_dot_type = GGML_TYPE_F32; break;
     }

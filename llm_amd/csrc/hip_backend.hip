@@ -34,6 +34,7 @@
 #include "kernels/mmq.h"
 #include "kernels/mmq_dma.h"
 #include "kernels/mmq_i8.h"
+#include "kernels/kquant.h"
 #include "kernels/gemm_f16.h"
 #include "kernels/ops.h"
 #include "kernels/decode.h"
@@ -92,6 +93,8 @@ struct DevTensor {
     bool zero_filled = false;     // created by assign_buffers_no_scratch (mutable state: never shared)
     uintptr_t owner_hdr = 0;      // auto-uploaded only: address of the ggml_tensor header that named this data
     QWeight qw{};
+    bool ksoa = false;            // K-quant planar layout (see KWeight, kernels/kquant.h)
+    KWeight kw{};
     ggml_type type = GGML_TYPE_F32;
     int64_t ne[4] = {0, 0, 0, 0};
 };
@@ -157,6 +160,7 @@ struct Backend {
     size_t dead_shadow_bytes = 0;
 } g;
 
+int kt_of(ggml_type t) { return t == GGML_TYPE_Q4_K ? KT_Q4_K : t == GGML_TYPE_Q6_K ? KT_Q6_K : -1; }
 int qt_of(ggml_type t) {
     switch (t) {
         case GGML_TYPE_Q4_0: return QT_Q4_0;
@@ -542,6 +546,43 @@ bool wants_soa(const ggml_tensor *t) {
     return qt_of(t->type) >= 0 && t->ne[2] == 1 && t->ne[3] == 1 && t->ne[0] % 32 == 0 && ggml_is_contiguous(t);
 }
 
+// K-quants (kernels/kquant.h): planes {qs, aux (Q6_K), sc, d}
+size_t kw_layout(int kt, int64_t nsbt, size_t off[4]) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    off[0] = o;
+    o = al(o + (size_t)nsbt * 128);
+    off[1] = o;
+    if (kt == KT_Q6_K) o = al(o + (size_t)nsbt * 64);
+    off[2] = o;
+    o = al(o + (size_t)nsbt * 16);
+    off[3] = o;
+    o = al(o + (size_t)nsbt * (kt == KT_Q4_K ? 4 : 2));
+    return o;
+}
+KWeight kw_at(char *base, int kt, int64_t M, int64_t nsb) {
+    size_t off[4];
+    kw_layout(kt, M * nsb, off);
+    KWeight w;
+    w.qs = (const uint8_t *)(base + off[0]);
+    w.aux = (const uint32_t *)(base + off[1]);
+    w.sc = (const uint8_t *)(base + off[2]);
+    w.d = (const __half *)(base + off[3]);
+    w.M = M;
+    w.nsb = nsb;
+    w.kt = kt;
+    return w;
+}
+void relayout_k_launch(const char *raw_dev, int kt, int64_t M, int64_t nsb, char *base) {
+    const KWeight w = kw_at(base, kt, M, nsb);
+    hipLaunchKernelGGL(k_relayout_k, grid1(M * nsb * 8), dim3(256), 0, g.stream, (const uint8_t *)raw_dev, kt, M * nsb,
+                       (uint8_t *)w.qs, (uint32_t *)w.aux, (uint8_t *)w.sc, (__half *)w.d);
+    HIP_CHECK(hipGetLastError());
+}
+bool wants_ksoa(const ggml_tensor *t) {
+    return kt_of(t->type) >= 0 && t->ne[2] == 1 && t->ne[3] == 1 && t->ne[0] % 256 == 0 && ggml_is_contiguous(t);
+}
+
 // Uploads `nbytes` from host `data` as the device copy of `t`. Returns the record (registered in g.tensors).
 DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill, bool is_auto = false) {
     ensure_init();
@@ -580,6 +621,21 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill,
         HIP_CHECK(hipFree(tmp));
         e->soa = true;
         e->qw = qw_at(e->dev, qt, M, nb);
+    } else if (!zero_fill && wants_ksoa(t)) {
+        const int kt = kt_of(t->type);
+        const int64_t M = t->ne[1], nsb = t->ne[0] / 256;
+        size_t off[4];
+        const size_t total = kw_layout(kt, M * nsb, off);
+        HIP_CHECK(hipMalloc((void **)&e->dev, total));
+        e->dev_bytes = total;
+        char *tmp = nullptr;
+        HIP_CHECK(hipMalloc((void **)&tmp, nbytes));
+        h2d_bulk(tmp, data, nbytes);
+        relayout_k_launch(tmp, kt, M, nsb, e->dev);
+        HIP_CHECK(hipStreamSynchronize(g.stream));
+        HIP_CHECK(hipFree(tmp));
+        e->ksoa = true;
+        e->kw = kw_at(e->dev, kt, M, nsb);
     } else {
         HIP_CHECK(hipMalloc((void **)&e->dev, std::max<size_t>(nbytes, 16)));
         e->dev_bytes = nbytes;
@@ -636,6 +692,24 @@ QWeight qweight_of(const ggml_tensor *t) {
     char *soa = ws_alloc(total);
     relayout_launch(raw, qt, M, nb, soa);
     return qw_at(soa, qt, M, nb);
+}
+
+KWeight kweight_of(const ggml_tensor *t) {
+    DevTensor *e = extra_of(t);
+    if (!e) e = find_tensor((uintptr_t)t->data);
+    if (e && e->ksoa) {
+        if ((uintptr_t)t->data != e->host || t->ne[0] != e->ne[0] || t->ne[1] != e->ne[1])
+            die("tensor '%s': views of re-laid-out quantized weights are not supported", t->name);
+        return e->kw;
+    }
+    if (!wants_ksoa(t)) die("tensor '%s': K-quant operand must be a contiguous 2-D matrix with ne0 %% 256 == 0", t->name);
+    const int kt = kt_of(t->type);
+    const int64_t M = t->ne[1], nsb = t->ne[0] / 256;
+    size_t off[4];
+    const size_t total = kw_layout(kt, M * nsb, off);
+    char *soa = ws_alloc(total);
+    relayout_k_launch(dev_ptr(t), kt, M, nsb, soa);
+    return kw_at(soa, kt, M, nsb);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -807,6 +881,88 @@ void launch_mmq_i8(const MmqI8Args &a, dim3 grid) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_i8<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS));
     }
     hipLaunchKernelGGL(k_mmq_i8<QT>, grid, dim3(256), I8_LDS, g.stream, a);
+}
+
+// ---- K-quant mat-vec (kernels/kquant.h): Q8_K activations (ggml's vec_dot_type of every K-quant), one launch per
+// chunk of up to 8 columns.  Prompt batches take the same kernel (weights streamed once per 8 tokens): there is no
+// K-quant GEMM yet.
+struct XKBuf {
+    const void *src_data = nullptr;
+    size_t src_bytes = 0;
+    int64_t nsb = 0, ncols = 0;
+    KAct act{};
+    bool valid = false;
+} g_xk;
+KAct quantize_activation_k(const ggml_tensor *src1) {
+    BK_ASSERT(src1->type == GGML_TYPE_F32 && src1->nb[0] == 4 && src1->ne[2] == 1 && src1->ne[3] == 1);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nsb = K / 256;
+    if (!(g_xk.valid && g_xk.src_data == src1->data && g_xk.nsb == nsb && g_xk.ncols == N)) {
+        int8_t *q8 = (int8_t *)ws_alloc((size_t)N * K);
+        float *d8 = (float *)ws_alloc((size_t)N * nsb * 4);
+        int16_t *bs = (int16_t *)ws_alloc((size_t)N * nsb * 32);
+        Timed tm(GGML_HIP_KCLASS_OTHER, (double)(K * N * 5));
+        hipLaunchKernelGGL(k_quant_q8k, dim3((unsigned)nsb, (unsigned)N), dim3(256), 0, g.stream, dev_ptr(src1),
+                           (int64_t)src1->nb[1], nsb, q8, d8, bs);
+        HIP_CHECK(hipGetLastError());
+        g_xk.valid = true;
+        g_xk.src_data = src1->data;
+        g_xk.src_bytes = ggml_nbytes(src1);
+        g_xk.nsb = nsb;
+        g_xk.ncols = N;
+        g_xk.act = KAct{q8, d8, bs};
+    }
+    return g_xk.act;
+}
+template <int KT, int NCOLS>
+void launch_mmvq_k(const MmvqKArgs &a, int nwg, size_t lds) {
+    static size_t opted = 64 * 1024;
+    if (lds > opted) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmvq_k<KT, NCOLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        opted = 150 * 1024;
+    }
+    hipLaunchKernelGGL((k_mmvq_k<KT, NCOLS>), dim3(nwg), dim3(256), lds, g.stream, a);
+}
+template <int KT>
+void launch_mmvq_k_c(const MmvqKArgs &a, int ncols, int nwg, size_t lds) {
+    switch (ncols) {
+        case 1: launch_mmvq_k<KT, 1>(a, nwg, lds); break;
+        case 2: launch_mmvq_k<KT, 2>(a, nwg, lds); break;
+        case 4: launch_mmvq_k<KT, 4>(a, nwg, lds); break;
+        default: launch_mmvq_k<KT, 8>(a, nwg, lds); break;
+    }
+}
+void mul_mat_k(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
+    const int kt = kt_of(src0->type);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nsb = K / 256;
+    BK_ASSERT(K % 256 == 0 && src0->ne[0] == K && dst->type == GGML_TYPE_F32 && dst->nb[0] == 4);
+    const KWeight w = kweight_of(src0);
+    const KAct act = quantize_activation_k(src1);
+    const size_t col_lds = (size_t)K + (size_t)nsb * (4 + 64);
+    if (col_lds > 150 * 1024) die("mul_mat: K=%lld too large for the LDS-staged K-quant mat-vec", (long long)K);
+    const double sb_bytes = kt == KT_Q4_K ? 148.0 : 210.0;
+    int64_t c0 = 0;
+    while (c0 < N) {
+        int ncols = 8;
+        while (ncols > 1 && (ncols > N - c0 || (size_t)ncols * col_lds > 150 * 1024)) ncols >>= 1;
+        MmvqKArgs a;
+        a.w = w;
+        a.x.q8 = act.q8 + c0 * K;
+        a.x.d8 = act.d8 + c0 * nsb;
+        a.x.bs = act.bs + c0 * nsb * 16;
+        a.dst = (float *)(dev_ptr(dst) + c0 * dst->nb[1]);
+        a.ldd = (int64_t)dst->nb[1] / 4;
+        const size_t lds = (size_t)ncols * col_lds;
+        // enough workgroups to fill the CUs' wave slots at this LDS footprint, never more than one row per wave
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / std::max<size_t>(lds, 1)));
+        const int nwg = (int)std::min<int64_t>((w.M + 3) / 4, (int64_t)g.num_cus * per_cu);
+        Timed tm(GGML_HIP_KCLASS_MMVQ, (double)w.M * nsb * sb_bytes + (double)w.M * ncols * 4 + (double)lds);
+        if (kt == KT_Q4_K)
+            launch_mmvq_k_c<KT_Q4_K>(a, ncols, nwg, lds);
+        else
+            launch_mmvq_k_c<KT_Q6_K>(a, ncols, nwg, lds);
+        HIP_CHECK(hipGetLastError());
+        c0 += ncols;
+    }
 }
 
 // Quantized GEMM on the f16 matrix cores (kernels/mmq.h); the `algo_bytes` slot of the MMQ_MFMA timing class
@@ -983,6 +1139,10 @@ void op_mul_mat(ggml_tensor *dst) {
         const ggml_tensor *s0[1] = {a};
         ggml_tensor *d[1] = {dst};
         mul_mat_q(1, s0, b, d);
+        return;
+    }
+    if (kt_of(a->type) >= 0) {
+        mul_mat_k(a, b, dst);
         return;
     }
     BK_ASSERT(b->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32);
@@ -1198,6 +1358,10 @@ void op_get_rows(ggml_tensor *dst) {
         const QWeight w = qweight_of(tab);
         hipLaunchKernelGGL(k_get_rows_q, dim3((unsigned)((w.nb + 255) / 256), (unsigned)N), dim3(256), 0, g.stream, w,
                            pid, pd, ne0);
+    } else if (kt_of(tab->type) >= 0) {
+        const KWeight w = kweight_of(tab);
+        hipLaunchKernelGGL(k_get_rows_k, dim3((unsigned)((w.nsb * 8 + 255) / 256), (unsigned)N), dim3(256), 0, g.stream, w, pid,
+                           pd, ne0);
     } else if (tab->type == GGML_TYPE_F16) {
         hipLaunchKernelGGL(k_get_rows<__half>, dim3((unsigned)((ne0 + 255) / 256), (unsigned)N), dim3(256), 0, g.stream,
                            (const char *)dev_ptr(tab), (int64_t)tab->nb[1], pid, pd, ne0);
@@ -1281,6 +1445,11 @@ void invalidate_qact_if_overwritten(const ggml_tensor *n) {
         const uintptr_t b0 = (uintptr_t)n->data, b1 = b0 + ggml_nbytes(n);
         if (b0 < c1 && c0 < b1) g_xi8.valid = false;
     }
+    if (g_xk.valid && n->data != nullptr) {
+        const uintptr_t c0 = (uintptr_t)g_xk.src_data, c1 = c0 + g_xk.src_bytes;
+        const uintptr_t b0 = (uintptr_t)n->data, b1 = b0 + ggml_nbytes(n);
+        if (b0 < c1 && c0 < b1) g_xk.valid = false;
+    }
     invalidate_xf16_if_overwritten_impl(n);
     if (!g_qact.valid || n->data == nullptr) return;
     const uintptr_t a0 = (uintptr_t)g_qact.src_data, a1 = a0 + g_qact.src_bytes;
@@ -1317,6 +1486,7 @@ void execute_graph(ggml_cgraph *gr) {
     g_xf16.valid = false;
     g_xq8.valid = false;
     g_xi8.valid = false;
+    g_xk.valid = false;
     if (try_decode_plan(gr)) return;  // single-token LLaMA decode: fused launches + hipGraph replay
     g.stat_generic_graphs++;
     upload_inputs(gr);
@@ -1514,6 +1684,7 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     g_xf16.valid = false;
     g_xq8.valid = false;
     g_xi8.valid = false;
+    g_xk.valid = false;
     int async = 0;
     if (try_decode_plan(cgraph, true)) {
         async = 1;
@@ -1618,7 +1789,7 @@ void ggml_hip_assign_buffers_no_scratch(struct ggml_tensor *tensor) {
     tensor->extra = upload_tensor(tensor->data, tensor, true);
 }
 bool ggml_hip_can_mul_mat(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
-    const bool q = qt_of(src0->type) >= 0 || src0->type == GGML_TYPE_F16 || src0->type == GGML_TYPE_F32;
+    const bool q = qt_of(src0->type) >= 0 || kt_of(src0->type) >= 0 || src0->type == GGML_TYPE_F16 || src0->type == GGML_TYPE_F32;
     return q && src1->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32;
 }
 size_t ggml_hip_mul_mat_get_wsize(const struct ggml_tensor *, const struct ggml_tensor *, struct ggml_tensor *) {

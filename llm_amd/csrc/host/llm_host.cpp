@@ -951,6 +951,17 @@ void llm_synth_blocks(int type, void *dst, int64_t nblocks, uint64_t seed, float
             const float u = (float)(next() >> 40) * (1.0f / 16777216.0f);
             const float d = d_scale * (0.5f + u);
             const ggml_fp16_t dh = ggml_fp32_to_fp16(d);
+            if (type == GGML_TYPE_Q6_K) {  // block_q6_K: ql[128] qh[64] scales[16] d — int8 scales x 6-bit quants, |sc*q| ~ 1e3
+                const ggml_fp16_t d6 = ggml_fp32_to_fp16(d * (1.0f / 1024.0f));
+                memcpy(p + 208, &d6, 2);
+                continue;
+            }
+            if (type == GGML_TYPE_Q4_K) {  // block_q4_K: d dmin scales[12] qs[128] — x = d*sc*q - dmin*m, sc, m six-bit
+                const ggml_fp16_t d4 = ggml_fp32_to_fp16(d * (1.0f / 32.0f)), m4 = ggml_fp32_to_fp16(d * (7.5f / 32.0f));
+                memcpy(p, &d4, 2);
+                memcpy(p + 2, &m4, 2);
+                continue;
+            }
             memcpy(p, &dh, 2);
             if (has_m) {
                 const ggml_fp16_t mh = ggml_fp32_to_fp16(-lv * ggml_fp16_to_fp32(dh));
