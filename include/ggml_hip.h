@@ -524,6 +524,27 @@ GGML_API void ggml_hip_graph_compute_end(void);
  * memory advances by n positions; the caller adds n to its n_past.  Returns 0, or -1 if the precondition does not
  * hold (nothing was executed: decode token by token instead). */
 GGML_API int ggml_hip_decode_greedy_chain(struct ggml_cgraph *last, int n, int32_t *out_tokens, float *last_logits);
+/* Top-k prefilter of a logits row on the device: the k (<= 1024, <= ne0) largest entries of row `row` of
+ * the f32 tensor `t` — a node of the caller's most recent ggml_graph_compute, normally the logits — as (value, id) pairs,
+ * value descending, lower id first among equal values, followed by the entries of `extra_ids` (n_extra ids, e.g. the
+ * tokens a repetition penalty or a bias list touches) in the order given.  out_vals / out_ids hold k + n_extra entries.
+ * For the reference's sampler chain (crates/llm-base/src/samplers.rs:289-306 sample_token; top-k after flat bias and
+ * repetition penalty): the tokens that can be among the k best after the host has changed the n_extra listed logits
+ * are all in {raw top-(k + n_extra)} U extra_ids, so a caller asks for k + n_extra and sorts at most k + 2 n_extra
+ * pairs instead of n_vocab logits; only those pairs cross PCIe.  Returns 0, -1 on bad arguments. */
+GGML_API int ggml_hip_topk(const struct ggml_tensor *t, int64_t row, int k, const int32_t *extra_ids, int n_extra,
+                           float *out_vals, int32_t *out_ids);
+/* ggml_quantize_q4_0 / q4_1 / q5_0 / q5_1 / q8_0 (crates/ggml/src/lib.rs:419-483, called by
+ * crates/llm-base/src/quantize.rs:363-379) computed on the device: n f32 values at `src` (host memory, rows
+ * of k, k % 32 == 0) -> raw GGML blocks at `dst` (host memory), byte-identical to the host functions; the 16-bin
+ * histogram is ADDED to hist (may be NULL).  Returns the bytes written.  PCIe-bound: ~1.2 bytes moved per weight. */
+GGML_API size_t ggml_hip_quantize(enum ggml_type type, const float *src, void *dst, int64_t n, int64_t k, int64_t *hist);
+/* The same for a matrix that already lives in HBM: `src` is a contiguous 2-D f32 or f16 tensor previously handed to
+ * ggml_hip_transform_tensor; `dst` is a tensor of a 32-wide block type with the same shape whose data pointer names the
+ * result (its host bytes are neither read nor written).  After the call dst is a device-resident quantized weight
+ * (GGML_BACKEND_GPU, extra set) exactly as if the host-quantized blocks had been uploaded: mul_mat / get_rows accept
+ * it; nothing crosses PCIe.  Returns 0, -1 if the precondition does not hold. */
+GGML_API int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor *dst, int64_t *hist);
 /* In-kernel timeline of the decode mat-vec launches (ggml_hip_set_option("timeline", 1), eager or graph mode):
  * records of 8 x int64 {entry, loads issued, x staged, barrier passed, first weights landed, exit (100 MHz
  * wall clock ticks), steps of wave 0, workgroup id}; 4 (or "timeline" = n) sampled workgroups per launch, launch order.

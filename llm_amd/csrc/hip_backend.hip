@@ -35,6 +35,8 @@
 #include "kernels/mmq_dma.h"
 #include "kernels/mmq_i8.h"
 #include "kernels/kquant.h"
+#include "kernels/quantize.h"
+#include "kernels/topk.h"
 #include "kernels/gemm_f16.h"
 #include "kernels/ops.h"
 #include "kernels/decode.h"
@@ -1767,6 +1769,121 @@ void ggml_hip_transform_tensor(void *data, struct ggml_tensor *tensor) {
     tensor->backend = GGML_BACKEND_GPU;
     tensor->extra = upload_tensor(data, tensor, false);
 }
+
+// ---- device quantizer (kernels/quantize.h) ----
+static bool quantizable(int type) {
+    return type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q8_0;
+}
+static void launch_quantize_blocks(const void *src_dev, bool f16_src, int type, int64_t nblocks, uint8_t *out_dev,
+                                   unsigned long long *hist_dev) {
+    Timed tm(GGML_HIP_KCLASS_OTHER, (double)nblocks * (f16_src ? 64 : 128) + (double)nblocks * ggml_type_size((ggml_type)type));
+    if (f16_src)
+        hipLaunchKernelGGL(k_quantize_blocks<true>, grid1(nblocks), dim3(256), 0, g.stream, src_dev, type, nblocks, out_dev, hist_dev);
+    else
+        hipLaunchKernelGGL(k_quantize_blocks<false>, grid1(nblocks), dim3(256), 0, g.stream, src_dev, type, nblocks, out_dev, hist_dev);
+    HIP_CHECK(hipGetLastError());
+}
+size_t ggml_hip_quantize(enum ggml_type type, const float *src, void *dst, int64_t n, int64_t k, int64_t *hist) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    if (!quantizable(type)) die("ggml_hip_quantize: %s has no device encoder", ggml_type_name(type));
+    if (k % 32 != 0 || n % k != 0) die("ggml_hip_quantize: n = %lld must be rows of k = %lld, k %% 32 == 0", (long long)n, (long long)k);
+    const size_t bs = ggml_type_size(type);
+    const int64_t nblocks = n / 32;
+    const int64_t piece = (int64_t)1 << 23;  // blocks per pass: 1 GiB of f32 in, <= 272 MiB out
+    char *din = nullptr, *dout = nullptr;
+    unsigned long long *dh = nullptr;
+    const int64_t cap = std::min(nblocks, piece);
+    HIP_CHECK(hipMalloc((void **)&din, (size_t)cap * 128));
+    HIP_CHECK(hipMalloc((void **)&dout, (size_t)cap * bs));
+    HIP_CHECK(hipMalloc((void **)&dh, 128));
+    HIP_CHECK(hipMemsetAsync(dh, 0, 128, g.stream));
+    for (int64_t b0 = 0; b0 < nblocks; b0 += piece) {
+        const int64_t nb = std::min(piece, nblocks - b0);
+        h2d_bulk(din, src + b0 * 32, (size_t)nb * 128);
+        launch_quantize_blocks(din, false, (int)type, nb, (uint8_t *)dout, dh);
+        HIP_CHECK(hipMemcpyAsync((char *)dst + (size_t)b0 * bs, dout, (size_t)nb * bs, hipMemcpyDeviceToHost, g.stream));
+        HIP_CHECK(hipStreamSynchronize(g.stream));
+    }
+    unsigned long long hh[16];
+    HIP_CHECK(hipMemcpy(hh, dh, 128, hipMemcpyDeviceToHost));
+    if (hist)
+        for (int i = 0; i < 16; i++) hist[i] += (int64_t)hh[i];
+    HIP_CHECK(hipFree(din));
+    HIP_CHECK(hipFree(dout));
+    HIP_CHECK(hipFree(dh));
+    return (size_t)nblocks * bs;
+}
+int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor *dst, int64_t *hist) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    if (!quantizable(dst->type) || (src->type != GGML_TYPE_F32 && src->type != GGML_TYPE_F16)) return -1;
+    if (!ggml_is_contiguous(src) || src->ne[2] != 1 || src->ne[3] != 1 || src->ne[0] % 32 != 0 || src->ne[0] != dst->ne[0] ||
+        src->ne[1] != dst->ne[1] || dst->ne[2] != 1 || dst->ne[3] != 1 || extra_of(dst) || dst->data == nullptr)
+        return -1;
+    if (!extra_of(src) && !find_tensor((uintptr_t)src->data)) return -1;  // the source must already be on the device
+    finish_pending();
+    const int64_t M = src->ne[1], nb = src->ne[0] / 32, nblocks = M * nb;
+    const size_t bs = ggml_type_size(dst->type);
+    char *raw = nullptr;
+    unsigned long long *dh = nullptr;
+    HIP_CHECK(hipMalloc((void **)&raw, (size_t)nblocks * bs));
+    HIP_CHECK(hipMalloc((void **)&dh, 128));
+    HIP_CHECK(hipMemsetAsync(dh, 0, 128, g.stream));
+    launch_quantize_blocks(dev_ptr(src), src->type == GGML_TYPE_F16, (int)dst->type, nblocks, (uint8_t *)raw, dh);
+    DevTensor *e = new DevTensor();
+    e->host = (uintptr_t)dst->data;
+    e->nbytes = ggml_nbytes(dst);
+    e->type = dst->type;
+    for (int i = 0; i < 4; i++) e->ne[i] = dst->ne[i];
+    const int qt = qt_of(dst->type);
+    size_t off[5];
+    const size_t total = qw_layout(qt, nblocks, off);
+    HIP_CHECK(hipMalloc((void **)&e->dev, total));
+    e->dev_bytes = total;
+    relayout_launch(raw, qt, M, nb, e->dev);
+    unsigned long long hh[16];
+    HIP_CHECK(hipMemcpyAsync(hh, dh, 128, hipMemcpyDeviceToHost, g.stream));
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    if (hist)
+        for (int i = 0; i < 16; i++) hist[i] += (int64_t)hh[i];
+    HIP_CHECK(hipFree(raw));
+    HIP_CHECK(hipFree(dh));
+    e->soa = true;
+    e->qw = qw_at(e->dev, qt, M, nb);
+    evict_overlapping(g.auto_tensors, e->host, std::max<size_t>(e->nbytes, 1));
+    evict_overlapping(g.tensors, e->host, std::max<size_t>(e->nbytes, 1));
+    g.tensors[e->host] = e;
+    dst->backend = GGML_BACKEND_GPU;
+    dst->extra = e;
+    return 0;
+}
+
+// ---- device top-k prefilter (kernels/topk.h) ----
+int ggml_hip_topk(const struct ggml_tensor *t, int64_t row, int k, const int32_t *extra_ids, int n_extra, float *out_vals,
+                  int32_t *out_ids) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    if (!t || t->type != GGML_TYPE_F32 || t->nb[0] != 4 || row < 0 || row >= t->ne[1] * t->ne[2] * t->ne[3] || t->ne[2] != 1 ||
+        t->ne[3] != 1 || k < 1 || k > TOPK_MAX || k > t->ne[0] || n_extra < 0 || t->ne[0] > 0x7FFFFFFF)
+        return -1;
+    const float *x = (const float *)(dev_ptr(t) + row * (int64_t)t->nb[1]);
+    char *buf = ws_alloc((size_t)(k + n_extra) * 8 + (size_t)n_extra * 4 + 64);
+    float *dv = (float *)buf;
+    int *di = (int *)(buf + (size_t)(k + n_extra) * 4);
+    int *de = di + (k + n_extra);
+    if (n_extra) HIP_CHECK(hipMemcpyAsync(de, extra_ids, (size_t)n_extra * 4, hipMemcpyHostToDevice, g.stream));
+    {
+        Timed tm(GGML_HIP_KCLASS_OTHER, (double)t->ne[0] * 4 * 9);
+        hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, g.stream, x, (int)t->ne[0], k, (const int *)de, n_extra, dv, di);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipMemcpyAsync(out_vals, dv, (size_t)(k + n_extra) * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_CHECK(hipMemcpyAsync(out_ids, di, (size_t)(k + n_extra) * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
 void ggml_hip_free_data(struct ggml_tensor *tensor) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     if (!tensor || !tensor->extra) return;

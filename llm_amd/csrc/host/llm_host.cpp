@@ -924,6 +924,17 @@ size_t llm_session_read_node(const llm_session *s, int index, const char *name, 
     return n;
 }
 
+// The k best logits of the last evaluated token without reading n_vocab floats back (ggml_hip_topk on the logits node of
+// the last graph = its last node, last row): what the sampler chain's top-k stage needs (samplers.rs:289-306).
+// `extra_ids`: tokens whose raw logits the caller wants too (repetition-penalty window, bias list).  0 on success.
+int llm_session_topk(const llm_session *s, int k, const int32_t *extra_ids, int n_extra, float *out_vals, int32_t *out_ids) {
+    ggml_cgraph *g = s->s->last_graph;
+    if (!g || g->n_nodes < 1) return -1;
+    const ggml_tensor *t = g->nodes[g->n_nodes - 1];
+    if (t->type != GGML_TYPE_F32 || (size_t)t->ne[0] != s->s->last_logits.size()) return -1;
+    return ggml_hip_topk(t, t->ne[1] - 1, k, extra_ids, n_extra, out_vals, out_ids);
+}
+
 // Synthetic GGML blocks for full-size benchmarks (no checkpoints are obtainable offline): uniform random
 // quants, f16 scale d = d_scale*(0.5+u), and for the *_1 types a min that centres the block.  Fills
 // `nblocks` blocks of `type` at dst; deterministic in (seed, block index); multi-threaded.

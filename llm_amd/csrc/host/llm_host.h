@@ -111,6 +111,10 @@ GGML_API size_t llm_session_kv(llm_session *s, int which, int set, void *buf, si
 GGML_API size_t llm_session_snapshot(llm_session *s, void *buf, size_t cap);
 GGML_API llm_session *llm_session_from_snapshot(llm_model *m, const void *buf, size_t n);
 /* test hook: reads the device contents of a node of the last evaluated graph (by index, or k-th node named `name`) */
+/* top-k prefilter of the last token's logits on the device (ggml_hip_topk): k (value, id) pairs, best first, then the
+ * raw logits of extra_ids; 0 on success, -1 if there is no evaluated graph or the arguments are out of range */
+GGML_API int llm_session_topk(const llm_session *s, int k, const int32_t *extra_ids, int n_extra, float *out_vals,
+                              int32_t *out_ids);
 GGML_API size_t llm_session_read_node(const llm_session *s, int index, const char *name, int occurrence, void *dst,
                                       size_t max_bytes);
 /* synthetic GGML blocks for full-size benchmarks (deterministic in seed and block index) */

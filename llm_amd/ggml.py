@@ -220,6 +220,9 @@ PROTOTYPES.update({
     "ggml_hip_get_stat": (C.c_int64, [C.c_char_p]),
     "ggml_hip_read_timeline": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ggml_hip_decode_greedy_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ggml_hip_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ggml_hip_quantize": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "ggml_hip_quantize_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ggml_hip_graph_compute_begin": (C.c_int, [C.c_void_p]),
     "ggml_hip_graph_compute_end": (None, []),
     "ggml_hip_bench_plan_class": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -282,6 +285,29 @@ def quantize(t, x):
     got = fn(x.ctypes.data, out.ctypes.data, x.size, k, hist.ctypes.data)
     assert got == out.size, (got, out.size)
     return out
+
+
+def quantize_on_device(t, x):
+    """ggml_hip_quantize: the same bytes as quantize(), computed on the GPU.  Returns (raw bytes, 16-bin histogram)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(row_bytes(t, x.size), dtype=np.uint8)
+    hist = np.zeros(16, dtype=np.int64)
+    got = lib().ggml_hip_quantize(t, x.ctypes.data, out.ctypes.data, x.size, x.shape[-1], hist.ctypes.data)
+    assert got == out.size, (got, out.size)
+    return out, hist
+
+
+def topk(tensor, row, k, extra_ids=()):
+    """ggml_hip_topk on a node of the last computed graph: (values, ids) of the k largest entries of `row` (descending,
+    lower id first on ties) followed by the entries of extra_ids."""
+    extra = np.ascontiguousarray(extra_ids, dtype=np.int32)
+    vals = np.zeros(k + extra.size, dtype=np.float32)
+    ids = np.zeros(k + extra.size, dtype=np.int32)
+    ptr = tensor.ptr if isinstance(tensor, Tensor) else tensor
+    rc = lib().ggml_hip_topk(ptr, row, k, extra.ctypes.data if extra.size else None, extra.size, vals.ctypes.data, ids.ctypes.data)
+    if rc != 0:
+        raise ValueError("ggml_hip_topk: bad arguments")
+    return vals, ids
 
 
 class Tensor:

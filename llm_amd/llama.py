@@ -76,6 +76,8 @@ def _lib():
                                                 C.POINTER(C.c_size_t)]
         L.llm_session_kv.restype = C.c_size_t
         L.llm_session_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.llm_session_topk.restype = C.c_int
+        L.llm_session_topk.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.llm_session_read_node.restype = C.c_size_t
         L.llm_session_read_node.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
         _bound = True
@@ -269,6 +271,19 @@ class Session:
         for which, a in ((0, k), (1, v)):
             a = np.ascontiguousarray(a)
             _lib().llm_session_kv(self.ptr, which, 1, a.ctypes.data, a.nbytes)
+
+    def top_k(self, k, extra_ids=()):
+        """(values, ids) of the k largest logits of the last evaluated token, best first (lower id first on ties), then
+        the raw logits of extra_ids — computed on the device (llm_session_topk); only k + len(extra_ids) pairs are
+        read back."""
+        extra = np.ascontiguousarray(extra_ids, dtype=np.int32)
+        vals = np.zeros(k + extra.size, dtype=np.float32)
+        ids = np.zeros(k + extra.size, dtype=np.int32)
+        rc = _lib().llm_session_topk(self.ptr, k, extra.ctypes.data if extra.size else None, extra.size, vals.ctypes.data,
+                                     ids.ctypes.data)
+        if rc != 0:
+            raise ValueError("llm_session_topk: no evaluated graph or bad arguments")
+        return vals, ids
 
     def read_node(self, index=-1, name=None, occurrence=0, dtype=np.float32):
         """Test hook: device contents of a node of the last evaluated graph."""

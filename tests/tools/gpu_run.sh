@@ -2,5 +2,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 300 python tests/tools/decode_repro.py 7b q4_k 2>&1 | tail -12
-timeout 300 python tests/tools/decode_repro.py 7b q6_k 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_device_tools_gpu.py -q -x 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl" | tail -25
