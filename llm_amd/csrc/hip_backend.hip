@@ -43,6 +43,7 @@
 #include "kernels/decode_big.h"
 #include "kernels/decode_big8.h"
 #include "kernels/decode_attn_split.h"
+#include "kernels/prompt.h"
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -119,7 +120,10 @@ struct Backend {
     hipStream_t stream = nullptr;
     int opt_attn_split = 1;  // long contexts: attention split over positions too (kernels/decode_attn_split.h)
     int opt_prefetch = 0;  // MB of w1|w3 (plus all of wo) that the idle CUs of the decode attention launch pull into the
-                           // Infinity Cache (llama_plan.inc); 0 = off
+                           // L2 of the XCD that will read them (llama_plan.inc, kernels/decode.h prefetch_slice); 0 = off
+    int opt_prefetch_wo = 1;     // 0: leave wo out of the warm-up
+    int opt_prefetch_delay = 0;  // ~0.2 us units before the warm-up's first request
+    int opt_prefetch_wgs = 0;    // spare workgroups that take part (multiple of 8; 0 = all idle CUs): the warm-up's request rate
     std::map<uintptr_t, Arena> arenas;          // by base
     std::map<uintptr_t, DevTensor *> tensors;   // explicit records (transform_tensor / assign_buffers_no_scratch)
     std::map<uintptr_t, DevTensor *> auto_tensors;  // persistent leaves uploaded on first use (never offloaded by
@@ -137,6 +141,7 @@ struct Backend {
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
+    int opt_plan_prompt = 1; // fused plan for prompt batches of >= mmq_min tokens (kernels/prompt.h)
     int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
     int opt_probe = 0;      // measurement only: k_mmvq_big returns early (BigArgs::probe), tests/tools/launch_probe.py
     int num_cus = 256;
@@ -154,7 +159,7 @@ struct Backend {
     int opt_plan = 1;       // recognise the LLaMA decode graph and run the fused plan
     int opt_graph = 1;      // replay the plan from a captured hipGraph
     int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
-    uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0, stat_split_tokens = 0;
+    uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0, stat_split_tokens = 0, stat_prompt_plan_tokens = 0;
     void *chain_plan = nullptr;            // the plan a greedy chain may continue (set by its last single-token run)
     ggml_cgraph *chain_graph = nullptr;    // ... and the cgraph that run executed
     bool pending_wait = false;  // a decode plan was launched by graph_compute_begin and not yet waited for
@@ -186,6 +191,9 @@ void ensure_init() {
     HIP_CHECK(hipSetDevice(g.device));
     HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (const char *v = getenv("GGML_HIP_PREFETCH")) g.opt_prefetch = atoi(v);
+    if (const char *v = getenv("GGML_HIP_PREFETCH_WO")) g.opt_prefetch_wo = atoi(v);
+    if (const char *v = getenv("GGML_HIP_PREFETCH_DELAY")) g.opt_prefetch_delay = atoi(v);
+    if (const char *v = getenv("GGML_HIP_PREFETCH_WGS")) g.opt_prefetch_wgs = atoi(v);
     if (const char *v = getenv("GGML_HIP_ATTN_SPLIT")) g.opt_attn_split = atoi(v);
     if (const char *v = getenv("GGML_HIP_FUSE")) g.opt_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN")) g.opt_plan = atoi(v);
@@ -195,6 +203,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_MMQ_MIN")) g.opt_mmq_min = atoi(v);
     if (const char *v = getenv("GGML_HIP_BIG")) g.opt_big = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN_MULTI")) g.opt_plan_multi = atoi(v);
+    if (const char *v = getenv("GGML_HIP_PLAN_PROMPT")) g.opt_plan_prompt = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_I8")) g.opt_mmq_i8 = atoi(v);
@@ -967,52 +976,18 @@ void mul_mat_k(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *ds
     }
 }
 
-// Quantized GEMM on the f16 matrix cores (kernels/mmq.h); the `algo_bytes` slot of the MMQ_MFMA timing class
-// carries FLOPs (2*M*N*K), the unit that class is bounded by.
-void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
-    const int qt = qt_of(src0->type);
-    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
-    const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
-    if (g.opt_mmq_i8 && nb % 2 == 0) {  // integer matrix cores: ggml's exact block dots (kernels/mmq_i8.h)
-        MmqI8Args ia;
-        ia.w = qweight_of(src0);
-        quantize_activation_i8(src1, qt, &ia.x8, &ia.dx, &ia.xs);
-        ia.dst = (float *)dev_ptr(dst);
-        ia.ldd = (int64_t)dst->nb[1] / 4;
-        ia.M = ia.w.M;
-        ia.N = N;
-        ia.nb = nb;
-        const int tiles_m = (int)((ia.M + MMQ_TM - 1) / MMQ_TM);
-        ia.tiles_n = (int)((N + MMQ_TN - 1) / MMQ_TN);
-        const int nstage = (int)(nb / 2);
-        const int splits = (g.opt_mmq_splitk && tiles_m * ia.tiles_n * 2 <= g.num_cus * 3 && nstage >= 16 && dst->nb[0] == 4 &&
-                            ggml_is_contiguous(dst)) ? 2 : 1;  // two workgroups per CU: fewer than 1.5 tiles per slot -> split K
-        if (splits > 1) HIP_CHECK(hipMemsetAsync(ia.dst, 0, (size_t)ia.M * N * 4, g.stream));
-        const dim3 grid((unsigned)(tiles_m * ia.tiles_n), (unsigned)splits);
-        Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)ia.M * (double)N * (double)K);
-        switch (qt) {
-            case QT_Q4_0: launch_mmq_i8<QT_Q4_0>(ia, grid); break;
-            case QT_Q4_1: launch_mmq_i8<QT_Q4_1>(ia, grid); break;
-            case QT_Q5_0: launch_mmq_i8<QT_Q5_0>(ia, grid); break;
-            case QT_Q5_1: launch_mmq_i8<QT_Q5_1>(ia, grid); break;
-            case QT_Q8_0: launch_mmq_i8<QT_Q8_0>(ia, grid); break;
-            default: die("mmq: bad weight type");
-        }
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
+// The default prompt GEMM launch (f16 matrix cores, k_mmq_dma / k_mmq): x16 (or x8 + dx for option mmq_dma = 2) are the
+// activations after the Q8 pre-pass; dst[n * ldd + m].  Shared by the generic executor and the fused prompt plan.
+void mmq_f16_launch(int qt, const QWeight &w, const _Float16 *x16, const int8_t *x8, const _Float16 *dx, float *dst,
+                    int64_t ldd, int64_t N, int64_t nb, bool dst_contig) {
     MmqArgs a;
-    a.w = qweight_of(src0);
+    a.w = w;
     const bool use_dma = g.opt_mmq_dma && nb % 2 == 0, use_x8 = use_dma && g.opt_mmq_dma >= 2;
-    a.x = nullptr;
-    a.x8 = nullptr;
-    a.dx = nullptr;
-    if (use_x8)
-        quantize_activation_q8p(src1, f16_d, &a.x8, &a.dx);
-    else
-        a.x = quantize_activation_f16(src1, f16_d);
-    a.dst = (float *)dev_ptr(dst);
-    a.ldd = (int64_t)dst->nb[1] / 4;
+    a.x = x16;
+    a.x8 = x8;
+    a.dx = dx;
+    a.dst = dst;
+    a.ldd = ldd;
     a.M = a.w.M;
     a.N = N;
     a.nb = nb;
@@ -1021,8 +996,7 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
     // too few tiles to fill the chip (E x E at 512 tokens: 128 tiles for 256 CUs): split K in two, combined with
     // commutative (2-addend) f32 atomic adds into a zeroed dst
     const int nstage = (int)((nb + 1) / 2);
-    const int splits = (g.opt_mmq_splitk && tiles_m * a.tiles_n * 4 <= g.num_cus * 3 && nstage >= 16 &&
-                        dst->nb[0] == 4 && ggml_is_contiguous(dst)) ? 2 : 1;
+    const int splits = (g.opt_mmq_splitk && tiles_m * a.tiles_n * 4 <= g.num_cus * 3 && nstage >= 16 && dst_contig) ? 2 : 1;
     if (splits > 1) HIP_CHECK(hipMemsetAsync(a.dst, 0, (size_t)a.M * N * 4, g.stream));
     a.xcd_by_n = g.opt_mmq_xcdn == 2 ? 1 : g.opt_mmq_xcdn && (a.tiles_n == 1 || a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && tiles_m % (8 / a.tiles_n) == 0;
     const dim3 grid((unsigned)(tiles_m * a.tiles_n), (unsigned)splits);
@@ -1035,7 +1009,7 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
         lds_attr_set = true;
     }
-    Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)a.M * (double)N * (double)K);
+    Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)a.M * (double)N * (double)(nb * 32));
     if (use_dma) {
         static bool dma_attr_set = false;
         if (!dma_attr_set) {
@@ -1077,6 +1051,51 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
         default: die("mmq: bad weight type");
     }
     HIP_CHECK(hipGetLastError());
+}
+
+// Quantized GEMM on the f16 matrix cores (kernels/mmq.h); the `algo_bytes` slot of the MMQ_MFMA timing class
+// carries FLOPs (2*M*N*K), the unit that class is bounded by.
+void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
+    const int qt = qt_of(src0->type);
+    const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
+    const bool f16_d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
+    if (g.opt_mmq_i8 && nb % 2 == 0) {  // integer matrix cores: ggml's exact block dots (kernels/mmq_i8.h)
+        MmqI8Args ia;
+        ia.w = qweight_of(src0);
+        quantize_activation_i8(src1, qt, &ia.x8, &ia.dx, &ia.xs);
+        ia.dst = (float *)dev_ptr(dst);
+        ia.ldd = (int64_t)dst->nb[1] / 4;
+        ia.M = ia.w.M;
+        ia.N = N;
+        ia.nb = nb;
+        const int tiles_m = (int)((ia.M + MMQ_TM - 1) / MMQ_TM);
+        ia.tiles_n = (int)((N + MMQ_TN - 1) / MMQ_TN);
+        const int nstage = (int)(nb / 2);
+        const int splits = (g.opt_mmq_splitk && tiles_m * ia.tiles_n * 2 <= g.num_cus * 3 && nstage >= 16 && dst->nb[0] == 4 &&
+                            ggml_is_contiguous(dst)) ? 2 : 1;  // two workgroups per CU: fewer than 1.5 tiles per slot -> split K
+        if (splits > 1) HIP_CHECK(hipMemsetAsync(ia.dst, 0, (size_t)ia.M * N * 4, g.stream));
+        const dim3 grid((unsigned)(tiles_m * ia.tiles_n), (unsigned)splits);
+        Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)ia.M * (double)N * (double)K);
+        switch (qt) {
+            case QT_Q4_0: launch_mmq_i8<QT_Q4_0>(ia, grid); break;
+            case QT_Q4_1: launch_mmq_i8<QT_Q4_1>(ia, grid); break;
+            case QT_Q5_0: launch_mmq_i8<QT_Q5_0>(ia, grid); break;
+            case QT_Q5_1: launch_mmq_i8<QT_Q5_1>(ia, grid); break;
+            case QT_Q8_0: launch_mmq_i8<QT_Q8_0>(ia, grid); break;
+            default: die("mmq: bad weight type");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    const bool use_dma = g.opt_mmq_dma && nb % 2 == 0, use_x8 = use_dma && g.opt_mmq_dma >= 2;
+    const _Float16 *x16 = nullptr, *dx = nullptr;
+    const int8_t *x8 = nullptr;
+    if (use_x8)
+        quantize_activation_q8p(src1, f16_d, &x8, &dx);
+    else
+        x16 = quantize_activation_f16(src1, f16_d);
+    mmq_f16_launch(qt, qweight_of(src0), x16, x8, dx, (float *)dev_ptr(dst), (int64_t)dst->nb[1] / 4, N, nb,
+                   dst->nb[0] == 4 && ggml_is_contiguous(dst));
 }
 
 int pick_rows(int64_t M) {
@@ -2083,6 +2102,22 @@ void ggml_hip_set_option(const char *key, int value) {
         if (g.opt_prefetch != value) drop_all_plans();
         g.opt_prefetch = value;
     }
+    else if (k == "prefetch_wo") {
+        if (g.opt_prefetch_wo != value) drop_all_plans();
+        g.opt_prefetch_wo = value;
+    }
+    else if (k == "prefetch_wgs") {
+        if (g.opt_prefetch_wgs != value) drop_all_plans();
+        g.opt_prefetch_wgs = value;
+    }
+    else if (k == "prefetch_delay") {
+        if (g.opt_prefetch_delay != value) drop_all_plans();
+        g.opt_prefetch_delay = value;
+    }
+    else if (k == "plan_prompt") {
+        if (g.opt_plan_prompt != value) drop_all_plans();
+        g.opt_plan_prompt = value;
+    }
     else if (k == "plan_multi") {
         if (g.opt_plan_multi != value) drop_all_plans();
         g.opt_plan_multi = value;
@@ -2380,6 +2415,7 @@ int64_t ggml_hip_get_stat(const char *key) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     const std::string k(key);
     if (k == "attn_split_tokens") return (int64_t)g.stat_split_tokens;  // tokens whose attention ran split over positions
+    if (k == "prompt_plan_tokens") return (int64_t)g.stat_prompt_plan_tokens;  // tokens executed by the fused prompt plan
     if (k == "plan_tokens") return (int64_t)g.stat_plan_tokens;       // tokens executed by the fused decode plan
     if (k == "graph_replays") {
         int64_t n = 0;

@@ -1,0 +1,113 @@
+"""The fused prompt plan (llama_plan.inc plan_launch_prompt, kernels/prompt.h): a prompt batch of >= 32 tokens
+(crates/llm-base/src/inference_session.rs:315-316 feeds n_batch tokens per Model::evaluate; graph of
+crates/models/llama/src/lib.rs:166-362) as 13 launches per layer instead of 24.
+
+The plan performs the node-by-node executor's floating-point operations in the same order on the same values (same GEMM
+kernels and split-K choice, same rms_norm / RoPE / softmax / SiLU / re-quantization arithmetic), so the comparison is
+BIT-EXACT: logits of every token, the final-norm embedding, and the K/V cache — for all five block formats, grouped-query
+attention, ragged batch sizes, and batches that start at n_past > 0.  Parity of the generic executor with the oracle
+is established in test_llama_gpu.py; one case here checks the plan against the oracle directly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GQA = dict(n_vocab=256, n_embd=128, n_head=4, n_head_kv=2, n_layer=2, n_rot=32, n_ff=352, n_mult=32)
+WIDE = dict(n_vocab=320, n_embd=256, n_head=4, n_head_kv=4, n_layer=3, n_rot=64, n_ff=512, n_mult=32)  # K/32 even everywhere: DMA GEMM
+
+
+def _stat(G, key):
+    return int(G.lib().ggml_hip_get_stat(key.encode()))
+
+
+def _run(G, model, chunks, plan, want_emb=False):
+    G.set_option("plan_prompt", plan)
+    sess = model.start_session(n_batch=512)
+    outs = []
+    for c in chunks:
+        p0, g0 = _stat(G, "prompt_plan_tokens"), _stat(G, "generic_graphs")
+        r = sess.evaluate(c, want_embeddings=want_emb)
+        dp, dg = _stat(G, "prompt_plan_tokens") - p0, _stat(G, "generic_graphs") - g0
+        if len(c) >= 32:
+            assert (dp, dg) == ((len(c), 0) if plan else (0, 1)), (len(c), plan, dp, dg)
+        outs.append(r)
+    k, v = sess.get_kv()
+    sess.free()
+    G.set_option("plan_prompt", 1)
+    return outs, k, v
+
+
+@pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
+@pytest.mark.parametrize("cfg", ["tiny", "gqa", "wide"])
+def test_prompt_plan_is_bit_identical_to_the_node_by_node_executor(G, wtype, cfg):
+    from llm_amd import llama, synth
+    hp0 = {"tiny": synth.TINY, "gqa": GQA, "wide": WIDE}[cfg]
+    hp, w = synth.make_llama(hp0, wtype, seed=5)
+    model = llama.Llama(hp, w, context_size=512)
+    toks = np.random.default_rng([wtype, len(cfg)]).integers(0, hp["n_vocab"], 400).astype(np.int32)
+    # N = 64 at n_past 0; 33 (ragged, one partial tile); 3 (multi-token plan in between); 130 (two token tiles, n_past 100);
+    # 128 at n_past 230
+    chunks = [toks[0:64], toks[64:97], toks[97:100], toks[100:230], toks[230:358]]
+    a, ka, va = _run(G, model, chunks, 1, want_emb=True)
+    b, kb, vb = _run(G, model, chunks, 0, want_emb=True)
+    for i, ((la, ea), (lb, eb)) in enumerate(zip(a, b)):
+        assert la.shape == (len(chunks[i]), hp["n_vocab"])
+        assert np.array_equal(la, lb), (cfg, wtype, i, float(np.max(np.abs(la - lb))))
+        assert np.array_equal(ea, eb), (cfg, wtype, i)
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    model.free()
+
+
+def test_prompt_plan_matches_the_oracle(G, O):
+    """Direct check against the CPU oracle (mode 0 = ggml's exact integer block dots): the prompt GEMM rounds both
+    operands to f16, so the bound is the f16 GEMM's (test_llama_gpu.py: RMS 2e-2 of std(logits), EDGE on the maximum)."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(synth.TINY, 2, seed=1234)
+    model = llama.Llama(hp, w, context_size=128)
+    orc = O.Llama(hp, w, 128)
+    toks = np.random.default_rng(3).integers(0, hp["n_vocab"], 96).astype(np.int32)
+    sess = model.start_session(n_batch=64)
+    for c in (toks[:64], toks[64:96]):
+        p0 = _stat(G, "prompt_plan_tokens")
+        got = sess.evaluate(c)
+        assert _stat(G, "prompt_plan_tokens") - p0 == len(c)
+        ref = orc.evaluate(c, mode=0)
+        std = float(ref.std())
+        rms = float(np.sqrt(np.mean((got - ref) ** 2))) / std
+        assert rms <= 2e-2, rms
+        assert float(np.max(np.abs(got - ref))) / std <= 1e-1
+        k, v = sess.get_kv()
+        orc.memory_k[:] = k
+        orc.memory_v[:] = v
+    sess.free()
+    model.free()
+
+
+def test_prompt_plan_stage_of_a_layer_split(G):
+    """A first stage of a layer split (no final norm: the residual is handed on) and a later stage (residual received in
+    the hand-off buffer): with the plan and with the node-by-node executor the stages hand on the same residual, produce
+    the same logits and leave the same K/V."""
+    from llm_amd import synth
+    from llm_amd.pipeline import GpuStage
+    hp, w = synth.make_llama(synth.TINY, 2, seed=9)
+    toks = np.random.default_rng(1).integers(0, hp["n_vocab"], 48).astype(np.int32)
+
+    def run(plan):
+        G.set_option("plan_prompt", plan)
+        st0 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 0, 1)}, (0, 1), 64, n_batch=64)
+        st1 = GpuStage(hp, {k: v for k, v in w.items() if k in synth.stage_tensor_names(hp, 1, 2)}, (1, 2), 64, n_batch=64)
+        st0.new_sequence(0)
+        st1.new_sequence(0)
+        p0, g0 = _stat(G, "prompt_plan_tokens"), _stat(G, "generic_graphs")
+        res = st0.evaluate(0, toks, None)
+        st1.evaluate(0, toks, res)
+        dp, dg = _stat(G, "prompt_plan_tokens") - p0, _stat(G, "generic_graphs") - g0
+        assert (dp, dg) == ((2 * toks.size, 0) if plan else (0, 2)), (plan, dp, dg)
+        out = [res.copy(), st1.sessions[0].last_logits()] + st0.sessions[0].get_kv() + st1.sessions[0].get_kv()
+        st0.free()
+        st1.free()
+        G.set_option("plan_prompt", 1)
+        return out
+
+    for x, y in zip(run(1), run(0)):
+        assert np.array_equal(x, y)

@@ -2,17 +2,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-O=gpurun_out/r02_env_probe.txt
-: > $O
-run() { label="$1"; shift; env "$@" timeout 200 python tests/tools/env_probe.py "$label" 2>/dev/null | tail -1 >> $O; }
-run default A=1
-run HIP_FORCE_DEV_KERNARG=0 HIP_FORCE_DEV_KERNARG=0
-run HIP_FORCE_DEV_KERNARG=1 HIP_FORCE_DEV_KERNARG=1
-run GRAPH_PACKET_CAPTURE=0 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
-run GRAPH_PACKET_CAPTURE=1 DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
-run AMD_OPT_FLUSH=0 AMD_OPT_FLUSH=0
-run AMD_OPT_FLUSH=1 AMD_OPT_FLUSH=1
-run ROC_SYSTEM_SCOPE_SIGNAL=0 ROC_SYSTEM_SCOPE_SIGNAL=0
-run GPU_FLUSH_ON_EXECUTION=0 GPU_FLUSH_ON_EXECUTION=0
-run GGML_HIP_GRAPH=0 GGML_HIP_GRAPH=0
-cat $O
+for p in 1 0; do
+GGML_HIP_PLAN_PROMPT=$p timeout 300 python bench.py --mode prefill --weights blocks --no-cpu-baseline > gpurun_out/r02_prefill_plan$p.json 2> gpurun_out/r02_prefill_plan$p.err
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r02_prefill_plan$p.json").read().strip().splitlines()[-1])
+print("plan_prompt=$p", d["value"], d["unit"], d["ms_per_step"], "ms/step", json.dumps(d["roofline"].get("class_ms_per_step", d["config"].get("class_ms_per_step"))), d["roofline"]["frac"])
+PY
+done
