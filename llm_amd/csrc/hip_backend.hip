@@ -33,6 +33,7 @@
 #include "kernels/mmvq.h"
 #include "kernels/mmq.h"
 #include "kernels/mmq_dma.h"
+#include "kernels/mmq_dmap.h"
 #include "kernels/mmq_i8.h"
 #include "kernels/kquant.h"
 #include "kernels/quantize.h"
@@ -142,6 +143,8 @@ struct Backend {
     int opt_mmvq_rows = 0;  // 0 = auto
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
     int opt_plan_prompt = 1; // fused plan for prompt batches of >= mmq_min tokens (kernels/prompt.h)
+    int opt_mmq_persist = 1; // prompt GEMM as a persistent kernel (kernels/mmq_dmap.h)
+    int opt_mmq_fuse = 3;    // prompt plan: wq|wk|wv (bit 0) and w1|w3 (bit 1) as one GEMM launch each
     int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
     int opt_probe = 0;      // measurement only: k_mmvq_big returns early (BigArgs::probe), tests/tools/launch_probe.py
     int num_cus = 256;
@@ -204,6 +207,8 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_BIG")) g.opt_big = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN_MULTI")) g.opt_plan_multi = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN_PROMPT")) g.opt_plan_prompt = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_FUSE")) g.opt_mmq_fuse = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_PERSIST")) g.opt_mmq_persist = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_I8")) g.opt_mmq_i8 = atoi(v);
@@ -978,26 +983,47 @@ void mul_mat_k(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *ds
 
 // The default prompt GEMM launch (f16 matrix cores, k_mmq_dma / k_mmq): x16 (or x8 + dx for option mmq_dma = 2) are the
 // activations after the Q8 pre-pass; dst[n * ldd + m].  Shared by the generic executor and the fused prompt plan.
-void mmq_f16_launch(int qt, const QWeight &w, const _Float16 *x16, const int8_t *x8, const _Float16 *dx, float *dst,
-                    int64_t ldd, int64_t N, int64_t nb, bool dst_contig) {
+// nseg > 1: up to three matrices with the same K in one launch (MmqArgs: nseg); `splits` 0 = chosen here.
+struct MmqSegHost {
+    QWeight w;
+    float *dst;
+    int64_t ldd;
+};
+int mmq_auto_splits(int tiles, int64_t nb, bool dst_contig) {
+    // too few tiles to fill the chip (E x E at 512 tokens: 128 tiles for 256 CUs): split K in two, combined with
+    // commutative (2-addend) f32 atomic adds into a zeroed dst
+    const int nstage = (int)((nb + 1) / 2);
+    return (g.opt_mmq_splitk && tiles * 4 <= g.num_cus * 3 && nstage >= 16 && dst_contig) ? 2 : 1;
+}
+void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float16 *x16, const int8_t *x8, const _Float16 *dx,
+                          int64_t N, int64_t nb, bool dst_contig, int splits, bool zero_dst, int64_t split_stride = 0) {
     MmqArgs a;
-    a.w = w;
+    memset(&a, 0, sizeof(a));
+    a.w = segs[0].w;
     const bool use_dma = g.opt_mmq_dma && nb % 2 == 0, use_x8 = use_dma && g.opt_mmq_dma >= 2;
     a.x = x16;
     a.x8 = x8;
     a.dx = dx;
-    a.dst = dst;
-    a.ldd = ldd;
+    a.dst = segs[0].dst;
+    a.ldd = segs[0].ldd;
     a.M = a.w.M;
     a.N = N;
     a.nb = nb;
-    const int tiles_m = (int)((a.M + MMQ_TM - 1) / MMQ_TM);
+    a.nseg = nseg;
+    int tiles_m = 0;
+    double rows = 0;
+    for (int i = 0; i < nseg; i++) {
+        tiles_m += (int)((segs[i].w.M + MMQ_TM - 1) / MMQ_TM);
+        rows += (double)segs[i].w.M;
+        if (i < 2) a.tile_end[i] = tiles_m;
+    }
+    if (nseg > 1) { a.wb = segs[1].w; a.dst_b = segs[1].dst; a.ldd_b = segs[1].ldd; }
+    if (nseg > 2) { a.wc = segs[2].w; a.dst_c = segs[2].dst; a.ldd_c = segs[2].ldd; }
     a.tiles_n = (int)((N + MMQ_TN - 1) / MMQ_TN);
-    // too few tiles to fill the chip (E x E at 512 tokens: 128 tiles for 256 CUs): split K in two, combined with
-    // commutative (2-addend) f32 atomic adds into a zeroed dst
-    const int nstage = (int)((nb + 1) / 2);
-    const int splits = (g.opt_mmq_splitk && tiles_m * a.tiles_n * 4 <= g.num_cus * 3 && nstage >= 16 && dst_contig) ? 2 : 1;
-    if (splits > 1) HIP_CHECK(hipMemsetAsync(a.dst, 0, (size_t)a.M * N * 4, g.stream));
+    if (splits <= 0) splits = mmq_auto_splits(tiles_m * a.tiles_n, nb, dst_contig);
+    a.split_stride = splits > 1 ? split_stride : 0;
+    if (splits > 1 && zero_dst && !split_stride)
+        for (int i = 0; i < nseg; i++) HIP_CHECK(hipMemsetAsync(segs[i].dst, 0, (size_t)segs[i].w.M * N * 4, g.stream));
     a.xcd_by_n = g.opt_mmq_xcdn == 2 ? 1 : g.opt_mmq_xcdn && (a.tiles_n == 1 || a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && tiles_m % (8 / a.tiles_n) == 0;
     const dim3 grid((unsigned)(tiles_m * a.tiles_n), (unsigned)splits);
     static bool lds_attr_set = false;
@@ -1009,7 +1035,30 @@ void mmq_f16_launch(int qt, const QWeight &w, const _Float16 *x16, const int8_t 
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
         lds_attr_set = true;
     }
-    Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * (double)a.M * (double)N * (double)(nb * 32));
+    Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * rows * (double)N * (double)(nb * 32));
+    if (use_dma && !use_x8 && g.opt_mmq_persist) {  // one workgroup per CU walks the tiles (kernels/mmq_dmap.h)
+        static bool p_attr_set = false;
+        if (!p_attr_set) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+            p_attr_set = true;
+        }
+        const int tiles_total = tiles_m * a.tiles_n, n_items = tiles_total * splits;
+        const dim3 pgrid((unsigned)std::min(n_items, g.num_cus));
+        switch (qt) {
+            case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q4_0>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+            case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q4_1>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+            case QT_Q5_0: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q5_0>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+            case QT_Q5_1: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q5_1>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+            case QT_Q8_0: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q8_0>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+            default: die("mmq: bad weight type");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (use_dma) {
         static bool dma_attr_set = false;
         if (!dma_attr_set) {
@@ -1051,6 +1100,12 @@ void mmq_f16_launch(int qt, const QWeight &w, const _Float16 *x16, const int8_t 
         default: die("mmq: bad weight type");
     }
     HIP_CHECK(hipGetLastError());
+}
+
+void mmq_f16_launch(int qt, const QWeight &w, const _Float16 *x16, const int8_t *x8, const _Float16 *dx, float *dst,
+                    int64_t ldd, int64_t N, int64_t nb, bool dst_contig) {
+    const MmqSegHost seg{w, dst, ldd};
+    mmq_f16_launch_multi(qt, 1, &seg, x16, x8, dx, N, nb, dst_contig, 0, true);
 }
 
 // Quantized GEMM on the f16 matrix cores (kernels/mmq.h); the `algo_bytes` slot of the MMQ_MFMA timing class
@@ -2114,6 +2169,10 @@ void ggml_hip_set_option(const char *key, int value) {
         if (g.opt_prefetch_delay != value) drop_all_plans();
         g.opt_prefetch_delay = value;
     }
+    else if (k == "mmq_fuse")
+        g.opt_mmq_fuse = value;
+    else if (k == "mmq_persist")
+        g.opt_mmq_persist = value;
     else if (k == "plan_prompt") {
         if (g.opt_plan_prompt != value) drop_all_plans();
         g.opt_plan_prompt = value;

@@ -193,7 +193,36 @@ struct MmqArgs {
     int64_t M, N, nb;
     int tiles_n;
     int xcd_by_n;  // 1: XCD x works on token tile x % tiles_n only (its slice of the activations stays in that L2)
+    // Several weight matrices that share the activations in ONE launch (the prompt plan's wq|wk|wv and w1|w3: the tiles
+    // of all matrices fill the chip together instead of each launch ending on a partial round of workgroups — 344
+    // tiles of a 7B w1 on 256 CUs are two rounds, 688 tiles of w1|w3 are three, not four).  Tile rows [0, tile_end[0])
+    // belong to w / dst, [tile_end[0], tile_end[1]) to wb / dst_b, the rest to wc / dst_c.  nseg <= 1: single matrix.
+    int64_t split_stride;  // != 0 with a K split: partial tiles are stored at dst + split * split_stride instead of added atomically
+    int nseg;
+    int tile_end[2];
+    QWeight wb, wc;
+    float *dst_b, *dst_c;
+    int64_t ldd_b, ldd_c;
 };
+
+// multi-matrix launch: tile row -> (matrix, tile row inside it); everything here is workgroup-uniform (scalar registers)
+__device__ __forceinline__ void mmq_select_seg(MmqArgs &a, int &tm) {
+    if (a.nseg > 1) {
+        if (a.nseg > 2 && tm >= a.tile_end[1]) {
+            tm -= a.tile_end[1];
+            a.w = a.wc;
+            a.dst = a.dst_c;
+            a.ldd = a.ldd_c;
+            a.M = a.wc.M;
+        } else if (tm >= a.tile_end[0]) {
+            tm -= a.tile_end[0];
+            a.w = a.wb;
+            a.dst = a.dst_b;
+            a.ldd = a.ldd_b;
+            a.M = a.wb.M;
+        }
+    }
+}
 
 // registers holding one stage of global data in flight: the weight block (5..10 VGPRs) and the 4 activation chunks
 // (16 VGPRs); two ring slots each (stages s+1 and s+2)
@@ -240,7 +269,8 @@ __device__ __forceinline__ void mmq_load_x(MmqX &s, const MmqArgs &a, int64_t kb
 // gridDim.y = number of K splits (1 or 2): with 2 the partial tiles are combined with f32 atomic adds into a zeroed
 // dst — two addends commute, so the result does not depend on arrival order.
 template <int QT>
-__global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
+__global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a_in) {
+    MmqArgs a = a_in;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -258,6 +288,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
         tm = t / a.tiles_n;
         tn = t % a.tiles_n;
     }
+    mmq_select_seg(a, tm);
     const int64_t m0 = (int64_t)tm * MMQ_TM, n0 = (int64_t)tn * MMQ_TN;
 
     // staging assignment
@@ -366,7 +397,10 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
 
     // C layout of the 32x32 MFMA: column (B index = weight row) = lane & 31,
     // row (A index = token) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const bool split = gridDim.y > 1;
+    // K split in two: either f32 atomic adds into a zeroed dst (two addends commute), or — split_stride != 0 — each
+    // half stores its partial tile to its own buffer (dst + blockIdx.y * split_stride) and the consumer adds them
+    const bool split = gridDim.y > 1 && a.split_stride == 0;
+    float *const dstp = a.dst + (int64_t)blockIdx.y * a.split_stride;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -379,7 +413,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
                     if (split)
                         unsafeAtomicAdd(a.dst + n * a.ldd + m, acc[j][i][r]);
                     else
-                        a.dst[n * a.ldd + m] = acc[j][i][r];
+                        dstp[n * a.ldd + m] = acc[j][i][r];
                 }
             }
         }

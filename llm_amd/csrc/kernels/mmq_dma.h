@@ -53,7 +53,8 @@ __device__ __forceinline__ constexpr int dma_group() {  // DMA instructions per 
 }
 
 template <int QT, bool X8 = false>
-__global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
+__global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a_in) {
+    MmqArgs a = a_in;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,6 +72,7 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
         tm = t / a.tiles_n;
         tn = t % a.tiles_n;
     }
+    mmq_select_seg(a, tm);
     const int64_t m0 = (int64_t)tm * MMQ_TM, n0 = (int64_t)tn * MMQ_TN;
 
     // this workgroup's stages [s_begin, s_end) of the K loop (K/32 is even: checked by the launcher)
@@ -253,7 +255,10 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the workgroup's LDS is released
 
-    const bool split = gridDim.y > 1;
+    // K split in two: either f32 atomic adds into a zeroed dst (two addends commute), or — split_stride != 0 — each
+    // half stores its partial tile to its own buffer (dst + blockIdx.y * split_stride) and the consumer adds them
+    const bool split = gridDim.y > 1 && a.split_stride == 0;
+    float *const dstp = a.dst + (int64_t)blockIdx.y * a.split_stride;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(256, 1) k_mmq_dma(const MmqArgs a) {
                     if (split)
                         unsafeAtomicAdd(a.dst + n * a.ldd + mrow, acc[j][i][r]);
                     else
-                        a.dst[n * a.ldd + mrow] = acc[j][i][r];
+                        dstp[n * a.ldd + mrow] = acc[j][i][r];
                 }
             }
         }

@@ -29,67 +29,146 @@ __device__ __forceinline__ _Float16 p_requant(float v) {
     return (_Float16)r;
 }
 
-// one 256-thread workgroup per token row.  ADD: xs = x + r first (written to xsum: the residual stream of the layer).
+// one 256-thread workgroup per token row.  ADD: xs = (x [+ x2]) + r first (written to xsum: the residual stream of the
+// layer; x2 = the second partial of a K-split GEMM, only with ADD).
 // E % 32 == 0 (a block never straddles two rows of threads).
 template <bool F16_D, bool ADD>
-__global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ x, const float *__restrict__ r, float *xsum,
-                                                      const float *__restrict__ w, float eps, int E, float *y_f32 /*nullable*/,
-                                                      _Float16 *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ x, const float *__restrict__ x2 /*nullable*/,
+                                                      const float *__restrict__ r, float *xsum, const float *__restrict__ w,
+                                                      float eps, int E, float *y_f32 /*nullable*/, _Float16 *__restrict__ out) {
     __shared__ double s_part[4];
     const int64_t row = blockIdx.x;
     const float *xr = x + row * E;
-    const float *src = xr;
-    if constexpr (ADD) {
-        const float *rr = r + row * E;
-        float *xs = xsum + row * E;
-        double s = 0.0;
-        for (int i = threadIdx.x; i < E; i += 256) {
-            const float v = xr[i] + rr[i];
-            xs[i] = v;
-            s += (double)(v * v);
+    const float *x2r = x2 ? x2 + row * E : nullptr;  // second partial of a K-split GEMM: x = x + x2 (what the atomics computed)
+    const float *rr = ADD ? r + row * E : nullptr;
+    float *xs = ADD ? xsum + row * E : nullptr;
+    const float *src = ADD ? xs : xr;  // pass 2 re-reads what the same thread wrote in pass 1 (L2)
+    constexpr int U = 8;  // loads of a chunk are independent: 8 (16 with the residual) in flight per thread
+    // pass 1: thread t sums elements t, t + 256, ... in ascending order, like k_rms_norm (f64 accumulation)
+    double s = 0.0;
+    for (int i0 = threadIdx.x; i0 < E; i0 += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 256;
+            v[u] = i < E ? xr[i] : 0.0f;
         }
-        s = wave_sum_f64(s);
-        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
-        src = xs;  // re-read below by the thread that wrote it
-    } else {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < E; i += 256) {
-            const float v = xr[i];
-            s += (double)(v * v);
+        if constexpr (ADD) {
+            float t[U];
+            if (x2r) {  // uniform
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int i = i0 + u * 256;
+                    t[u] = i < E ? x2r[i] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = v[u] + t[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * 256;
+                t[u] = i < E ? rr[i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = v[u] + t[u];
         }
-        s = wave_sum_f64(s);
-        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 256;
+            if (i < E) {
+                if constexpr (ADD) xs[i] = v[u];
+                s += (double)(v[u] * v[u]);
+            }
+        }
     }
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
     __syncthreads();
     const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
     const float mean = (float)(tot / (double)E);
     const float scale = 1.0f / sqrtf(mean + eps);
     _Float16 *orow = out + row * E;
-    for (int i0 = 0; i0 < E; i0 += 256) {  // uniform trip count: whole blocks of 32 lanes take part in the reduction
-        const int i = i0 + threadIdx.x;
-        float v = 0.0f;
-        if (i < E) {
-            v = src[i] * scale;
-            v = v * w[i];
-            if (y_f32) y_f32[row * E + i] = v;
+    for (int i0 = 0; i0 < E; i0 += 256 * U) {  // uniform trip count: whole blocks of 32 lanes take part in the reduction
+        float v[U], ww[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 256 + threadIdx.x;
+            v[u] = i < E ? src[i] : 0.0f;
+            ww[u] = i < E ? w[i] : 0.0f;
         }
-        const _Float16 h = p_requant<F16_D>(v);
-        if (i < E) orow[(i & ~31) + mmq_kperm_inv(i & 31)] = h;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 256 + threadIdx.x;
+            if (i0 + u * 256 >= E) break;  // uniform
+            float y = v[u] * scale;
+            y = y * ww[u];
+            if (y_f32 && i < E) y_f32[row * E + i] = y;
+            const _Float16 h = p_requant<F16_D>(i < E ? y : 0.0f);
+            if (i < E) orow[(i & ~31) + mmq_kperm_inv(i & 31)] = h;
+        }
     }
 }
 
-// silu(a) * b (ggml's f16-table SiLU) -> re-quantization; 32 lanes per block, n = number of elements (multiple of 32)
+// Four consecutive values of a block per lane (a block = 8 lanes): the same re-quantization, the block maximum taken over
+// the lane's four values and then over the 8 lanes.  Element 4*l8 + i of the block goes to position
+// 8*(l8 & 3) + 4*(l8 >> 2) + {0, 2, 1, 3}[i] of the GEMM's k order (mmq_kperm_inv): four adjacent f16, one 8-byte store.
 template <bool F16_D>
-__global__ void __launch_bounds__(256) k_p_silu_mul_quant(const float *__restrict__ a, const float *__restrict__ b, int64_t n,
+__device__ __forceinline__ void p_requant4_store(const f32x4 v, int64_t i4 /* index of the lane's 4-vector */, bool valid,
+                                                 _Float16 *__restrict__ out) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = g8_max_f32(amax);
+    float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const float dq = F16_D ? round_f16(d) : d;  // id comes from the unrounded d, as in k_quant_act_f16
+    _Float16 h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = (int)roundf(v[k] * id);
+        float r = dq * (float)q;
+        r = fminf(fmaxf(r, -65504.0f), 65504.0f);
+        h[k] = (_Float16)r;
+    }
+    if (valid) {
+        const int l8 = (int)(i4 & 7);
+        const int64_t base = (i4 >> 3) * 32 + 8 * (l8 & 3) + 4 * (l8 >> 2);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 o = {h[0], h[2], h[1], h[3]};
+        *(f16x4 *)(out + base) = o;
+    }
+}
+
+// f32 rows (contiguous, n4 4-vectors in total) -> re-quantized f16 operand: k_quant_act_f16 with four values per lane
+template <bool F16_D>
+__global__ void __launch_bounds__(256) k_p_quant4(const f32x4 *__restrict__ a, int64_t n4, _Float16 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n4;
+    const f32x4 v = valid ? a[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    p_requant4_store<F16_D>(v, i, valid, out);
+}
+
+// silu(a) * b (ggml's f16-table SiLU) -> re-quantization; four values per lane, n4 = number of 4-vectors (rows are
+// multiples of 32 wide, so a block never straddles rows)
+template <bool F16_D>
+__global__ void __launch_bounds__(256) k_p_silu_mul_quant(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, int64_t n4,
+                                                          int64_t part4 /* != 0: second partials this many 4-vectors on */,
                                                           _Float16 *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float v = 0.0f;
-    if (i < n) {
-        v = silu_table(a[i]);
-        v = v * b[i];
+    const bool valid = i < n4;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (valid) {
+        f32x4 x = a[i], y = b[i];
+        if (part4) {
+            x = x + a[i + part4];
+            y = y + b[i + part4];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float t = silu_table(x[k]);
+            t = t * y[k];
+            v[k] = t;
+        }
     }
-    const _Float16 h = p_requant<F16_D>(v);
-    if (i < n) out[(i & ~(int64_t)31) + mmq_kperm_inv((int)(i & 31))] = h;
+    p_requant4_store<F16_D>(v, i, valid, out);
 }
 
 // RoPE + K/V store of a prompt batch.  q [N][E] f32 is rotated in place; kf [N][Egqa], vf [N][Egqa] f32 are the wk / wv
@@ -102,35 +181,44 @@ struct PQkvPost {
     __half *mem_k, *mem_v;
     int N, E, Egqa, D, n_past;
     int64_t C;
-    int nb_rope, vt_n, vt_m;  // rope blocks; V tiles along tokens / channels
+    int nb_rope, vt_n, vt_m;  // rope blocks (two pairs per thread); V tiles along tokens / channels
+    int64_t part;             // != 0: q / kf / vf are the first partials of a K-split GEMM, the second ones lie `part` floats on
 };
 __global__ void __launch_bounds__(256) k_p_qkv_post(const PQkvPost a) {
     __shared__ float s_t[64][65];
     const int b = blockIdx.x;
     if (b < a.nb_rope) {
-        const int per_tok = (a.E + a.Egqa) >> 1;  // pairs per token: Q then K
+        const int per_tok = (a.E + a.Egqa) >> 2;  // 4-vectors (two pairs) per token: Q then K; D/2 is even, so are E/2, Egqa/2
         const int64_t idx = (int64_t)b * 256 + threadIdx.x;
         if (idx >= (int64_t)a.N * per_tok) return;
         const int n = (int)(idx / per_tok), pr = (int)(idx - (int64_t)n * per_tok);
-        const bool is_k = pr >= (a.E >> 1);
-        const int pi = is_k ? pr - (a.E >> 1) : pr;  // pair index inside the row
+        const bool is_k = pr >= (a.E >> 2);
+        const int pi = 2 * (is_k ? pr - (a.E >> 2) : pr);  // first of the two pairs, index inside the row
         const int kk = pi % (a.D >> 1);
-        const f32x2 cs = *(const f32x2 *)(a.tab + (int64_t)n * 128 + 2 * kk);
-        const float c = cs[0], s = cs[1];
+        const f32x4 cs = *(const f32x4 *)(a.tab + (int64_t)n * 128 + 2 * kk);  // cos, sin of pairs kk, kk + 1
         if (!is_k) {
             float *p = a.q + (int64_t)n * a.E + 2 * pi;
-            const f32x2 v = *(const f32x2 *)p;
-            f32x2 o;
-            o[0] = v[0] * c - v[1] * s;
-            o[1] = v[0] * s + v[1] * c;
-            *(f32x2 *)p = o;
+            f32x4 v = *(const f32x4 *)p;
+            if (a.part) v = v + *(const f32x4 *)(p + a.part);
+            f32x4 o;
+            o[0] = v[0] * cs[0] - v[1] * cs[1];
+            o[1] = v[0] * cs[1] + v[1] * cs[0];
+            o[2] = v[2] * cs[2] - v[3] * cs[3];
+            o[3] = v[2] * cs[3] + v[3] * cs[2];
+            *(f32x4 *)p = o;
         } else {
-            const f32x2 v = *(const f32x2 *)(a.kf + (int64_t)n * a.Egqa + 2 * pi);
-            const float o0 = v[0] * c - v[1] * s, o1 = v[0] * s + v[1] * c;
-            __half2 h;
-            h.x = __float2half_rn(o0);
-            h.y = __float2half_rn(o1);
-            *(__half2 *)(a.mem_k + ((int64_t)a.n_past + n) * a.Egqa + 2 * pi) = h;
+            f32x4 v = *(const f32x4 *)(a.kf + (int64_t)n * a.Egqa + 2 * pi);
+            if (a.part) v = v + *(const f32x4 *)(a.kf + a.part + (int64_t)n * a.Egqa + 2 * pi);
+            const float o0 = v[0] * cs[0] - v[1] * cs[1], o1 = v[0] * cs[1] + v[1] * cs[0];
+            const float o2 = v[2] * cs[2] - v[3] * cs[3], o3 = v[2] * cs[3] + v[3] * cs[2];
+            __half2 h0, h1;
+            h0.x = __float2half_rn(o0);
+            h0.y = __float2half_rn(o1);
+            h1.x = __float2half_rn(o2);
+            h1.y = __float2half_rn(o3);
+            __half2 *dst = (__half2 *)(a.mem_k + ((int64_t)a.n_past + n) * a.Egqa + 2 * pi);
+            dst[0] = h0;
+            dst[1] = h1;
         }
         return;
     }
@@ -140,7 +228,12 @@ __global__ void __launch_bounds__(256) k_p_qkv_post(const PQkvPost a) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int n = n0 + ly + 4 * i, m = m0 + lx;
-        s_t[ly + 4 * i][lx] = (n < a.N && m < a.Egqa) ? a.vf[(int64_t)n * a.Egqa + m] : 0.0f;
+        float v = 0.0f;
+        if (n < a.N && m < a.Egqa) {
+            v = a.vf[(int64_t)n * a.Egqa + m];
+            if (a.part) v = v + a.vf[a.part + (int64_t)n * a.Egqa + m];
+        }
+        s_t[ly + 4 * i][lx] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -161,6 +254,40 @@ __global__ void __launch_bounds__(256) k_p_soft_max(float *x, int64_t rows, int 
     const int lane = threadIdx.x & 63;
     float *p = x + row * nc;
     const int lim = n_past + (int)(row % nr);  // columns > lim are masked
+    if (nc <= 512) {  // the whole row in registers: one read, one write (8 independent loads per lane)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = lane + 64 * u;
+            v[u] = (i < nc && i <= lim) ? p[i] : 0.0f;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = lane + 64 * u;
+            v[u] = (i < nc && i <= lim) ? v[u] * scale : -INFINITY;
+            mx = fmaxf(mx, v[u]);
+        }
+        mx = wave_max_f32(mx);
+        double sum = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            float e = 0.0f;
+            if (v[u] != -INFINITY) {
+                e = round_f16(expf(round_f16(v[u] - mx)));
+                sum += (double)e;
+            }
+            v[u] = e;
+        }
+        sum = wave_sum_f64(sum);
+        const float inv = (float)(1.0 / sum);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = lane + 64 * u;
+            if (i < nc) p[i] = v[u] * inv;
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int i = lane; i < nc; i += 64) {
         const float v = i > lim ? -INFINITY : p[i] * scale;

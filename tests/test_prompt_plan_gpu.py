@@ -14,6 +14,9 @@ pytestmark = pytest.mark.gpu
 
 GQA = dict(n_vocab=256, n_embd=128, n_head=4, n_head_kv=2, n_layer=2, n_rot=32, n_ff=352, n_mult=32)
 WIDE = dict(n_vocab=320, n_embd=256, n_head=4, n_head_kv=4, n_layer=3, n_rot=64, n_ff=512, n_mult=32)  # K/32 even everywhere: DMA GEMM
+# K >= 1024 and few tiles: every GEMM splits K in two — atomics into a zeroed dst in the node-by-node executor, partial
+# tiles added by the consuming kernel in the plan; grouped-query attention on top (wk / wv narrower than wq)
+SPLITK = dict(n_vocab=256, n_embd=1024, n_head=8, n_head_kv=4, n_layer=2, n_rot=128, n_ff=2048, n_mult=32)
 
 
 def _stat(G, key):
@@ -38,10 +41,13 @@ def _run(G, model, chunks, plan, want_emb=False):
 
 
 @pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
-@pytest.mark.parametrize("cfg", ["tiny", "gqa", "wide"])
+@pytest.mark.parametrize("cfg", ["tiny", "gqa", "wide", "splitk", "splitk_unfused"])
 def test_prompt_plan_is_bit_identical_to_the_node_by_node_executor(G, wtype, cfg):
     from llm_amd import llama, synth
-    hp0 = {"tiny": synth.TINY, "gqa": GQA, "wide": WIDE}[cfg]
+    if cfg.startswith("splitk") and wtype not in (2, 7):
+        pytest.skip("the K-split paths do not depend on the block format: two formats")
+    hp0 = {"tiny": synth.TINY, "gqa": GQA, "wide": WIDE, "splitk": SPLITK, "splitk_unfused": SPLITK}[cfg]
+    G.set_option("mmq_fuse", 0 if cfg == "splitk_unfused" else 3)
     hp, w = synth.make_llama(hp0, wtype, seed=5)
     model = llama.Llama(hp, w, context_size=512)
     toks = np.random.default_rng([wtype, len(cfg)]).integers(0, hp["n_vocab"], 400).astype(np.int32)
@@ -55,6 +61,7 @@ def test_prompt_plan_is_bit_identical_to_the_node_by_node_executor(G, wtype, cfg
         assert np.array_equal(la, lb), (cfg, wtype, i, float(np.max(np.abs(la - lb))))
         assert np.array_equal(ea, eb), (cfg, wtype, i)
     assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    G.set_option("mmq_fuse", 3)
     model.free()
 
 
@@ -111,3 +118,31 @@ def test_prompt_plan_stage_of_a_layer_split(G):
 
     for x, y in zip(run(1), run(0)):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
+@pytest.mark.parametrize("cfg", ["wide", "splitk"])
+def test_persistent_gemm_is_bit_identical_to_one_workgroup_per_tile(G, wtype, cfg):
+    """k_mmq_dma_p (one workgroup per CU walks the tiles, the DMA ring runs across tile boundaries) against k_mmq_dma (one
+    workgroup per tile): same tile arithmetic, so the same bits — node-by-node executor (atomics for K splits) and plan
+    (partial tiles), batches of 1..3 token tiles, more tiles than CUs in none of them (that is covered at full size by
+    tests/test_fullsize_gpu.py against the oracle)."""
+    from llm_amd import llama, synth
+    if cfg == "splitk" and wtype not in (2, 7):
+        pytest.skip("two formats for the K-split shapes")
+    hp, w = synth.make_llama({"wide": WIDE, "splitk": SPLITK}[cfg], wtype, seed=6)
+    model = llama.Llama(hp, w, context_size=512)
+    toks = np.random.default_rng([wtype, 5]).integers(0, hp["n_vocab"], 330).astype(np.int32)
+    chunks = [toks[0:40], toks[40:170], toks[170:330]]
+    res = {}
+    for persist in (1, 0):
+        G.set_option("mmq_persist", persist)
+        for plan in (1, 0):
+            res[persist, plan] = _run(G, model, chunks, plan)
+    G.set_option("mmq_persist", 1)
+    for plan in (1, 0):
+        (a, ka, va), (b, kb, vb) = res[1, plan], res[0, plan]
+        for la, lb in zip(a, b):
+            assert np.array_equal(la, lb), (cfg, wtype, plan, float(np.max(np.abs(la - lb))))
+        assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    model.free()
