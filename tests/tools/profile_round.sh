@@ -1,0 +1,24 @@
+#!/bin/bash
+# End-of-round measurement set (run on the MI355X box through gpurun): the driver's bench line, the rocprofv3 kernel
+# traces of the decode and prefill legs, and the PMC traffic passes.  Outputs under gpurun_out/; the summaries are
+# copied into profiles/ by hand.   bash tests/tools/profile_round.sh r02
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-rNN}
+cd $R
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 600 python bench.py > gpurun_out/${TAG}_bench_final.json 2> gpurun_out/${TAG}_bench_final.err
+cd /tmp
+rm -rf /tmp/prof_d /tmp/prof_p /tmp/pmc_f /tmp/pmc_w
+GGML_HIP_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_d -o d -- python $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline --prefill-steps 0 --weights blocks > $R/gpurun_out/${TAG}_bench_line_under_rocprof.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o p -- python $R/bench.py --mode prefill --weights blocks --no-cpu-baseline > $R/gpurun_out/${TAG}_prefill_line_under_rocprof.json 2> /dev/null
+GGML_HIP_GRAPH=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_f -o f -- python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --prefill-steps 0 --weights blocks --roofline-steps 1 > /dev/null 2>&1
+GGML_HIP_GRAPH=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc_w -o w -- python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --prefill-steps 0 --weights blocks --roofline-steps 1 > /dev/null 2>&1
+cd $R
+python tests/tools/kstats.py /tmp/prof_d > gpurun_out/${TAG}_decode7b_kernel_stats.txt 2>&1
+python tests/tools/kstats.py /tmp/prof_p > gpurun_out/${TAG}_prefill7b_kernel_stats.txt 2>&1
+python tests/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/${TAG}_pmc_traffic.err
+head -12 gpurun_out/${TAG}_decode7b_kernel_stats.txt
+head -12 gpurun_out/${TAG}_prefill7b_kernel_stats.txt
+cat gpurun_out/${TAG}_pmc_traffic.json | head -40
+tail -c 1500 gpurun_out/${TAG}_bench_final.json
