@@ -34,6 +34,7 @@
 #include "kernels/mmq.h"
 #include "kernels/mmq_dma.h"
 #include "kernels/mmq_dmap.h"
+#include "kernels/mmq_dmap8.h"
 #include "kernels/mmq_i8.h"
 #include "kernels/kquant.h"
 #include "kernels/quantize.h"
@@ -144,6 +145,7 @@ struct Backend {
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
     int opt_plan_prompt = 1; // fused plan for prompt batches of >= mmq_min tokens (kernels/prompt.h)
     int opt_mmq_persist = 1; // prompt GEMM as a persistent kernel (kernels/mmq_dmap.h)
+    int opt_mmq_waves = 8;   // waves per workgroup of the persistent prompt GEMM: 4 (mmq_dmap.h) or 8 (mmq_dmap8.h)
     int opt_mmq_fuse = 3;    // prompt plan: wq|wk|wv (bit 0) and w1|w3 (bit 1) as one GEMM launch each
     int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
     int opt_probe = 0;      // measurement only: k_mmvq_big returns early (BigArgs::probe), tests/tools/launch_probe.py
@@ -209,6 +211,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_PLAN_PROMPT")) g.opt_plan_prompt = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_FUSE")) g.opt_mmq_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_PERSIST")) g.opt_mmq_persist = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_WAVES")) g.opt_mmq_waves = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_I8")) g.opt_mmq_i8 = atoi(v);
@@ -1048,6 +1051,27 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
         }
         const int tiles_total = tiles_m * a.tiles_n, n_items = tiles_total * splits;
         const dim3 pgrid((unsigned)std::min(n_items, g.num_cus));
+        if (g.opt_mmq_waves == 8) {  // two waves per SIMD on the same tile (kernels/mmq_dmap8.h)
+            static bool p8_attr_set = false;
+            if (!p8_attr_set) {
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+                p8_attr_set = true;
+            }
+            switch (qt) {
+                case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_0>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_1>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q5_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q5_0>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q5_1: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q5_1>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q8_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q8_0>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+                default: die("mmq: bad weight type");
+            }
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         switch (qt) {
             case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q4_0>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
             case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q4_1>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
@@ -2173,6 +2197,8 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_mmq_fuse = value;
     else if (k == "mmq_persist")
         g.opt_mmq_persist = value;
+    else if (k == "mmq_waves")
+        g.opt_mmq_waves = value;
     else if (k == "plan_prompt") {
         if (g.opt_plan_prompt != value) drop_all_plans();
         g.opt_plan_prompt = value;

@@ -135,14 +135,17 @@ def test_persistent_gemm_is_bit_identical_to_one_workgroup_per_tile(G, wtype, cf
     toks = np.random.default_rng([wtype, 5]).integers(0, hp["n_vocab"], 330).astype(np.int32)
     chunks = [toks[0:40], toks[40:170], toks[170:330]]
     res = {}
-    for persist in (1, 0):
+    for persist, waves in ((1, 8), (1, 4), (0, 4)):  # 8 waves per workgroup (mmq_dmap8.h), 4 (mmq_dmap.h), one workgroup per tile
         G.set_option("mmq_persist", persist)
+        G.set_option("mmq_waves", waves)
         for plan in (1, 0):
-            res[persist, plan] = _run(G, model, chunks, plan)
+            res[persist, waves, plan] = _run(G, model, chunks, plan)
     G.set_option("mmq_persist", 1)
+    G.set_option("mmq_waves", 8)
     for plan in (1, 0):
-        (a, ka, va), (b, kb, vb) = res[1, plan], res[0, plan]
-        for la, lb in zip(a, b):
-            assert np.array_equal(la, lb), (cfg, wtype, plan, float(np.max(np.abs(la - lb))))
-        assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+        for variant in ((1, 8), (1, 4)):
+            (a, ka, va), (b, kb, vb) = res[variant + (plan,)], res[0, 4, plan]
+            for la, lb in zip(a, b):
+                assert np.array_equal(la, lb), (cfg, wtype, plan, variant, float(np.max(np.abs(la - lb))))
+            assert np.array_equal(ka, kb) and np.array_equal(va, vb)
     model.free()
