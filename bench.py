@@ -139,7 +139,7 @@ def prefill_leg(L, ggml, model, hp, n, steps, warmup):
     sess.free()
     return {"tokens": n, "steps": steps, "tokens_per_s": round(n * steps / elapsed, 1),
             "ms_per_step": round(elapsed / steps * 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "k_mmq_dma / k_mmq (quantized GEMM on the matrix cores)",
+            "roofline": {"bound": "mfma", "kernel": "k_mmq_dma_p8 (persistent quantized GEMM on the f16 matrix cores; wq|wk|wv, wo, w1|w3, w2 per layer + lm_head)",
                          "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "launches_per_step": launches,
                          "algo_flops_per_step": flops, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
@@ -267,7 +267,7 @@ def run_single(args):
     out = {"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}", "value": round(tok_s, 2),
            "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "i8*i4->i32 block dots, f32 accumulate (W4A8 = ggml's Q4_0·Q8_0)",
+           "vs_baseline": None, "dtype": DTYPES[args.wtype],
            "data": "synthetic",
            "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode "
                                   f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",
@@ -290,6 +290,15 @@ def run_single(args):
     model.free()
 
 
+DTYPES = {  # the arithmetic the decode path computes in: ggml's block dot of the weight type with its vec_dot_type
+    "q4_0": "i8*i4->i32 block dots, f32 accumulate (W4A8 = ggml's Q4_0·Q8_0)",
+    "q4_1": "i8*u4->i32 block dots + m*s term, f32 accumulate (ggml's Q4_1·Q8_1)",
+    "q5_0": "i8*i5->i32 block dots, f32 accumulate (ggml's Q5_0·Q8_0)",
+    "q5_1": "i8*u5->i32 block dots + m*s term, f32 accumulate (ggml's Q5_1·Q8_1)",
+    "q8_0": "i8*i8->i32 block dots, f32 accumulate (ggml's Q8_0·Q8_0)",
+    "q4_k": "i8*u4->i32 sub-block dots with 6-bit scales, f32 accumulate (ggml's Q4_K·Q8_K)",
+    "q6_k": "i8*i6->i32 sub-block dots with 8-bit scales, f32 accumulate (ggml's Q6_K·Q8_K)",
+}
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X dense f16 MFMA peak, MI355X_MICROARCH.md "BF16/F16 ~2.5 PF dense"
 
 
@@ -330,7 +339,7 @@ def run_prefill(args):
         cls[name] = (ms, launches, work)
     ms, launches, flops = cls["mmq_mfma"]
     achieved = flops / 1e12 / (ms / 1e3) if ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "k_mmq (quantized GEMM, in-LDS dequant to f16, v_mfma_f32_32x32x16_f16)",
+    roofline = {"bound": "mfma", "kernel": "k_mmq_dma_p8 (persistent quantized GEMM, in-LDS dequant to f16, v_mfma_f32_32x32x16_f16)",
                 "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches_per_step": launches,

@@ -6,6 +6,7 @@ Layout (only what the path needs):
   ggml.py          ctypes twin of the reference's `ggml-sys` bindings over that ABI
   llama.py         ctypes handle on the host mirror (Model / InferenceSession call sequence)
   synth.py         synthetic GGML-format weights (no real checkpoints are obtainable offline)
-  ggjt.py          GGJT v3 container writer/reader (crates/ggml/src/format)
+  gpt2.py          GPT-2 (BASELINE configs[0]) graph builder over the ctypes binding
+  pipeline.py      layer split over several GPUs: stages, schedule, the residual hop through ggml_hip_comm_* (RCCL)
 """
 __all__ = ["ggml", "llama", "synth"]
