@@ -18,8 +18,10 @@ drain, (3) waits for the input, (4) evaluates its layers, (5) posts the send of 
 first is what makes the ring (last rank → rank 0 for the token) deadlock-free.
 
 The stage compute is behind a tiny interface (`Stage`) so that tests/test_pipeline_cpu.py can run the schedule and
-the message protocol on CPU (gloo, world size 2) with a stub stage, and tests/test_pipeline_gpu.py can run real
-stages of a split model on one GPU.
+the message protocol on CPU (gloo, world sizes 2 and 3) with a stub stage; real stages of a split model run on one GPU in
+tests/test_llama_gpu.py (test_layer_split_stages_match_whole_model; the RCCL hop itself in
+test_layer_split_hop_through_rccl_inside_the_library, as a 1-rank communicator sending to itself) and
+tests/test_prompt_plan_gpu.py (prompt batches through a split).
 """
 import json
 import os
