@@ -1264,6 +1264,8 @@ void op_mul_mat(ggml_tensor *dst) {
             ga.M = a->ne[1]; ga.N = b->ne[1]; ga.K = a->ne[0];
             ga.ne12 = b->ne[2]; ga.r2 = b->ne[2] / a->ne[2]; ga.r3 = b->ne[3] / a->ne[3];
             ga.tiles_n = (int)((ga.N + 127) / 128);
+            ga.causal = 0;
+            ga.causal_past = 0;
             const int tiles_m = (int)((ga.M + 127) / 128);
             static bool attr_set = false;
             if (!attr_set) {

@@ -25,6 +25,13 @@ struct GemmF16Args {
     int64_t M, N, K;
     int64_t ne12, r2, r3;  // batch dims of src1; broadcast ratios src1/src0 (GQA)
     int tiles_n;
+    // causal structure of a prompt batch (the prompt plan; 0 = plain GEMM).  Row n of src1 is query n at position
+    // causal_past + n and may look at keys 0 .. causal_past + n.
+    //   1 (K.Q: M runs over keys): tiles whose keys all lie beyond the last query of the tile are skipped — the softmax
+    //     never reads those scores.   2 (V.P: K runs over keys): the k loop stops after the last key any query of the
+    //     tile can see — the probabilities beyond are exact zeros.
+    int causal;
+    int causal_past;
 };
 
 __device__ __forceinline__ u32x4 gf16_mask_tail(u32x4 v, int valid /*elements 0..8*/) {
@@ -37,6 +44,7 @@ __device__ __forceinline__ u32x4 gf16_mask_tail(u32x4 v, int valid /*elements 0.
     return v;
 }
 
+template <bool B16>
 __device__ __forceinline__ void gf16_load(u32x4 (&ra)[4], u32x4 (&rb)[4], const GemmF16Args &g, const char *ab,
                                           const char *bb, int64_t m0, int64_t n0, int64_t k0, int tid) {
 #pragma unroll
@@ -50,7 +58,12 @@ __device__ __forceinline__ void gf16_load(u32x4 (&ra)[4], u32x4 (&rb)[4], const 
                 va = *(const u32x4 *)(ab + (m0 + row) * g.a_nb1 + k * 2);  // host checked 16-B alignment
                 if (valid < 8) va = gf16_mask_tail(va, valid);
             }
-            if (n0 + row < g.N) {
+            if (B16) {  // src1 already converted (rows 16-byte aligned: host checked)
+                if (n0 + row < g.N) {
+                    vb = *(const u32x4 *)(bb + (n0 + row) * g.b_nb1 + k * 2);
+                    if (valid < 8) vb = gf16_mask_tail(vb, valid);
+                }
+            } else if (n0 + row < g.N) {
                 const float *bp = (const float *)(bb + (n0 + row) * g.b_nb1) + k;
                 float f[8];
                 if (valid == 8) {
@@ -76,7 +89,8 @@ __device__ __forceinline__ void gf16_load(u32x4 (&ra)[4], u32x4 (&rb)[4], const 
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_gemm_f16(const GemmF16Args g) {
+template <bool B16>
+__device__ __forceinline__ void gemm_f16_body(const GemmF16Args &g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -88,6 +102,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f16(const GemmF16Args g) {
     const char *bb = g.b + i12 * g.b_nb2 + i13 * g.b_nb3;
     char *db = g.d + i12 * g.d_nb2 + i13 * g.d_nb3;
 
+    const int64_t last_key = (int64_t)g.causal_past + n0 + 127;  // the last key a query of this tile can see
+    if (g.causal == 1 && m0 > last_key) return;                 // uniform
     f32x16 acc[2][2];
 #pragma unroll
     for (int j = 0; j < 2; j++)
@@ -96,9 +112,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f16(const GemmF16Args g) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[j][i][r] = 0.0f;
 
-    const int nstage = (int)((g.K + 63) >> 6);
+    const int64_t K_eff = g.causal == 2 ? min(g.K, last_key + 1) : g.K;
+    const int nstage = (int)((K_eff + 63) >> 6);
     u32x4 ra[4], rb[4];
-    gf16_load(ra, rb, g, ab, bb, m0, n0, 0, tid);
+    gf16_load<B16>(ra, rb, g, ab, bb, m0, n0, 0, tid);
     for (int s = 0; s < nstage; s++) {
         char *W = lds + (s & 1) * 2 * MMQ_TILEB, *X = W + MMQ_TILEB;
 #pragma unroll
@@ -108,7 +125,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f16(const GemmF16Args g) {
             *(u32x4 *)(X + off) = rb[i];
         }
         __syncthreads();
-        if (s + 1 < nstage) gf16_load(ra, rb, g, ab, bb, m0, n0, (int64_t)(s + 1) * 64, tid);
+        if (s + 1 < nstage) gf16_load<B16>(ra, rb, g, ab, bb, m0, n0, (int64_t)(s + 1) * 64, tid);
         mma_stage_128x128(W, X, lane, wm, wn, acc);
     }
 #pragma unroll
@@ -123,3 +140,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f16(const GemmF16Args g) {
             }
         }
 }
+
+__global__ void __launch_bounds__(256, 2) k_gemm_f16(const GemmF16Args g) { gemm_f16_body<false>(g); }
+// src1 given as f16 (the prompt plan's probabilities, written as f16 by k_p_soft_max)
+__global__ void __launch_bounds__(256, 2) k_gemm_f16_b16(const GemmF16Args g) { gemm_f16_body<true>(g); }

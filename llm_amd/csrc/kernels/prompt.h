@@ -29,6 +29,9 @@ __device__ __forceinline__ _Float16 p_requant(float v) {
     return (_Float16)r;
 }
 
+template <bool F16_D>
+__device__ __forceinline__ void p_requant4_store(const f32x4 v, int64_t i4, bool valid, _Float16 *__restrict__ out);
+
 // one 256-thread workgroup per token row.  ADD: xs = (x [+ x2]) + r first (written to xsum: the residual stream of the
 // layer; x2 = the second partial of a K-split GEMM, only with ADD).
 // E % 32 == 0 (a block never straddles two rows of threads).
@@ -42,7 +45,7 @@ __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ 
     const float *x2r = x2 ? x2 + row * E : nullptr;  // second partial of a K-split GEMM: x = x + x2 (what the atomics computed)
     const float *rr = ADD ? r + row * E : nullptr;
     float *xs = ADD ? xsum + row * E : nullptr;
-    const float *src = ADD ? xs : xr;  // pass 2 re-reads what the same thread wrote in pass 1 (L2)
+    const float *src = ADD ? xs : xr;  // pass 2 re-reads what pass 1 wrote (L2)
     constexpr int U = 8;  // loads of a chunk are independent: 8 (16 with the residual) in flight per thread
     // pass 1: thread t sums elements t, t + 256, ... in ascending order, like k_rms_norm (f64 accumulation)
     double s = 0.0;
@@ -87,24 +90,33 @@ __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ 
     const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
     const float mean = (float)(tot / (double)E);
     const float scale = 1.0f / sqrtf(mean + eps);
+    // pass 2 is element-wise apart from the block maximum (order-free): four consecutive values per lane, a block = 8 lanes,
+    // so the maximum needs three DPP steps instead of an LDS round trip per value (16 dependent ds_bpermute per thread
+    // made this kernel 13 us for 28 MB).  The values of pass 1 come back from L2 (written by other threads of this
+    // workgroup before the barrier above).
     _Float16 *orow = out + row * E;
-    for (int i0 = 0; i0 < E; i0 += 256 * U) {  // uniform trip count: whole blocks of 32 lanes take part in the reduction
-        float v[U], ww[U];
+    const int E4 = E >> 2;
+    for (int j0 = 0; j0 < E4; j0 += 256 * 2) {  // uniform trip count: whole 8-lane groups take part in the reduction
+        f32x4 v[2], ww[2];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * 256 + threadIdx.x;
-            v[u] = i < E ? src[i] : 0.0f;
-            ww[u] = i < E ? w[i] : 0.0f;
+        for (int u = 0; u < 2; u++) {
+            const int j = j0 + u * 256 + threadIdx.x;
+            v[u] = j < E4 ? ((const f32x4 *)src)[j] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            ww[u] = j < E4 ? ((const f32x4 *)w)[j] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * 256 + threadIdx.x;
-            if (i0 + u * 256 >= E) break;  // uniform
-            float y = v[u] * scale;
-            y = y * ww[u];
-            if (y_f32 && i < E) y_f32[row * E + i] = y;
-            const _Float16 h = p_requant<F16_D>(i < E ? y : 0.0f);
-            if (i < E) orow[(i & ~31) + mmq_kperm_inv(i & 31)] = h;
+        for (int u = 0; u < 2; u++) {
+            const int j = j0 + u * 256 + threadIdx.x;
+            if (j0 + u * 256 >= E4) break;  // uniform
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float t = v[u][k] * scale;
+                t = t * ww[u][k];
+                y[k] = t;
+            }
+            if (y_f32 && j < E4) ((f32x4 *)(y_f32 + row * E))[j] = y;
+            p_requant4_store<F16_D>(y, j, j < E4, orow);
         }
     }
 }
@@ -248,13 +260,19 @@ __global__ void __launch_bounds__(256) k_p_qkv_post(const PQkvPost a) {
 // sum in f64, y = e * (float)(1/sum).  The f64 sum is order-sensitive only through rounding of a double accumulation of
 // f16-valued terms (<= 2^15 terms of 11 significant bits each fit 53 bits exactly), so any order gives the same bits.
 // x: [rows][nc] f32, in place; row r of a head has query index j = r % nr and sees columns <= n_past + j.
-__global__ void __launch_bounds__(256) k_p_soft_max(float *x, int64_t rows, int nc, int nr, float scale, int n_past) {
+// y16 != nullptr: the probabilities are written as f16 rows of ld16 elements instead of in place — the V.P product
+// converts them to f16 anyway (ggml converts src1 of an F16 mat-mul; k_gemm_f16 does it while loading), so the bits
+// that reach the matrix cores are the same and the row is written and read once at half the size.
+__global__ void __launch_bounds__(256) k_p_soft_max(float *x, int64_t rows, int nc, int nr, float scale, int n_past,
+                                                    _Float16 *y16, int64_t ld16) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     float *p = x + row * nc;
+    _Float16 *p16 = y16 ? y16 + row * ld16 : nullptr;
     const int lim = n_past + (int)(row % nr);  // columns > lim are masked
-    if (nc <= 512) {  // the whole row in registers: one read, one write (8 independent loads per lane)
+    if (nc <= 512) {  // the whole row in registers: one read, one write (8 independent loads per lane; pairing adjacent
+                      // columns per lane for 4-byte f16 stores was measured slower: 27 vs 23 us)
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -284,7 +302,12 @@ __global__ void __launch_bounds__(256) k_p_soft_max(float *x, int64_t rows, int 
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int i = lane + 64 * u;
-            if (i < nc) p[i] = v[u] * inv;
+            if (i < nc) {
+                if (p16)
+                    p16[i] = (_Float16)(v[u] * inv);
+                else
+                    p[i] = v[u] * inv;
+            }
         }
         return;
     }
@@ -306,5 +329,10 @@ __global__ void __launch_bounds__(256) k_p_soft_max(float *x, int64_t rows, int 
     }
     sum = wave_sum_f64(sum);
     const float inv = (float)(1.0 / sum);
-    for (int i = lane; i < nc; i += 64) p[i] *= inv;  // the same lane wrote p[i]
+    for (int i = lane; i < nc; i += 64) {  // the same lane wrote p[i]
+        if (p16)
+            p16[i] = (_Float16)(p[i] * inv);
+        else
+            p[i] *= inv;
+    }
 }

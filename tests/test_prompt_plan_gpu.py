@@ -25,7 +25,7 @@ def _stat(G, key):
 
 def _run(G, model, chunks, plan, want_emb=False):
     G.set_option("plan_prompt", plan)
-    sess = model.start_session(n_batch=512)
+    sess = model.start_session(n_batch=192)
     outs = []
     for c in chunks:
         p0, g0 = _stat(G, "prompt_plan_tokens"), _stat(G, "generic_graphs")
