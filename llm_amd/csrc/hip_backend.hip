@@ -1054,19 +1054,19 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
         if (g.opt_mmq_waves == 8) {  // two waves per SIMD on the same tile (kernels/mmq_dmap8.h)
             static bool p8_attr_set = false;
             if (!p8_attr_set) {
-                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q4_0>::LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q4_1>::LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q5_0>::LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q5_1>::LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q8_0>::LDS));
                 p8_attr_set = true;
             }
             switch (qt) {
-                case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_0>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
-                case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_1>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
-                case QT_Q5_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q5_0>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
-                case QT_Q5_1: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q5_1>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
-                case QT_Q8_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q8_0>, pgrid, dim3(512), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_0>, pgrid, dim3(512), Dma8<QT_Q4_0>::LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_1>, pgrid, dim3(512), Dma8<QT_Q4_1>::LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q5_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q5_0>, pgrid, dim3(512), Dma8<QT_Q5_0>::LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q5_1: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q5_1>, pgrid, dim3(512), Dma8<QT_Q5_1>::LDS, g.stream, a, n_items, tiles_total, splits); break;
+                case QT_Q8_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q8_0>, pgrid, dim3(512), Dma8<QT_Q8_0>::LDS, g.stream, a, n_items, tiles_total, splits); break;
                 default: die("mmq: bad weight type");
             }
             HIP_CHECK(hipGetLastError());

@@ -10,6 +10,24 @@
 #pragma once
 #include "mmq_dmap.h"
 
+// Ring slot of k_mmq_dma_p8, packed per weight type (mmq_dma.h reserves room for every part in every slot): the X tile, then only
+// the parts the type has.  The 4- and 5-bit types then fit FIVE slots next to the two dequantized W tiles in the CU's
+// 160 KB — four stages in flight instead of three (1.5 us of latency cover at 0.5 us per stage).  Measured: no change
+// (GEMMs 10.8 vs 10.7 ms per batch) — the waits the counters show (profiles/r02_prefill_mmq_p8_pmc.txt: waves spend 47 % of
+// their cycles waiting, matrix pipes busy 26 %) are not DMA landing.  Q8_0 (two quant planes) stays at four.
+template <int QT>
+struct Dma8 {
+    static constexpr int WQ = 16384;
+    static constexpr int WQ2 = WQ + 4096;                                                    // Q8_0 only
+    static constexpr int WH = WQ + 4096;                                                     // Q5 only
+    static constexpr int WD = WQ + 4096 + (QT == QT_Q8_0 ? 4096 : 0) + ((QT == QT_Q5_0 || QT == QT_Q5_1) ? 1024 : 0);
+    static constexpr int WM = WD + 1024;                                                     // Q4_1 / Q5_1 only
+    static constexpr int SLOT = WD + 1024 + ((QT == QT_Q4_1 || QT == QT_Q5_1) ? 1024 : 0);
+    static constexpr int RING = (5 * SLOT + 2 * MMQ_TILEB <= 160 * 1024) ? 5 : 4;
+    static constexpr int WT = RING * SLOT;
+    static constexpr int LDS = WT + 2 * MMQ_TILEB;
+};
+
 template <int QT>
 __device__ __forceinline__ constexpr int dma8_group() {  // DMA instructions per stage and wave: 2 of X + 1 or 2 weight parts
     return QT == QT_Q4_0 ? 3 : 4;
@@ -24,7 +42,8 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
     const int wv = wave & 3;                  // DMA: which quarter of the weight rows this wave requests
     const bool lo = wave < 4;                 // waves 0..3 request the quants, 4..7 the scales (see issue)
     constexpr int G = dma8_group<QT>();
-    constexpr int SLOT = DMA_SLOT, WT = DMA_WT;
+    typedef Dma8<QT> L;
+    constexpr int SLOT = L::SLOT, WT = L::WT, RING = L::RING;
     const int nstage_all = (int)(a.nb >> 1);
     const int per = (nstage_all + splits - 1) / splits;
 
@@ -106,7 +125,7 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
     lane_addr(Ti, Ai);
     auto issue = [&]() {
         const int64_t kb = (int64_t)(Ti.s_begin + is) * 2;  // first block of the stage
-        char *slot = lds + (gi & (DMA_RING - 1)) * SLOT;
+        char *slot = lds + (gi % RING) * SLOT;
 #pragma unroll
         for (int i = 0; i < 2; i++)
             __builtin_amdgcn_global_load_lds((gptr_t)(Ai.xsrc[i] + kb * 64), (lptr_t)(slot + DMA_XS + (16 * wave + 8 * i) * 128), 16, 0, 0);
@@ -114,19 +133,19 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
         // scales.  Every wave issues the same NUMBER of DMAs per stage (the counted waits rely on it): where a type has an
         // odd number of parts the scale waves request the scales twice.
         if (lo) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wq + kb * 16), (lptr_t)(slot + DMA_WQ + wv * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wq + kb * 16), (lptr_t)(slot + L::WQ + wv * 1024), 16, 0, 0);
             if constexpr (QT == QT_Q8_0)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wq2 + kb * 16), (lptr_t)(slot + DMA_WQ2 + wv * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wq2 + kb * 16), (lptr_t)(slot + L::WQ2 + wv * 1024), 16, 0, 0);
             if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wh + kb * 4), (lptr_t)(slot + DMA_WH + wv * 256), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wh + kb * 4), (lptr_t)(slot + L::WH + wv * 256), 4, 0, 0);
             if constexpr (QT == QT_Q4_1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wm_ + kb * 2), (lptr_t)(slot + DMA_WM + wv * 256), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wm_ + kb * 2), (lptr_t)(slot + L::WM + wv * 256), 4, 0, 0);
         } else {
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wd + kb * 2), (lptr_t)(slot + DMA_WD + wv * 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wd + kb * 2), (lptr_t)(slot + L::WD + wv * 256), 4, 0, 0);
             if constexpr (QT == QT_Q5_1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wm_ + kb * 2), (lptr_t)(slot + DMA_WM + wv * 256), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wm_ + kb * 2), (lptr_t)(slot + L::WM + wv * 256), 4, 0, 0);
             if constexpr (QT == QT_Q8_0 || QT == QT_Q5_0 || QT == QT_Q4_1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wd + kb * 2), (lptr_t)(slot + DMA_WD + wv * 256), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ai.wd + kb * 2), (lptr_t)(slot + L::WD + wv * 256), 4, 0, 0);
         }
         gi++;
         if (is + 1 < Ti.nstage) {
@@ -145,16 +164,16 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
     const int wr = bt >> 1, wj = bt & 1;
     const int woff = wr * MMQ_ROWB + wj * 64 + h * 32;
     auto raw_load = [&](int s, u32x4 &q, u32x4 &q2, uint32_t &qh, _Float16 &d, _Float16 &m) {
-        const char *slot = lds + (s & (DMA_RING - 1)) * SLOT;
-        q = *(const u32x4 *)(slot + DMA_WQ + bt * 16);
+        const char *slot = lds + (s % RING) * SLOT;
+        q = *(const u32x4 *)(slot + L::WQ + bt * 16);
         q2 = q;
         qh = 0;
         m = (_Float16)0.0f;
-        if constexpr (QT == QT_Q8_0) q2 = *(const u32x4 *)(slot + DMA_WQ2 + bt * 16);
-        if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) qh = *(const uint32_t *)(slot + DMA_WH + bt * 4);
-        d = *(const _Float16 *)(slot + DMA_WD + (wr >> 5) * 256 + (wr & 31) * 4 + wj * 2);
+        if constexpr (QT == QT_Q8_0) q2 = *(const u32x4 *)(slot + L::WQ2 + bt * 16);
+        if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) qh = *(const uint32_t *)(slot + L::WH + bt * 4);
+        d = *(const _Float16 *)(slot + L::WD + (wr >> 5) * 256 + (wr & 31) * 4 + wj * 2);
         if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1)
-            m = *(const _Float16 *)(slot + DMA_WM + (wr >> 5) * 256 + (wr & 31) * 4 + wj * 2);
+            m = *(const _Float16 *)(slot + L::WM + (wr >> 5) * 256 + (wr & 31) * 4 + wj * 2);
     };
 
     // the thread's two words moved to positions 0, 1 (and the fifth bits of those words to the low bits of each half of
@@ -166,11 +185,10 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
             qh >>= 8;
         }
     };
-    // ---- prologue: groups 0, 1, 2 in flight; global stage 0's weights dequantized into W tile 0
-    issue();
-    issue();
-    issue();
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");  // group 0 landed, every wave's part
+    // ---- prologue: groups 0 .. RING-2 in flight; global stage 0's weights dequantized into W tile 0
+#pragma unroll
+    for (int i = 0; i < RING - 1; i++) issue();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 2) * G) : "memory");  // group 0 landed, every wave's part
     {
         u32x4 q, q2, o[4];
         uint32_t qh;
@@ -201,10 +219,10 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
 #pragma unroll
           for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
       for (int s = 0; s < Tc.nstage; s++, g++) {
-        // group g+1 landed (group g+2 may still be in flight), this wave's W-tile writes of the previous stage done
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
-        issue();  // global stage g+3 into the slot of stage g-1: every wave is past its MFMAs
-        const char *X = lds + (g & (DMA_RING - 1)) * SLOT + DMA_XS;
+        // group g+1 landed (groups g+2 .. g+RING-2 may still be in flight), this wave's W-tile writes of the previous stage done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 3) * G) : "memory");
+        issue();  // global stage g+RING-1 into the slot of stage g-1: every wave is past its MFMAs
+        const char *X = lds + (g % RING) * SLOT + DMA_XS;
         const char *W = lds + WT + (g & 1) * MMQ_TILEB;
         char *Wn = lds + WT + ((g + 1) & 1) * MMQ_TILEB;
         u32x4 q, q2;
@@ -213,7 +231,10 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
         raw_load(g + 1, q, q2, qh, d, m);  // stage g+1: the next item's first stage at an item boundary
         take_half(q, q2, qh);
         const f16x2 dd = {d, d}, mm = {m, m};
-        f16x8 fa[2], fb[2][2];
+        // fragments are requested TWO k-steps ahead of the MFMAs that use them (all four k-steps have their own registers).
+        // Measured against one step of lookahead: no difference (11.1 vs 10.8 ms per batch on different boxes, the 4-wave
+        // kernel moved by the same 2 %) — the LDS round trip in front of a k-step is covered by the SIMD's other wave
+        f16x8 fa[4], fb[4][2];
         auto xfrag = [&](int ks) {
             const int R = wn * 32 + frow_x;
             const int p = (ks * 2 + fh) ^ ((R >> 1) & 7);
@@ -222,23 +243,26 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
         auto wfrag = [&](int i, int ks) {
             return *(const f16x8 *)(W + (wm * 64 + i * 32 + frow_x) * MMQ_ROWB + ks * 32 + fh * 16);
         };
-        fa[0] = xfrag(0);
 #pragma unroll
-        for (int i = 0; i < 2; i++) fb[0][i] = wfrag(i, 0);
+        for (int ks = 0; ks < 2; ks++) {
+            fa[ks] = xfrag(ks);
+#pragma unroll
+            for (int i = 0; i < 2; i++) fb[ks][i] = wfrag(i, ks);
+        }
         __builtin_amdgcn_sched_barrier(0);
         u32x4 o;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; t2++) {
-                const int cb = ks & 1, nb2 = cb ^ 1, idx = ks * 2 + t2;  // idx 0..7: slice idx & 3 of the thread's word idx >> 2
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cb], fb[cb][t2], acc[t2], 0, 0, 0);
-                if (ks < 3) {
+                const int idx = ks * 2 + t2;  // idx 0..7: slice idx & 3 of the thread's word idx >> 2
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks][t2], acc[t2], 0, 0, 0);
+                if (ks < 2) {
                     if (t2 == 0) {
-                        fa[nb2] = xfrag(ks + 1);
-                        fb[nb2][0] = wfrag(0, ks + 1);
+                        fa[ks + 2] = xfrag(ks + 2);
+                        fb[ks + 2][0] = wfrag(0, ks + 2);
                     } else {
-                        fb[nb2][1] = wfrag(1, ks + 1);
+                        fb[ks + 2][1] = wfrag(1, ks + 2);
                     }
                 }
                 o[idx & 3] = mmq_dequant_slice<QT>(q, q2, qh, idx >> 2, idx & 3, dd, mm);
