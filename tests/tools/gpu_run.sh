@@ -2,14 +2,17 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_prompt_plan_gpu.py tests/test_ops_gpu.py -q -x 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl" | tail -25 > gpurun_out/r02_pytest_prompt.txt
-tail -6 gpurun_out/r02_pytest_prompt.txt
-for w in 8 4; do
-GGML_HIP_MMQ_WAVES=$w timeout 300 python bench.py --mode prefill --weights blocks --no-cpu-baseline > gpurun_out/r02_prefill_w$w.json 2> gpurun_out/r02_prefill_w$w.err
+timeout 400 python bench.py --model 13b --wtype q5_1 --weights blocks --no-cpu-baseline > gpurun_out/r02_bench_13b_q5_1.json 2> gpurun_out/err13.txt
+timeout 600 python bench.py --model 65b --wtype q8_0 --weights blocks --no-cpu-baseline --steps 32 --prefill-steps 2 > gpurun_out/r02_bench_65b_q8_0.json 2> gpurun_out/err65.txt
+timeout 300 python bench.py --model 7b --wtype q8_0 --weights blocks --no-cpu-baseline > gpurun_out/r02_bench_7b_q8_0.json 2> gpurun_out/err7.txt
 python - <<PY
 import json
-d=json.loads(open("gpurun_out/r02_prefill_w$w.json").read().strip().splitlines()[-1])
-print("waves=$w:", d["value"], d["unit"], d["ms_per_step"], "ms/step", json.dumps(d["roofline"].get("class_ms_per_step", d["config"].get("class_ms_per_step"))), d["roofline"]["frac"])
+for f in ("r02_bench_13b_q5_1","r02_bench_65b_q8_0","r02_bench_7b_q8_0"):
+    try:
+        d=json.loads(open("gpurun_out/%s.json"%f).read().strip().splitlines()[-1])
+        pf=d["config"].get("prefill") or {}
+        print(f, d["value"], "tok/s", d["ms_per_step"], "ms; w1|w3 frac", d["roofline"]["frac"], "all-matvec frac", d["roofline"]["all_matvecs_per_token"]["frac"], "| prefill", pf.get("tokens_per_s"), pf.get("ms_per_step"), (pf.get("roofline") or {}).get("frac"))
+    except Exception as e:
+        print(f, "failed", e)
 PY
-done
+tail -3 gpurun_out/err65.txt
