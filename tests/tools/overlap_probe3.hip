@@ -37,6 +37,14 @@ __global__ __launch_bounds__(1024) void k_link(Chain c, int k) {
     u32x4 r[PFN];
 #pragma unroll
     for (int i = 0; i < PFN; i++) r[i] = __builtin_nontemporal_load(w + i * 1024);
+    // WHERE == 2: translation warm-up only — the first workgroup of every XCD touches one word per 2 MB of the NEXT link's
+    // weights right after its own first requests (no data is prefetched; the loads hide under the stream)
+    unsigned tlb = 0;
+    if (WHERE == 2 && blockIdx.x < 8) {
+        const size_t region_bytes = c.region * 16, page = (size_t)2 << 20;
+        const char *nb = (const char *)(c.w + (size_t)((k + 1) % c.nreg) * c.region);
+        for (size_t off = (size_t)tid * page; off < region_bytes; off += (size_t)1024 * page) tlb += *(const unsigned *)(nb + off);
+    }
     const f32x4 *xp = (const f32x4 *)(c.act + (size_t)k * XN) + tid;
     f32x4 xv = *xp;
     ((f32x4 *)s_x)[tid] = xv;
@@ -58,10 +66,11 @@ __global__ __launch_bounds__(1024) void k_link(Chain c, int k) {
 #pragma unroll
         for (int j = 0; j < PF; j++) p[j] = wn[j * 1024];
     }
-    if (PF > 0) {
+    if (PF > 0 && WHERE != 2) {
 #pragma unroll
         for (int j = 0; j < PF; j++) acc += p[j][0] & 1u;
     }
+    acc += tlb & 1u;
     c.sink[blockIdx.x * 1024 + tid] = acc;
     float v = s_x[(tid * 5) & (XN - 1)] + 1.0f + (acc == 0x12345u ? 1.0f : 0.0f);
     if (tid < XN / W) c.act[(size_t)(k + 1) * XN + blockIdx.x * (XN / W) + tid] = v;
@@ -108,6 +117,7 @@ int main() {
         run<3, 0>("P3 next link's steps 0-2, under the tail", c, W, L, s);
         run<3, 1>("P3 next link's steps 0-2, after the last dot", c, W, L, s);
         run<6, 0>("P6 next link's steps 0-5, under the tail", c, W, L, s);
+        run<1, 2>("T  translations of the next link only", c, W, L, s);
     }
     return 0;
 }
