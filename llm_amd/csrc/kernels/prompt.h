@@ -272,12 +272,16 @@ __global__ void __launch_bounds__(256) k_p_soft_max(float *x, int64_t rows, int 
     _Float16 *p16 = y16 ? y16 + row * ld16 : nullptr;
     const int lim = n_past + (int)(row % nr);  // columns > lim are masked
     if (nc <= 512) {  // the whole row in registers: one read, one write (8 independent loads per lane; pairing adjacent
-                      // columns per lane for 4-byte f16 stores was measured slower: 27 vs 23 us)
+                      // columns per lane for 4-byte f16 stores was measured slower: 27 vs 23 us).  The kernel is VALU-bound
+                      // (expf, f16 round trips and f64 adds per element), and under the causal mask half of the 64-column
+                      // chunks of a batch are masked entirely: those are skipped with a wave-uniform branch (zeros stored).
+        const int ulim = __builtin_amdgcn_readfirstlane(lim);  // one row per wave: uniform
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int i = lane + 64 * u;
-            v[u] = (i < nc && i <= lim) ? p[i] : 0.0f;
+            v[u] = 0.0f;
+            if (64 * u <= ulim) v[u] = (i < nc && i <= lim) ? p[i] : 0.0f;
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -291,9 +295,11 @@ __global__ void __launch_bounds__(256) k_p_soft_max(float *x, int64_t rows, int 
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             float e = 0.0f;
-            if (v[u] != -INFINITY) {
-                e = round_f16(expf(round_f16(v[u] - mx)));
-                sum += (double)e;
+            if (64 * u <= ulim) {
+                if (v[u] != -INFINITY) {
+                    e = round_f16(expf(round_f16(v[u] - mx)));
+                    sum += (double)e;
+                }
             }
             v[u] = e;
         }
