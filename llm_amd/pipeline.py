@@ -293,7 +293,7 @@ def run_bench(args):
                "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} greedy decode, layer split over "
                                       f"{world} GPUs ({le - lb} layers/GPU), {n_seq} sequences in flight (one per stage), "
                                       f"{args.prompt}-token prompts, ctx {ctx}, f16 KV",
-                          "parallelism": f"pp{world} layer split, RCCL send/recv of the residual",
+                          "parallelism": f"pp{world} layer split, residual hop: " + ("RCCL send/recv inside the library" if use_rccl else "host copies over gloo (fewer GPUs than ranks)"),
                           "sequences_in_flight": n_seq,
                           "single_stream_tokens_per_s": round(args.steps / elapsed, 2),
                           "comm_backend": backend, "comm_ranks_seen_by_rccl": comm_ranks},
