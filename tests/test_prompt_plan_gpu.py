@@ -149,3 +149,31 @@ def test_persistent_gemm_is_bit_identical_to_one_workgroup_per_tile(G, wtype, cf
                 assert np.array_equal(la, lb), (cfg, wtype, plan, variant, float(np.max(np.abs(la - lb))))
             assert np.array_equal(ka, kb) and np.array_equal(va, vb)
     model.free()
+
+
+@pytest.mark.parametrize("wtype", [2, 7])
+def test_prompt_plan_rows_longer_than_512_positions(G, wtype):
+    """Score rows of more than 512 positions take the softmax kernel's multi-pass branch (row not held in registers), the
+    attention GEMMs see several key tiles with the causal skip active at n_past > 0, and a 500-token batch has a ragged
+    last token tile: still bit-identical to the node-by-node executor."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(GQA, wtype, seed=13)
+    model = llama.Llama(hp, w, context_size=1024)
+    toks = np.random.default_rng([wtype, 99]).integers(0, hp["n_vocab"], 900).astype(np.int32)
+    chunks = [toks[0:64], toks[64:564], toks[564:764], toks[764:900]]  # T = 64, 564, 764, 900
+
+    def run(plan):
+        G.set_option("plan_prompt", plan)
+        sess = model.start_session(n_batch=512)
+        outs = [sess.evaluate(c) for c in chunks]
+        k, v = sess.get_kv()
+        sess.free()
+        G.set_option("plan_prompt", 1)
+        return outs, k, v
+
+    a, ka, va = run(1)
+    b, kb, vb = run(0)
+    for i, (la, lb) in enumerate(zip(a, b)):
+        assert np.array_equal(la, lb), (wtype, i, float(np.max(np.abs(la - lb))))
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    model.free()
