@@ -35,6 +35,7 @@
 #include "kernels/mmq_dma.h"
 #include "kernels/mmq_dmap.h"
 #include "kernels/mmq_dmap8.h"
+#include "kernels/mmq_w16.h"
 #include "kernels/mmq_i8.h"
 #include "kernels/kquant.h"
 #include "kernels/quantize.h"
@@ -98,6 +99,7 @@ struct DevTensor {
     bool zero_filled = false;     // created by assign_buffers_no_scratch (mutable state: never shared)
     uintptr_t owner_hdr = 0;      // auto-uploaded only: address of the ggml_tensor header that named this data
     QWeight qw{};
+    char *w16 = nullptr;          // resident f16 copy of a quantized weight for the prompt GEMM (ensure_w16); qw.w16 names it
     bool ksoa = false;            // K-quant planar layout (see KWeight, kernels/kquant.h)
     KWeight kw{};
     ggml_type type = GGML_TYPE_F32;
@@ -145,6 +147,8 @@ struct Backend {
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
     int opt_plan_prompt = 1; // fused plan for prompt batches of >= mmq_min tokens (kernels/prompt.h)
     int opt_mmq_persist = 1; // prompt GEMM as a persistent kernel (kernels/mmq_dmap.h)
+    int opt_mmq_w16 = 1;     // prompt GEMM on resident f16 copies of the quantized weights when HBM has room (kernels/mmq_w16.h)
+    size_t w16_bytes = 0;    // HBM held by those copies
     int opt_mmq_waves = 8;   // waves per workgroup of the persistent prompt GEMM: 4 (mmq_dmap.h) or 8 (mmq_dmap8.h)
     int opt_mmq_fuse = 3;    // prompt plan: wq|wk|wv (bit 0) and w1|w3 (bit 1) as one GEMM launch each
     int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
@@ -212,6 +216,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_MMQ_FUSE")) g.opt_mmq_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_PERSIST")) g.opt_mmq_persist = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_WAVES")) g.opt_mmq_waves = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_W16")) g.opt_mmq_w16 = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_I8")) g.opt_mmq_i8 = atoi(v);
@@ -550,6 +555,7 @@ QWeight qw_at(char *base, int qt, int64_t M, int64_t nb) {
     w.M = M;
     w.nb = nb;
     w.qt = qt;
+    w.w16 = nullptr;
     return w;
 }
 
@@ -681,6 +687,10 @@ void destroy_record(DevTensor *e) {
     drop_all_plans();  // cached decode plans hold device addresses of weight / KV records
     if (g.stream) HIP_CHECK(hipStreamSynchronize(g.stream));
     if (e->dev) HIP_CHECK(hipFree(e->dev));
+    if (e->w16) {
+        HIP_CHECK(hipFree(e->w16));
+        g.w16_bytes -= (size_t)e->qw.M * e->qw.nb * 64;
+    }
     e->magic = 0;
     delete e;
 }
@@ -984,6 +994,35 @@ void mul_mat_k(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *ds
     }
 }
 
+// Resident f16 copy of a quantized weight (kernels/mmq_w16.h): created on first use by a prompt plan, kept until the
+// weight's record dies.  Returns false (and the GEMM dequantizes in LDS as before) when the option is off, K / 32 is odd,
+// or HBM would be left with less than 16 GB after the allocation.
+bool ensure_w16(DevTensor *e) {
+    if (!e || !e->soa || !g.opt_mmq_w16 || e->qw.nb % 2 != 0) return false;
+    if (e->w16) return true;
+    const size_t bytes = (size_t)e->qw.M * e->qw.nb * 64;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)16 << 30)) return false;
+    if (hipMalloc((void **)&e->w16, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        e->w16 = nullptr;
+        return false;
+    }
+    g.w16_bytes += bytes;
+    const unsigned nblk = (unsigned)((e->qw.M * e->qw.nb + 255) / 256);
+    switch (e->qw.qt) {
+        case QT_Q4_0: hipLaunchKernelGGL(k_dequant_w16<QT_Q4_0>, dim3(nblk), dim3(256), 0, g.stream, e->qw, (_Float16 *)e->w16); break;
+        case QT_Q4_1: hipLaunchKernelGGL(k_dequant_w16<QT_Q4_1>, dim3(nblk), dim3(256), 0, g.stream, e->qw, (_Float16 *)e->w16); break;
+        case QT_Q5_0: hipLaunchKernelGGL(k_dequant_w16<QT_Q5_0>, dim3(nblk), dim3(256), 0, g.stream, e->qw, (_Float16 *)e->w16); break;
+        case QT_Q5_1: hipLaunchKernelGGL(k_dequant_w16<QT_Q5_1>, dim3(nblk), dim3(256), 0, g.stream, e->qw, (_Float16 *)e->w16); break;
+        case QT_Q8_0: hipLaunchKernelGGL(k_dequant_w16<QT_Q8_0>, dim3(nblk), dim3(256), 0, g.stream, e->qw, (_Float16 *)e->w16); break;
+        default: die("w16: bad weight type");
+    }
+    HIP_CHECK(hipGetLastError());
+    e->qw.w16 = e->w16;
+    return true;
+}
+
 // The default prompt GEMM launch (f16 matrix cores, k_mmq_dma / k_mmq): x16 (or x8 + dx for option mmq_dma = 2) are the
 // activations after the Q8 pre-pass; dst[n * ldd + m].  Shared by the generic executor and the fused prompt plan.
 // nseg > 1: up to three matrices with the same K in one launch (MmqArgs: nseg); `splits` 0 = chosen here.
@@ -1051,6 +1090,18 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
         }
         const int tiles_total = tiles_m * a.tiles_n, n_items = tiles_total * splits;
         const dim3 pgrid((unsigned)std::min(n_items, g.num_cus));
+        bool all_w16 = g.opt_mmq_w16 != 0;
+        for (int i = 0; i < nseg; i++) all_w16 = all_w16 && segs[i].w.w16 != nullptr;
+        if (all_w16) {  // both operands by DMA from resident f16 copies (kernels/mmq_w16.h)
+            static bool w16_attr_set = false;
+            if (!w16_attr_set) {
+                HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_p8, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS));
+                w16_attr_set = true;
+            }
+            hipLaunchKernelGGL(k_mmq_w16_p8, pgrid, dim3(512), W16_LDS, g.stream, a, n_items, tiles_total, splits);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         if (g.opt_mmq_waves == 8) {  // two waves per SIMD on the same tile (kernels/mmq_dmap8.h)
             static bool p8_attr_set = false;
             if (!p8_attr_set) {
@@ -2201,6 +2252,10 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_mmq_persist = value;
     else if (k == "mmq_waves")
         g.opt_mmq_waves = value;
+    else if (k == "mmq_w16") {
+        if (g.opt_mmq_w16 != value) drop_all_plans();
+        g.opt_mmq_w16 = value;
+    }
     else if (k == "plan_prompt") {
         if (g.opt_plan_prompt != value) drop_all_plans();
         g.opt_plan_prompt = value;
@@ -2502,6 +2557,7 @@ int64_t ggml_hip_get_stat(const char *key) {
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     const std::string k(key);
     if (k == "attn_split_tokens") return (int64_t)g.stat_split_tokens;  // tokens whose attention ran split over positions
+    if (k == "w16_bytes") return (int64_t)g.w16_bytes;  // HBM held by resident f16 weight copies
     if (k == "prompt_plan_tokens") return (int64_t)g.stat_prompt_plan_tokens;  // tokens executed by the fused prompt plan
     if (k == "plan_tokens") return (int64_t)g.stat_plan_tokens;       // tokens executed by the fused decode plan
     if (k == "graph_replays") {

@@ -43,6 +43,7 @@ struct QWeight {
     int64_t M;   // rows (ne1)
     int64_t nb;  // blocks per row (ne0/32)
     int qt;
+    const void *w16;  // optional resident f16 copy [M][nb * 32] for the prompt GEMM (kernels/mmq_w16.h); nullptr = none
 };
 
 // Activations re-quantized to the weight type's vec_dot_type (Q8_0 / Q8_1 semantics of ggml), in a

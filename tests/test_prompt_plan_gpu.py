@@ -177,3 +177,32 @@ def test_prompt_plan_rows_longer_than_512_positions(G, wtype):
         assert np.array_equal(la, lb), (wtype, i, float(np.max(np.abs(la - lb))))
     assert np.array_equal(ka, kb) and np.array_equal(va, vb)
     model.free()
+
+
+@pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
+@pytest.mark.parametrize("cfg", ["wide", "splitk", "tiny"])
+def test_gemm_on_resident_f16_weight_copies_is_bit_identical(G, wtype, cfg):
+    """k_mmq_w16_p8 (both operands by LDS-DMA from an f16 copy of the weights made once, kernels/mmq_w16.h) against the
+    kernels that dequantize the blocks in LDS: the same f16 values in the same MFMA sequence, so the same bits.  The
+    copies exist only where K / 32 is even (tiny: w2 keeps dequantizing) and are released with the model."""
+    from llm_amd import llama, synth
+    if cfg == "splitk" and wtype not in (2, 7):
+        pytest.skip("two formats for the K-split shapes")
+    hp, w = synth.make_llama({"wide": WIDE, "splitk": SPLITK, "tiny": synth.TINY}[cfg], wtype, seed=8)
+    toks = np.random.default_rng([wtype, 17]).integers(0, hp["n_vocab"], 300).astype(np.int32)
+    chunks = [toks[0:48], toks[48:200], toks[200:300]]
+    res = {}
+    for w16 in (1, 0):
+        G.set_option("mmq_w16", w16)
+        b0 = _stat(G, "w16_bytes")
+        model = llama.Llama(hp, w, context_size=512)
+        res[w16] = _run(G, model, chunks, 1)
+        held = _stat(G, "w16_bytes") - b0
+        assert (held > 0) == bool(w16), (w16, held)
+        model.free()
+        assert _stat(G, "w16_bytes") == b0  # released with the weights
+    G.set_option("mmq_w16", 1)
+    (a, ka, va), (b, kb, vb) = res[1], res[0]
+    for la, lb in zip(a, b):
+        assert np.array_equal(la, lb), (cfg, wtype, float(np.max(np.abs(la - lb))))
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
