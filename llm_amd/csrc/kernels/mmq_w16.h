@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_dequant_w16(const QWeight w, _Float16 *
 #define W16_X 0
 #define W16_W 16384
 #define W16_SLOT 32768
-#define W16_RING 4
+#define W16_RING 5  /* 5 x 32 KB = the CU's whole 160 KB */
 #define W16_LDS (W16_RING * W16_SLOT)
 
 // MmqArgs: w.w16 / wb.w16 / wc.w16 hold the f16 copies ([M][nb * 32] f16, k permuted inside each block like the activations)
@@ -145,6 +145,16 @@ __global__ void __launch_bounds__(512, 1) k_mmq_w16_p8(const MmqArgs a, int n_it
         return *(const f16x8 *)(T + R * 128 + p * 16);
     };
     const int Rx = wn * 32 + frow_x, Rw0 = wm * 64 + frow_x, Rw1 = wm * 64 + 32 + frow_x;
+    // Fragments of the first two k-steps of a stage are requested at the END of the stage before it (the wait at the
+    // top of a stage retires the DMA group of the NEXT stage too), so the first MFMA after a barrier never waits for LDS.
+    f16x8 fa[4], fb[4][2];
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 2) * G) : "memory");  // group 0 landed, every wave's part
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        fa[ks] = frag(lds + W16_X, Rx, ks);
+        fb[ks][0] = frag(lds + W16_W, Rw0, ks);
+        fb[ks][1] = frag(lds + W16_W, Rw1, ks);
+    }
     int g = 0;
     for (int cw = (int)blockIdx.x; cw < n_items; cw += (int)gridDim.x) {
       Item Tc;
@@ -155,18 +165,12 @@ __global__ void __launch_bounds__(512, 1) k_mmq_w16_p8(const MmqArgs a, int n_it
 #pragma unroll
           for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
       for (int s = 0; s < Tc.nstage; s++, g++) {
-        // group g landed (groups g+1 .. g+RING-2 may still be in flight); every wave is past the MFMAs of stage g-1
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 2) * G) : "memory");
+        // group g+1 landed (groups g+2 .. g+RING-2 may still be in flight); every wave is past its LDS reads of stage g-1
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 3) * G) : "memory");
         issue();  // global stage g+RING-1 into the slot of stage g-1
         const char *X = lds + (g % RING) * SLOT + W16_X, *W = lds + (g % RING) * SLOT + W16_W;
-        f16x8 fa[4], fb[4][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            fa[ks] = frag(X, Rx, ks);
-            fb[ks][0] = frag(W, Rw0, ks);
-            fb[ks][1] = frag(W, Rw1, ks);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        const char *Xn = lds + ((g + 1) % RING) * SLOT + W16_X, *Wn = lds + ((g + 1) % RING) * SLOT + W16_W;
+        f16x8 na[2], nb_[2][2];  // the next stage's first two k-steps
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
 #pragma unroll
@@ -179,9 +183,22 @@ __global__ void __launch_bounds__(512, 1) k_mmq_w16_p8(const MmqArgs a, int n_it
                     } else {
                         fb[ks + 2][1] = frag(W, Rw1, ks + 2);
                     }
+                } else {
+                    if (t2 == 0) {
+                        na[ks - 2] = frag(Xn, Rx, ks - 2);
+                        nb_[ks - 2][0] = frag(Wn, Rw0, ks - 2);
+                    } else {
+                        nb_[ks - 2][1] = frag(Wn, Rw1, ks - 2);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            fa[ks] = na[ks];
+            fb[ks][0] = nb_[ks][0];
+            fb[ks][1] = nb_[ks][1];
         }
       }
 #pragma unroll

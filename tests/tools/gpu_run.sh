@@ -2,13 +2,14 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_prompt_plan_gpu.py -q -x 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl" | tail -15
-for w in 1 0; do
-GGML_HIP_MMQ_W16=$w timeout 300 python bench.py --mode prefill --weights blocks --no-cpu-baseline > gpurun_out/r02_prefill_w16_$w.json 2> gpurun_out/r02_prefill_w16_$w.err
-python - <<PY
-import json
-d=json.loads(open("gpurun_out/r02_prefill_w16_$w.json").read().strip().splitlines()[-1])
-print("w16=$w:", d["value"], d["unit"], d["ms_per_step"], "ms/step", json.dumps(d["roofline"].get("class_ms_per_step", d["config"].get("class_ms_per_step"))), d["roofline"]["frac"])
-PY
-tail -2 gpurun_out/r02_prefill_w16_$w.err
-done
+R=$GRAFT_REPO_ROOT
+cd /tmp
+rm -rf /tmp/pmc_g /tmp/pmc_g2
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d /tmp/pmc_g -o g -- python $R/bench.py --mode prefill --steps 1 --warmup 1 --weights blocks --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM --kernel-trace -d /tmp/pmc_g2 -o g -- python $R/bench.py --mode prefill --steps 1 --warmup 1 --weights blocks --no-cpu-baseline > /dev/null 2>&1
+cd $R
+O=gpurun_out/r02_prefill_mmq_w16_pmc.txt
+echo "# rocprofv3 --pmc (two passes) --kernel-trace -- python bench.py --mode prefill --steps 1 --warmup 1 --weights blocks   (round 2; k_mmq_w16_p8, LLaMA-7B Q4_0, 512-token batch); per-dispatch averages over counter instances" > $O
+python tests/tools/pmc_kernel.py /tmp/pmc_g '%k_mmq_w16_p8%' >> $O 2>&1
+python tests/tools/pmc_kernel.py /tmp/pmc_g2 '%k_mmq_w16_p8%' >> $O 2>&1
+cat $O
