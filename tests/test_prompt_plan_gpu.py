@@ -206,3 +206,36 @@ def test_gemm_on_resident_f16_weight_copies_is_bit_identical(G, wtype, cfg):
     for la, lb in zip(a, b):
         assert np.array_equal(la, lb), (cfg, wtype, float(np.max(np.abs(la - lb))))
     assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+
+
+def test_prompt_plan_with_a_k_split_on_wk_wv_only(G):
+    """LLaMA-2-70B-like attention shape (8192-wide, 64 heads, 8 K/V heads): at 512 tokens wq has 256 tiles and runs
+    unsplit while wk / wv have 32 each and split K — the three cannot share a launch, and the kernel that consumes q | k | v
+    adds two partials for all of them or for none: wq's second partial is zero-filled.  Bit-identical to the node-by-node
+    executor (which splits exactly the same matrices, through atomics)."""
+    from llm_amd import llama, synth
+    hp0 = dict(n_vocab=256, n_embd=8192, n_head=64, n_head_kv=8, n_layer=1, n_rot=128, n_ff=1024, n_mult=32)
+    hp, w = synth.make_llama_fast(hp0, G.TYPE_Q4_0, seed=21)
+    model = llama.Llama(hp, w, context_size=1024)
+    toks = np.random.default_rng(77).integers(0, hp["n_vocab"], 600).astype(np.int32)
+    chunks = [toks[0:512], toks[512:600]]
+
+    def run(plan):
+        G.set_option("plan_prompt", plan)
+        sess = model.start_session(n_batch=512)
+        outs = []
+        for c in chunks:
+            p0 = _stat(G, "prompt_plan_tokens")
+            outs.append(sess.evaluate(c))
+            assert _stat(G, "prompt_plan_tokens") - p0 == (len(c) if plan else 0)
+        k, v = sess.get_kv()
+        sess.free()
+        G.set_option("plan_prompt", 1)
+        return outs, k, v
+
+    a, ka, va = run(1)
+    b, kb, vb = run(0)
+    for la, lb in zip(a, b):
+        assert np.isfinite(la).all() and np.array_equal(la, lb), float(np.max(np.abs(la - lb)))
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    model.free()
