@@ -15,20 +15,6 @@
 #include "mmq.h"
 #include "ops.h"
 
-// the Q8_0 / Q8_1 re-quantization of one value inside its 32-wide block, as k_quant_act_f16: lanes 32k..32k+31 hold a block
-template <bool F16_D>
-__device__ __forceinline__ _Float16 p_requant(float v) {
-    float amax = fabsf(v);
-    amax = g32_max_f32(amax);
-    float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int q = (int)roundf(v * id);
-    if (F16_D) d = round_f16(d);
-    float r = d * (float)q;
-    r = fminf(fmaxf(r, -65504.0f), 65504.0f);
-    return (_Float16)r;
-}
-
 template <bool F16_D>
 __device__ __forceinline__ void p_requant4_store(const f32x4 v, int64_t i4, bool valid, _Float16 *__restrict__ out);
 
