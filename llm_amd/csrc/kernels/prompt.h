@@ -1,13 +1,17 @@
 // prompt.h — the element-wise kernels of the fused PROMPT plan (llama_plan.inc plan_launch_prompt): a prompt batch of
 // N >= 32 tokens through the LLaMA graph of crates/models/llama/src/lib.rs:166-362 with the quantized GEMMs on the
-// matrix cores (mmq_dma.h) and everything between two GEMMs in ONE launch instead of 2-4 generic ones (ops.h):
+// matrix cores (mmq_w16.h / mmq_dmap8.h) and everything between two GEMMs in ONE launch instead of 2-4 generic ones (ops.h):
 //
 //   k_p_norm_quant     [residual add ->] rms_norm -> x weight -> Q8 re-quantization -> f16(d*q) in the GEMM's k order
 //                      (replaces k_bin4<ADD>, k_rms_norm<true>, k_quant_act_f16; lib.rs:183-186, 310-320, 343-347)
 //   k_p_qkv_post       RoPE of Q in place, RoPE of K -> f16 -> memory_k, V -> f16 -> memory_v transposed
 //                      (replaces 2 x k_rope, 2 x k_cpy<float, half>; lib.rs:191-244)
 //   k_p_silu_mul_quant silu(w1 x) * (w3 x) -> Q8 re-quantization -> f16(d*q)   (k_unary4 + k_quant_act_f16; lib.rs:322-330)
-//   k_p_soft_max       scale -> causal mask -> softmax of a row of scores, one wave per row (k_soft_max<true>; lib.rs:268-281)
+//   k_p_quant4         merged attention output -> Q8 re-quantization -> f16(d*q)  (k_quant_act_f16, four values per lane)
+//   k_p_soft_max       scale -> causal mask -> softmax of a row of scores, one wave per row, probabilities written as the
+//                      f16 the V.P product converts them to anyway (k_soft_max<true>; lib.rs:268-281)
+// A GEMM that splits K hands over two partial tiles; the kernel consuming them adds the two (what the atomics of the
+// node-by-node path add), so neither a memset nor atomics are needed.
 //
 // Every kernel performs the generic kernels' f32/f64 operations in the same order on the same values, so the plan's
 // results are bit-identical to the node-by-node executor's (tests/test_prompt_plan_gpu.py compares logits and K/V).
