@@ -151,8 +151,8 @@ _Static_assert(sizeof(block_q8_1) == 40, "q8_1");
 enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9,
        T_Q4_K = 12, T_Q6_K = 14, T_Q8_K = 15 };
 
-/* ---- K-quants (k_quants.c upstream): groundwork for the next step after the path — the oracle side
- * only; the product aborts on these types.  Struct layouts ARE in tree (bindgen: crates/ggml/sys/src/lib.rs:3103-3108,
+/* ---- K-quants (k_quants.c upstream): the checker of the product's Q4_K / Q6_K mat-vec and get_rows
+ * (llm_amd/csrc/kernels/kquant.h, tests/test_kquant_gpu.py).  Struct layouts ARE in tree (bindgen: crates/ggml/sys/src/lib.rs:3103-3108,
  * 3240-3245, 3303-3307, sizes 144 / 210 / 292 asserted at :3115, :3252, :3314; QK_K = 256, K_SCALE_SIZE = 12 at
  * :31-32); the arithmetic (scale packing, dequantization, the q8_K dot products) is restated from memory of upstream
  * like everything else here.  The ENCODERS for Q4_K / Q6_K below are plain min/max and abs-max fits, NOT upstream's
