@@ -73,6 +73,17 @@ def test_product_quantizer_matches_oracle_bytes_and_hist(G, O, t):
     assert np.array_equal(h1, h2) and h1.sum() == x.size
 
 
+def test_all_zero_block_keeps_the_sign_ggml_gives_its_scale(G, O):
+    """d = max / -8 (Q4_0) and max / -16 (Q5_0) of an all-zero block is -0.0, stored as f16 0x8000; Q8_0 (amax / 127)
+    and the min/max types store +0.  The host quantizer, the oracle and (tests/test_device_tools_gpu.py) the device
+    quantizer agree byte for byte — hipcc folds `x * c -> f16` into v_fma_mixlo_f16 x, c, +0, which would lose that sign."""
+    z = np.zeros((1, 32), np.float32)
+    for t, d_bytes in ((2, (0x00, 0x80)), (6, (0x00, 0x80)), (8, (0x00, 0x00)), (3, (0x00, 0x00)), (7, (0x00, 0x00))):
+        b = G.quantize(t, z)
+        assert tuple(int(v) for v in b[:2]) == d_bytes, (t, b[:2])
+        assert np.array_equal(b, O.quantize(t, z))
+
+
 @pytest.mark.parametrize("t", [2, 7])
 def test_product_quantizer_large_tensor_threaded_equals_serial(G, O, t):
     """Above 2^15 blocks ggml_quantize_q* cuts the tensor over threads: bytes and histogram must not
