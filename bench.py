@@ -30,13 +30,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=128, help="timed decode tokens (BASELINE.md section 3: 128)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "65b", "tiny"])
     ap.add_argument("--wtype", default="q4_0", choices=["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_k", "q6_k"])
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the token after the timed loop")
     ap.add_argument("--roofline-steps", type=int, default=20)
     ap.add_argument("--mode", default="decode", choices=["decode", "prefill"],
                     help="decode = BASELINE configs[1] (the metric); prefill = configs[2], 512-token prompt batch on MFMA")
@@ -108,7 +109,72 @@ def cpu_baseline(args, hp, w, budget_s):
                     "ggml's hand-written AVX2 kernels"}
 
 
-def prefill_leg(L, ggml, model, hp, n, steps, warmup):
+MMQ_KERNELS = (  # stat key suffix -> what the launch is (ggml_hip_get_stat("mmq_launches_<key>"))
+    ("w16_256", "k_mmq_w16_256 (persistent 256x256x64 f16 GEMM, 8 waves in two staggered groups, both operands by LDS-DMA from "
+                "resident f16 copies of the quantized weights, v_mfma_f32_32x32x16_f16)"),
+    ("w16_p8", "k_mmq_w16_p8 (persistent 128x128x64 f16 GEMM, 8 waves, both operands by LDS-DMA from resident f16 copies of the "
+               "quantized weights, v_mfma_f32_32x32x16_f16)"),
+    ("dma_p8", "k_mmq_dma_p8 (persistent 128x128x64 GEMM, 8 waves, quantized blocks by LDS-DMA, in-LDS dequant to f16, "
+               "v_mfma_f32_32x32x16_f16)"),
+    ("dma_p", "k_mmq_dma_p (persistent 128x128x64 GEMM, 4 waves, in-LDS dequant to f16)"),
+    ("dma", "k_mmq_dma (one workgroup per tile, in-LDS dequant to f16)"),
+    ("plain", "k_mmq (register-staged, in-LDS dequant to f16)"),
+    ("i8", "k_mmq_i8 (integer MFMA, exact block dots)"),
+)
+
+
+def mmq_counts(L):
+    return {k: int(L.ggml_hip_get_stat(("mmq_launches_" + k).encode())) for k, _ in MMQ_KERNELS}
+
+
+def mmq_label(before, after):
+    """Names the prompt-GEMM kernels that actually ran between two mmq_counts() snapshots, most launches first."""
+    d = {k: after[k] - before[k] for k in after}
+    ran = sorted((k for k in d if d[k] > 0), key=lambda k: -d[k])
+    names = dict(MMQ_KERNELS)
+    return "; ".join(f"{d[k]} x {names[k]}" for k in ran) or "none", d
+
+
+PARITY_EDGE = 4e-2  # tests/test_llama_gpu.py EDGE: one int8 activation quant on a rounding edge (DESIGN.md section 5)
+
+
+def parity_check(args, hp, w, sess):
+    """The token the timed loop would evaluate next, evaluated by the device AND by the CPU oracle (mode 0 = ggml's scalar
+    path) from the same K/V state: the session's K/V cache (what the timed steps wrote) is copied into the oracle, both
+    evaluate argmax(last logits) at the session's n_past.  The run fails if the logits differ by more than PARITY_EDGE
+    standard deviations.  The oracle is the checker here, never the thing measured."""
+    from oracle import oracle
+    ctx = sess.model.context_size
+    n_past = sess.n_past
+    tok = np.array([int(np.argmax(sess.last_logits()))], np.int32)
+    k, v = sess.get_kv()
+    orc = oracle.Llama(hp, w, ctx)
+    orc.memory_k[:] = k
+    orc.memory_v[:] = v
+    orc.n_past = n_past
+    assert sess.infer_next_token() == int(tok[0])  # InferenceSession::infer_next_token: argmax of the last logits, evaluated
+    got = sess.last_logits()
+    t = time.perf_counter()
+    ref = orc.evaluate(tok, mode=0)[-1]
+    ref_s = time.perf_counter() - t
+    k2, v2 = sess.get_kv()
+    std = float(ref.std())
+    d = float(np.max(np.abs(got - ref))) / std
+    rms = float(np.sqrt(np.mean((got - ref) ** 2))) / std
+    kv_equal = bool(np.array_equal(k2, orc.memory_k) and np.array_equal(v2, orc.memory_v))
+    out = {"max_over_std": float(f"{d:.3e}"), "rms_over_std": float(f"{rms:.3e}"),
+           "argmax_equal": bool(int(np.argmax(got)) == int(np.argmax(ref))),
+           "kv_rows_written_bit_equal": kv_equal, "n_past": int(n_past), "bound": PARITY_EDGE,
+           "oracle": "oracle/ggml_oracle.c mode 0 (ggml scalar path restated; parity unpinned, DESIGN.md section 5)",
+           "oracle_s": round(ref_s, 2),
+           "what": "logits of the next decode token after the timed steps, device vs CPU oracle on the session's own K/V"}
+    if not (d <= PARITY_EDGE):
+        print(json.dumps({"parity_check": out}), flush=True)
+        raise SystemExit(f"bench.py: parity check failed: max |dlogit| = {d:.3e} std > {PARITY_EDGE}")
+    return out
+
+
+def prefill_leg(L, ggml, model, hp, n, steps, warmup, wname):
     """BASELINE configs[2] on the resident model: one step = Model::evaluate of an n-token prompt batch (n_batch = n)
     at n_past = 1.  MFMA roofline of the quantized GEMM launches from per-launch HIP events of one extra step."""
     sess = model.start_session(n_batch=n)
@@ -119,17 +185,26 @@ def prefill_leg(L, ggml, model, hp, n, steps, warmup):
         sess.feed_prompt(prompt)
         assert sess.rewind(n) == 0
 
-    for _ in range(max(warmup, 1)):
+    w16_before = int(L.ggml_hip_get_stat(b"w16_bytes"))
+    tb = time.perf_counter()
+    for _ in range(max(warmup, 1)):  # the first step also builds the resident f16 weight copies (if HBM has room)
         step()
     L.ggml_hip_synchronize()
+    warm_s = time.perf_counter() - tb
+    w16_bytes = int(L.ggml_hip_get_stat(b"w16_bytes"))
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        ts = time.perf_counter()
         step()
-    L.ggml_hip_synchronize()
+        L.ggml_hip_synchronize()
+        per_step.append(time.perf_counter() - ts)
     elapsed = time.perf_counter() - t0
+    c0 = mmq_counts(L)
     L.ggml_hip_timing_begin()
     step()
     L.ggml_hip_timing_end()
+    label, counts = mmq_label(c0, mmq_counts(L))
     cls = {}
     for name, k in (("mmq_mfma", ggml.KCLASS_MMQ_MFMA), ("mmvq", ggml.KCLASS_MMVQ), ("attn", ggml.KCLASS_ATTN),
                     ("other", ggml.KCLASS_OTHER)):
@@ -139,7 +214,16 @@ def prefill_leg(L, ggml, model, hp, n, steps, warmup):
     sess.free()
     return {"tokens": n, "steps": steps, "tokens_per_s": round(n * steps / elapsed, 1),
             "ms_per_step": round(elapsed / steps * 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "k_mmq_dma_p8 (persistent quantized GEMM on the f16 matrix cores; wq|wk|wv, wo, w1|w3, w2 per layer + lm_head)",
+            "ms_per_step_min_median_max": [round(x * 1e3, 3) for x in (min(per_step), float(np.median(per_step)), max(per_step))],
+            "weights_f16_copy_bytes": w16_bytes,
+            "weights_f16_copy_note": (f"resident f16 copy of the quantized 2-D weights, {w16_bytes / 1e9:.2f} GB of HBM next to the "
+                                      f"{wname.upper()} blocks, built by k_dequant_w16 inside the first (untimed) prompt batch: "
+                                      f"{'built by this leg, ' if w16_before == 0 else 'already resident, '}"
+                                      f"{warm_s * 1e3:.0f} ms for the {max(warmup, 1)} warm-up batches incl. that pass; "
+                                      "decode keeps streaming the quantized blocks") if w16_bytes else
+                                     "no f16 copy (option off or HBM short): the GEMM dequantizes the blocks in LDS",
+            "roofline": {"bound": "mfma", "kernel": label + " — wq|wk|wv, wo, w1|w3, w2 per layer + lm_head",
+                         "kernel_launch_counts": {k: v for k, v in counts.items() if v},
                          "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "launches_per_step": launches,
                          "algo_flops_per_step": flops, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
@@ -167,12 +251,18 @@ def run_single(args):
     stat = lambda k: int(L.ggml_hip_get_stat(k.encode()))
     h0 = {k: stat(k) for k in ("ns_match", "ns_launch", "ns_wait", "ns_compute", "plan_tokens")}
     sess.host_timing(reset=True)
+    per_step = np.zeros(args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sess.infer_next_token()
+    tprev = t0
+    for i in range(args.steps):
+        sess.infer_next_token()  # returns after the token's logits are back on the host (the reference's contract)
+        tnow = time.perf_counter()
+        per_step[i] = tnow - tprev
+        tprev = tnow
     L.ggml_hip_synchronize()
     elapsed = time.perf_counter() - t0
     tok_s = args.steps / elapsed
+    parity = parity_check(args, hp, w, sess) if not args.no_parity_check else None
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
     h1 = {k: stat(k) - v for k, v in h0.items()}
     # the same greedy decode with the sampler on the device: ids identical to the loop above
@@ -260,14 +350,16 @@ def run_single(args):
     if args.prefill_steps > 0 and args.model != "tiny":
         sess.free()
         sess = None
-        prefill = prefill_leg(L, ggml, model, hp, args.prefill_tokens, args.prefill_steps, 2)
+        prefill = prefill_leg(L, ggml, model, hp, args.prefill_tokens, args.prefill_steps, 2, args.wtype)
     cpu = None
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(args, hp, w, args.cpu_secs)
     out = {"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}", "value": round(tok_s, 2),
            "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": DTYPES[args.wtype],
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "ms_per_step_min_median_max": [round(float(x) * 1e3, 4) for x in (per_step.min(), np.median(per_step), per_step.max())],
+           "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": DTYPES[args.wtype], "parity_check": parity,
            "data": "synthetic",
            "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode "
                                   f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",

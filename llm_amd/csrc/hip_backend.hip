@@ -36,6 +36,7 @@
 #include "kernels/mmq_dmap.h"
 #include "kernels/mmq_dmap8.h"
 #include "kernels/mmq_w16.h"
+#include "kernels/mmq_w16_256.h"
 #include "kernels/mmq_i8.h"
 #include "kernels/kquant.h"
 #include "kernels/quantize.h"
@@ -149,6 +150,9 @@ struct Backend {
     int opt_mmq_persist = 1; // prompt GEMM as a persistent kernel (kernels/mmq_dmap.h)
     int opt_mmq_w16 = 1;     // prompt GEMM on resident f16 copies of the quantized weights when HBM has room (kernels/mmq_w16.h)
     size_t w16_bytes = 0;    // HBM held by those copies
+    uint64_t w16_gen = 1;    // bumped when copies are released: cached prompt plans re-resolve their pointers
+    int opt_w16_headroom_gb = 16;  // HBM that must stay free after a copy is made (KV caches, workspaces, other models)
+    int opt_mmq_t256 = 1;    // prompt GEMM on 256 x 256 tiles (kernels/mmq_w16_256.h) where the launch fills the chip with them; 2 = wherever legal (tests)
     int opt_mmq_waves = 8;   // waves per workgroup of the persistent prompt GEMM: 4 (mmq_dmap.h) or 8 (mmq_dmap8.h)
     int opt_mmq_fuse = 3;    // prompt plan: wq|wk|wv (bit 0) and w1|w3 (bit 1) as one GEMM launch each
     int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
@@ -158,6 +162,7 @@ struct Backend {
     size_t timeline_bytes = 0;
     int timeline_wgs = 4;  // sampled workgroups per launch
     int opt_mmq_splitk = 1;
+    int opt_mmq_splits = 0;  // measurement: K splits of the node-by-node executor's prompt GEMM launches (0 = the rule)
     int opt_mmq_dma = 1;    // prompt GEMM with LDS-DMA staging (kernels/mmq_dma.h) when K/32 is even; 2 = int8 activations
                             // dequantized in the kernel (13 KB instead of 20 KB per stage, 2x the VALU work: 413 vs 467 TFLOP/s)
     int opt_mmq_i8 = 0;     // 1 = prompt GEMM on the integer matrix cores (kernels/mmq_i8.h): ggml's exact block dots (error
@@ -169,6 +174,10 @@ struct Backend {
     int opt_graph = 1;      // replay the plan from a captured hipGraph
     int opt_xsrc = 0;       // fuse norm / re-quantization into the mat-vec staging (see llama_plan.inc)
     uint64_t stat_plan_tokens = 0, stat_generic_graphs = 0, stat_split_tokens = 0, stat_prompt_plan_tokens = 0;
+    // prompt-GEMM launches by kernel (ggml_hip_get_stat("mmq_launches_<name>")): bench.py labels its MFMA roofline with the
+    // kernels that actually ran
+    enum { MMQ_K_PLAIN, MMQ_K_DMA, MMQ_K_DMA_P, MMQ_K_DMA_P8, MMQ_K_W16_P8, MMQ_K_W16_256, MMQ_K_I8, MMQ_K_COUNT };
+    uint64_t stat_mmq[MMQ_K_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     void *chain_plan = nullptr;            // the plan a greedy chain may continue (set by its last single-token run)
     ggml_cgraph *chain_graph = nullptr;    // ... and the cgraph that run executed
     bool pending_wait = false;  // a decode plan was launched by graph_compute_begin and not yet waited for
@@ -217,6 +226,8 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_MMQ_PERSIST")) g.opt_mmq_persist = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_WAVES")) g.opt_mmq_waves = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_W16")) g.opt_mmq_w16 = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_T256")) g.opt_mmq_t256 = atoi(v);
+    if (const char *v = getenv("GGML_HIP_W16_HEADROOM_GB")) g.opt_w16_headroom_gb = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_XCDN")) g.opt_mmq_xcdn = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_DMA")) g.opt_mmq_dma = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_I8")) g.opt_mmq_i8 = atoi(v);
@@ -256,6 +267,24 @@ DevTensor *find_tensor(uintptr_t p) {
     return find_in(g.auto_tensors, p);
 }
 void destroy_record(DevTensor *e);
+size_t release_w16_copies();
+// Every device allocation of the library goes through here.  The resident f16 weight copies of the prompt GEMM
+// (ensure_w16) are a CACHE: when HBM runs out (a second model, a long-context KV cache, score workspaces) they are
+// released, the plans that name them dropped, and the allocation retried before giving up.
+void dev_malloc(void **p, size_t bytes, const char *what) {
+    if (hipMalloc(p, bytes) == hipSuccess) return;
+    (void)hipGetLastError();
+    const size_t freed = release_w16_copies();
+    if (freed && hipMalloc(p, bytes) == hipSuccess) {
+        fprintf(stderr, "libggml_hip: released %.2f GB of resident f16 weight copies to allocate %.2f GB for %s\n", freed / 1e9,
+                bytes / 1e9, what);
+        return;
+    }
+    (void)hipGetLastError();
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    die("out of device memory: %s needs %zu bytes, %zu of %zu free", what, bytes, free_b, total_b);
+}
 // drops every record of `m` whose host range intersects [b, b+size)
 void evict_overlapping(std::map<uintptr_t, DevTensor *> &m, uintptr_t b, size_t size) {
     for (auto it = m.begin(); it != m.end();) {
@@ -276,7 +305,7 @@ DevTensor *extra_of(const ggml_tensor *t) {
 char *arena_dev(Arena *a) {
     if (!a->dev) {
         ensure_init();
-        HIP_CHECK(hipMalloc((void **)&a->dev, a->size));
+        dev_malloc((void **)&a->dev, a->size, "an arena shadow");
     }
     return a->dev;
 }
@@ -344,7 +373,7 @@ char *ws_alloc(size_t bytes) {
         for (auto &c : g.ws_chunks) total += c.size;
         const size_t want = std::max<size_t>(std::max<size_t>(bytes, total), (size_t)256 << 20);
         Backend::WsChunk c{nullptr, want};
-        HIP_CHECK(hipMalloc((void **)&c.p, want));
+        dev_malloc((void **)&c.p, want, "the graph workspace");
         g.ws_chunks.push_back(c);
         g.ws_off = 0;
     }
@@ -364,7 +393,7 @@ void ws_reset() {
     }
     g.ws_chunks.clear();
     Backend::WsChunk c{nullptr, total};
-    HIP_CHECK(hipMalloc((void **)&c.p, total));
+    dev_malloc((void **)&c.p, total, "the graph workspace");
     g.ws_chunks.push_back(c);
 }
 
@@ -636,10 +665,10 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill,
         const int64_t M = t->ne[1], nb = t->ne[0] / 32;
         size_t off[5];
         const size_t total = qw_layout(qt, M * nb, off);
-        HIP_CHECK(hipMalloc((void **)&e->dev, total));
+        dev_malloc((void **)&e->dev, total, "a weight tensor");
         e->dev_bytes = total;
         char *tmp = nullptr;
-        HIP_CHECK(hipMalloc((void **)&tmp, nbytes));
+        dev_malloc((void **)&tmp, nbytes, "an upload staging buffer");
         h2d_bulk(tmp, data, nbytes);
         relayout_launch(tmp, qt, M, nb, e->dev);
         HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -651,10 +680,10 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill,
         const int64_t M = t->ne[1], nsb = t->ne[0] / 256;
         size_t off[4];
         const size_t total = kw_layout(kt, M * nsb, off);
-        HIP_CHECK(hipMalloc((void **)&e->dev, total));
+        dev_malloc((void **)&e->dev, total, "a weight tensor");
         e->dev_bytes = total;
         char *tmp = nullptr;
-        HIP_CHECK(hipMalloc((void **)&tmp, nbytes));
+        dev_malloc((void **)&tmp, nbytes, "an upload staging buffer");
         h2d_bulk(tmp, data, nbytes);
         relayout_k_launch(tmp, kt, M, nsb, e->dev);
         HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -662,7 +691,7 @@ DevTensor *upload_tensor(const void *data, const ggml_tensor *t, bool zero_fill,
         e->ksoa = true;
         e->kw = kw_at(e->dev, kt, M, nsb);
     } else {
-        HIP_CHECK(hipMalloc((void **)&e->dev, std::max<size_t>(nbytes, 16)));
+        dev_malloc((void **)&e->dev, std::max<size_t>(nbytes, 16), "a persistent tensor");
         e->dev_bytes = nbytes;
         if (zero_fill)
             HIP_CHECK(hipMemsetAsync(e->dev, 0, std::max<size_t>(nbytes, 16), g.stream));
@@ -909,6 +938,7 @@ void launch_mmq_i8(const MmqI8Args &a, dim3 grid) {
         attr = true;
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_i8<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS));
     }
+    g.stat_mmq[Backend::MMQ_K_I8]++;
     hipLaunchKernelGGL(k_mmq_i8<QT>, grid, dim3(256), I8_LDS, g.stream, a);
 }
 
@@ -994,15 +1024,38 @@ void mul_mat_k(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *ds
     }
 }
 
-// Resident f16 copy of a quantized weight (kernels/mmq_w16.h): created on first use by a prompt plan, kept until the
-// weight's record dies.  Returns false (and the GEMM dequantizes in LDS as before) when the option is off, K / 32 is odd,
-// or HBM would be left with less than 16 GB after the allocation.
+// Resident f16 copy of a quantized weight (kernels/mmq_w16.h): created on first use by a prompt batch and kept as a CACHE:
+// released with the weight's record, when option mmq_w16 is switched off, and whenever another allocation of the library
+// fails (dev_malloc).  Returns false (and the GEMM dequantizes in LDS as before) when the option is off, K / 32 is odd,
+// or HBM would be left with less than the headroom (option w16_headroom_gb, default 16 GB) after the allocation.
+size_t w16_headroom() { return (size_t)std::max(0, g.opt_w16_headroom_gb) << 30; }
+size_t release_w16_copies() {
+    size_t freed = 0;
+    bool synced = false;
+    for (auto *m : {&g.tensors, &g.auto_tensors})
+        for (auto &kv : *m) {
+            DevTensor *e = kv.second;
+            if (!e->w16) continue;
+            if (!synced && g.stream) {
+                HIP_CHECK(hipStreamSynchronize(g.stream));
+                synced = true;
+            }
+            HIP_CHECK(hipFree(e->w16));
+            const size_t bytes = (size_t)e->qw.M * e->qw.nb * 64;
+            freed += bytes;
+            g.w16_bytes -= bytes;
+            e->w16 = nullptr;
+            e->qw.w16 = nullptr;
+        }
+    if (freed) g.w16_gen++;  // prompt plans re-read their weights' w16 pointers at the next launch (llama_plan.inc)
+    return freed;
+}
 bool ensure_w16(DevTensor *e) {
     if (!e || !e->soa || !g.opt_mmq_w16 || e->qw.nb % 2 != 0) return false;
     if (e->w16) return true;
     const size_t bytes = (size_t)e->qw.M * e->qw.nb * 64;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)16 << 30)) return false;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + w16_headroom()) return false;
     if (hipMalloc((void **)&e->w16, bytes) != hipSuccess) {
         (void)hipGetLastError();
         e->w16 = nullptr;
@@ -1037,8 +1090,72 @@ int mmq_auto_splits(int tiles, int64_t nb, bool dst_contig) {
     const int nstage = (int)((nb + 1) / 2);
     return (g.opt_mmq_splitk && tiles * 4 <= g.num_cus * 3 && nstage >= 16 && dst_contig) ? 2 : 1;
 }
+// Whether a prompt GEMM launch runs on the 256 x 256 kernel (kernels/mmq_w16_256.h): it needs every weight's resident f16
+// copy, at least 160 tokens (62 % of a token tile) and enough (tile x split) items to keep >= 60 % of the CUs busy in every
+// round.  The K split itself is NOT chosen here: it follows the 128-tile rule (mmq_auto_splits, per matrix) whatever the
+// kernel, so that a fused launch of the prompt plan and the per-matrix launches of the node-by-node executor add the same
+// partial sums (the kernels are bit-identical for equal splits).
+bool mmq_use_t256(int nseg, const MmqSegHost *segs, int64_t N, int64_t nb, int splits) {
+    if (!g.opt_mmq_t256 || !g.opt_mmq_w16 || !g.opt_mmq_persist || g.opt_mmq_dma != 1 || nb % 2 != 0) return false;
+    int tiles = 0;
+    for (int i = 0; i < nseg; i++) {
+        if (!segs[i].w.w16) return false;
+        tiles += (int)((segs[i].w.M + T256_TM - 1) / T256_TM);
+    }
+    if (g.opt_mmq_t256 == 2) return true;  // tests: every launch that can run on it does
+    if (N < 160) return false;
+    tiles *= (int)((N + T256_TN - 1) / T256_TN);
+    const int items = tiles * splits, rounds = (items + g.num_cus - 1) / g.num_cus;
+    return items * 5 >= rounds * g.num_cus * 3;
+}
+void mmq_w16_256_launch(int nseg, const MmqSegHost *segs, const _Float16 *x16, int64_t N, int64_t nb, int splits, bool zero_dst,
+                        int64_t split_stride) {
+    MmqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = segs[0].w;
+    a.x = x16;
+    a.dst = segs[0].dst;
+    a.ldd = segs[0].ldd;
+    a.M = a.w.M;
+    a.N = N;
+    a.nb = nb;
+    a.nseg = nseg;
+    int tiles_m = 0;
+    double rows = 0;
+    for (int i = 0; i < nseg; i++) {
+        tiles_m += (int)((segs[i].w.M + T256_TM - 1) / T256_TM);
+        rows += (double)segs[i].w.M;
+        if (i < 2) a.tile_end[i] = tiles_m;
+    }
+    if (nseg > 1) { a.wb = segs[1].w; a.dst_b = segs[1].dst; a.ldd_b = segs[1].ldd; }
+    if (nseg > 2) { a.wc = segs[2].w; a.dst_c = segs[2].dst; a.ldd_c = segs[2].ldd; }
+    a.tiles_n = (int)((N + T256_TN - 1) / T256_TN);
+    a.split_stride = splits > 1 ? split_stride : 0;
+    if (splits > 1 && zero_dst && !split_stride)
+        for (int i = 0; i < nseg; i++) HIP_CHECK(hipMemsetAsync(segs[i].dst, 0, (size_t)segs[i].w.M * N * 4, g.stream));
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
+        attr_set = true;
+    }
+    const int tiles_total = tiles_m * a.tiles_n, n_items = tiles_total * splits;
+    Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * rows * (double)N * (double)(nb * 32));
+    g.stat_mmq[Backend::MMQ_K_W16_256]++;
+    hipLaunchKernelGGL(k_mmq_w16_256, dim3((unsigned)std::min(n_items, g.num_cus)), dim3(512), T256_LDS, g.stream, a, n_items, tiles_total, splits);
+    HIP_CHECK(hipGetLastError());
+}
 void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float16 *x16, const int8_t *x8, const _Float16 *dx,
                           int64_t N, int64_t nb, bool dst_contig, int splits, bool zero_dst, int64_t split_stride = 0) {
+    if (splits <= 0) {
+        int t128 = 0;
+        for (int i = 0; i < nseg; i++) t128 += (int)((segs[i].w.M + MMQ_TM - 1) / MMQ_TM);
+        splits = mmq_auto_splits(t128 * (int)((N + MMQ_TN - 1) / MMQ_TN), nb, dst_contig);
+        if (g.opt_mmq_splits > 0 && dst_contig && nb / 2 >= 2 * g.opt_mmq_splits) splits = std::min(g.opt_mmq_splits, 2);  // probes
+    }
+    if (x16 && mmq_use_t256(nseg, segs, N, nb, splits)) {
+        mmq_w16_256_launch(nseg, segs, x16, N, nb, splits, zero_dst, split_stride);
+        return;
+    }
     MmqArgs a;
     memset(&a, 0, sizeof(a));
     a.w = segs[0].w;
@@ -1098,6 +1215,7 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_p8, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS));
                 w16_attr_set = true;
             }
+            g.stat_mmq[Backend::MMQ_K_W16_P8]++;
             hipLaunchKernelGGL(k_mmq_w16_p8, pgrid, dim3(512), W16_LDS, g.stream, a, n_items, tiles_total, splits);
             HIP_CHECK(hipGetLastError());
             return;
@@ -1112,6 +1230,7 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q8_0>::LDS));
                 p8_attr_set = true;
             }
+            g.stat_mmq[Backend::MMQ_K_DMA_P8]++;
             switch (qt) {
                 case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_0>, pgrid, dim3(512), Dma8<QT_Q4_0>::LDS, g.stream, a, n_items, tiles_total, splits); break;
                 case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma_p8<QT_Q4_1>, pgrid, dim3(512), Dma8<QT_Q4_1>::LDS, g.stream, a, n_items, tiles_total, splits); break;
@@ -1123,6 +1242,7 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
             HIP_CHECK(hipGetLastError());
             return;
         }
+        g.stat_mmq[Backend::MMQ_K_DMA_P]++;
         switch (qt) {
             case QT_Q4_0: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q4_0>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
             case QT_Q4_1: hipLaunchKernelGGL(k_mmq_dma_p<QT_Q4_1>, pgrid, dim3(256), DMA_LDS, g.stream, a, n_items, tiles_total, splits); break;
@@ -1149,6 +1269,7 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q8_0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
             dma_attr_set = true;
         }
+        g.stat_mmq[Backend::MMQ_K_DMA]++;
 #define LAUNCH_DMA(QT_)                                                                                             \
     if (use_x8)                                                                                                     \
         hipLaunchKernelGGL((k_mmq_dma<QT_, true>), grid, dim3(256), D8_LDS, g.stream, a);                           \
@@ -1166,6 +1287,7 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
         HIP_CHECK(hipGetLastError());
         return;
     }
+    g.stat_mmq[Backend::MMQ_K_PLAIN]++;
     switch (qt) {
         case QT_Q4_0: hipLaunchKernelGGL(k_mmq<QT_Q4_0>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
         case QT_Q4_1: hipLaunchKernelGGL(k_mmq<QT_Q4_1>, grid, dim3(256), MMQ_LDS, g.stream, a); break;
@@ -1220,6 +1342,11 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
     const bool use_dma = g.opt_mmq_dma && nb % 2 == 0, use_x8 = use_dma && g.opt_mmq_dma >= 2;
     const _Float16 *x16 = nullptr, *dx = nullptr;
     const int8_t *x8 = nullptr;
+    if (use_dma && !use_x8 && g.opt_mmq_persist && N >= W16_MIN_TOKENS) {  // a resident weight meeting a real prompt batch gets its
+        DevTensor *e = extra_of(src0);                                      // f16 copy here too (the prompt plan makes them
+        if (!e) e = find_tensor((uintptr_t)src0->data);                     // for a whole model at once, llama_plan.inc)
+        if (e && e->soa && (uintptr_t)src0->data == e->host) ensure_w16(e);
+    }
     if (use_x8)
         quantize_activation_q8p(src1, f16_d, &x8, &dx);
     else
@@ -1945,16 +2072,16 @@ size_t ggml_hip_quantize(enum ggml_type type, const float *src, void *dst, int64
     char *din = nullptr, *dout = nullptr;
     unsigned long long *dh = nullptr;
     const int64_t cap = std::min(nblocks, piece);
-    HIP_CHECK(hipMalloc((void **)&din, (size_t)cap * 128));
-    HIP_CHECK(hipMalloc((void **)&dout, (size_t)cap * bs));
+    dev_malloc((void **)&din, (size_t)cap * 128, "the quantizer input");
+    dev_malloc((void **)&dout, (size_t)cap * bs, "the quantizer output");
     HIP_CHECK(hipMalloc((void **)&dh, 128));
     HIP_CHECK(hipMemsetAsync(dh, 0, 128, g.stream));
     for (int64_t b0 = 0; b0 < nblocks; b0 += piece) {
         const int64_t nb = std::min(piece, nblocks - b0);
         h2d_bulk(din, src + b0 * 32, (size_t)nb * 128);
         launch_quantize_blocks(din, false, (int)type, nb, (uint8_t *)dout, dh);
-        HIP_CHECK(hipMemcpyAsync((char *)dst + (size_t)b0 * bs, dout, (size_t)nb * bs, hipMemcpyDeviceToHost, g.stream));
-        HIP_CHECK(hipStreamSynchronize(g.stream));
+        d2h_queue((char *)dst + (size_t)b0 * bs, dout, (size_t)nb * bs);  // pinned staging, delivered by d2h_finish
+        d2h_finish();
     }
     unsigned long long hh[16];
     HIP_CHECK(hipMemcpy(hh, dh, 128, hipMemcpyDeviceToHost));
@@ -1978,7 +2105,7 @@ int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor
     const size_t bs = ggml_type_size(dst->type);
     char *raw = nullptr;
     unsigned long long *dh = nullptr;
-    HIP_CHECK(hipMalloc((void **)&raw, (size_t)nblocks * bs));
+    dev_malloc((void **)&raw, (size_t)nblocks * bs, "the resident quantizer output");
     HIP_CHECK(hipMalloc((void **)&dh, 128));
     HIP_CHECK(hipMemsetAsync(dh, 0, 128, g.stream));
     launch_quantize_blocks(dev_ptr(src), src->type == GGML_TYPE_F16, (int)dst->type, nblocks, (uint8_t *)raw, dh);
@@ -1990,7 +2117,7 @@ int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor
     const int qt = qt_of(dst->type);
     size_t off[5];
     const size_t total = qw_layout(qt, nblocks, off);
-    HIP_CHECK(hipMalloc((void **)&e->dev, total));
+    dev_malloc((void **)&e->dev, total, "a weight tensor");
     e->dev_bytes = total;
     relayout_launch(raw, qt, M, nb, e->dev);
     unsigned long long hh[16];
@@ -2016,22 +2143,29 @@ int ggml_hip_topk(const struct ggml_tensor *t, int64_t row, int k, const int32_t
     std::lock_guard<std::recursive_mutex> lk(g.mu);
     ensure_init();
     if (!t || t->type != GGML_TYPE_F32 || t->nb[0] != 4 || row < 0 || row >= t->ne[1] * t->ne[2] * t->ne[3] || t->ne[2] != 1 ||
-        t->ne[3] != 1 || k < 1 || k > TOPK_MAX || k > t->ne[0] || n_extra < 0 || t->ne[0] > 0x7FFFFFFF)
+        t->ne[3] != 1 || k < 1 || k > TOPK_MAX || k > t->ne[0] || n_extra < 0 || t->ne[0] > 0x7FFFFFFF || !out_vals || !out_ids ||
+        (n_extra > 0 && !extra_ids) || t->data == nullptr)
         return -1;
+    {   // the tensor must have a device image (a record or an arena shadow); dev_ptr would abort otherwise
+        DevTensor *e = extra_of(t);
+        if (!e) e = find_tensor((uintptr_t)t->data);
+        if (e ? e->soa : find_arena((uintptr_t)t->data) == nullptr) return -1;
+    }
+    finish_pending();
     const float *x = (const float *)(dev_ptr(t) + row * (int64_t)t->nb[1]);
     char *buf = ws_alloc((size_t)(k + n_extra) * 8 + (size_t)n_extra * 4 + 64);
     float *dv = (float *)buf;
     int *di = (int *)(buf + (size_t)(k + n_extra) * 4);
     int *de = di + (k + n_extra);
-    if (n_extra) HIP_CHECK(hipMemcpyAsync(de, extra_ids, (size_t)n_extra * 4, hipMemcpyHostToDevice, g.stream));
+    if (n_extra) h2d_small((char *)de, extra_ids, (size_t)n_extra * 4);  // through pinned staging, never from caller pages
     {
         Timed tm(GGML_HIP_KCLASS_OTHER, (double)t->ne[0] * 4 * 9);
         hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, g.stream, x, (int)t->ne[0], k, (const int *)de, n_extra, dv, di);
         HIP_CHECK(hipGetLastError());
     }
-    HIP_CHECK(hipMemcpyAsync(out_vals, dv, (size_t)(k + n_extra) * 4, hipMemcpyDeviceToHost, g.stream));
-    HIP_CHECK(hipMemcpyAsync(out_ids, di, (size_t)(k + n_extra) * 4, hipMemcpyDeviceToHost, g.stream));
-    HIP_CHECK(hipStreamSynchronize(g.stream));
+    d2h_queue(out_vals, (const char *)dv, (size_t)(k + n_extra) * 4);
+    d2h_queue(out_ids, (const char *)di, (size_t)(k + n_extra) * 4);
+    d2h_finish();
     return 0;
 }
 
@@ -2057,7 +2191,11 @@ void ggml_hip_assign_buffers_no_scratch(struct ggml_tensor *tensor) {
     tensor->extra = upload_tensor(tensor->data, tensor, true);
 }
 bool ggml_hip_can_mul_mat(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
-    const bool q = qt_of(src0->type) >= 0 || kt_of(src0->type) >= 0 || src0->type == GGML_TYPE_F16 || src0->type == GGML_TYPE_F32;
+    // quantized operands: only the block formats with kernels behind them, in the shapes those kernels take (anything
+    // else is answered "no" here instead of aborting inside the launch)
+    bool q = src0->type == GGML_TYPE_F16 || src0->type == GGML_TYPE_F32;
+    if (qt_of(src0->type) >= 0) q = src0->ne[0] % 32 == 0;
+    if (kt_of(src0->type) >= 0) q = src0->ne[0] % 256 == 0;
     return q && src1->type == GGML_TYPE_F32 && dst->type == GGML_TYPE_F32;
 }
 size_t ggml_hip_mul_mat_get_wsize(const struct ggml_tensor *, const struct ggml_tensor *, struct ggml_tensor *) {
@@ -2252,10 +2390,21 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_mmq_persist = value;
     else if (k == "mmq_waves")
         g.opt_mmq_waves = value;
+    else if (k == "mmq_splits")
+        g.opt_mmq_splits = value;
+    else if (k == "mmq_t256") {
+        if (g.opt_mmq_t256 != value) drop_all_plans();
+        g.opt_mmq_t256 = value;
+    }
     else if (k == "mmq_w16") {
         if (g.opt_mmq_w16 != value) drop_all_plans();
         g.opt_mmq_w16 = value;
+        if (!value) release_w16_copies();  // the copies are a cache of this option
     }
+    else if (k == "w16_headroom_gb")
+        g.opt_w16_headroom_gb = value;
+    else if (k == "w16_release")  // drop the resident f16 weight copies now (they come back with the next prompt batch)
+        release_w16_copies();
     else if (k == "plan_prompt") {
         if (g.opt_plan_prompt != value) drop_all_plans();
         g.opt_plan_prompt = value;
@@ -2352,7 +2501,18 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
 // ===================================================================================================
 }  // extern "C"
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// Single-GPU builds need no RCCL development package: librccl is opened at run time (rccl_load), and these are the few
+// declarations of its stable C API the hop uses (nccl.h: ncclUniqueId is 128 opaque bytes, ncclUint8 = 1).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclFloat32 = 7 } ncclDataType_t;
+}
+#endif
 namespace {
 struct Rccl {
     void *dl = nullptr;
@@ -2558,6 +2718,12 @@ int64_t ggml_hip_get_stat(const char *key) {
     const std::string k(key);
     if (k == "attn_split_tokens") return (int64_t)g.stat_split_tokens;  // tokens whose attention ran split over positions
     if (k == "w16_bytes") return (int64_t)g.w16_bytes;  // HBM held by resident f16 weight copies
+    if (k.rfind("mmq_launches_", 0) == 0) {                 // prompt-GEMM launches by kernel since library load
+        static const char *names[Backend::MMQ_K_COUNT] = {"plain", "dma", "dma_p", "dma_p8", "w16_p8", "w16_256", "i8"};
+        for (int i = 0; i < Backend::MMQ_K_COUNT; i++)
+            if (k.substr(13) == names[i]) return (int64_t)g.stat_mmq[i];
+        return -1;
+    }
     if (k == "prompt_plan_tokens") return (int64_t)g.stat_prompt_plan_tokens;  // tokens executed by the fused prompt plan
     if (k == "plan_tokens") return (int64_t)g.stat_plan_tokens;       // tokens executed by the fused decode plan
     if (k == "graph_replays") {

@@ -488,7 +488,9 @@ __device__ __forceinline__ void prefetch_slice(const PrefetchArgs &a, int wg, in
 //   p   = softmax(s·scale) with ggml's f16-rounded exp, then rounded to f16 (src1 of the V matmul)
 //   o_d = Σ_t V[d][t]·p_t ; the head's D outputs are re-quantized to Q8 blocks for the wo mat-vec and
 //   optionally written as f32 (merge-heads layout [E]).
-// K: [C][Egqa] f16 (per layer), V: [Egqa][C] f16 (per layer).  Dynamic LDS: (C + D) floats + C halves.
+// K: [C][Egqa] f16 (per layer), V: [Egqa][C] f16 (per layer).  Dynamic LDS: (Clds + D) floats + Clds halves, Clds >= the
+// live length the launch can meet (the plan sizes it by the context, or by the split threshold when longer rows go to
+// kernels/decode_attn_split.h).
 //
 // At short context the kernel is a pure latency chain (a few tens of KB per head), so its shape is dictated by
 // round trips and instruction issue, not bandwidth (in-kernel timeline at 135 positions: position -> K/V loads
@@ -506,7 +508,8 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
                                                       const __half *__restrict__ mem_v, const DecParams *prm,
                                                       float scale, int D, int n_rep /* H / Hkv */, int64_t Egqa,
                                                       int64_t C, float *out_f32, int8_t *lo, int8_t *hi, float *dq,
-                                                      int *sumq, long long *ts, int n_head, const PrefetchArgs pf) {
+                                                      int *sumq, long long *ts, int n_head, const PrefetchArgs pf,
+                                                      int64_t Clds /* positions the LDS arrays hold (<= C, % 8 == 0) */) {
     // Workgroups past the heads (decode only; the plan launches one per otherwise idle CU) pull weights of the next two
     // mat-vecs into the L2 of the XCD that will read them (see prefetch_slice).
     if ((int)blockIdx.x >= n_head) {
@@ -515,9 +518,9 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     }
     const long long t_entry = ts ? (long long)wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_s = (float *)smem;  // C scores
-    float *s_o = s_s + C;        // D outputs
-    _Float16 *s_p = (_Float16 *)(s_o + D);  // C probabilities as f16 (src1 of the V matmul); C % 8 == 0
+    float *s_s = (float *)smem;  // Clds scores
+    float *s_o = s_s + Clds;     // D outputs
+    _Float16 *s_p = (_Float16 *)(s_o + D);  // Clds probabilities as f16 (src1 of the V matmul); Clds % 8 == 0
     __shared__ float s_red[16];
     __shared__ double s_redd[16];
     const int h = blockIdx.x, hk = h / n_rep;

@@ -199,9 +199,13 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
     }
 }
 
-template <int QT, int EPI, int XSRC>
+// INSTR: the measurement build (BigArgs::probe early exits, BigArgs::ts timeline stamps), launched only while option
+// "probe" or "timeline" is set; the production instantiation (INSTR = false) carries none of those branches.
+template <int QT, int EPI, int XSRC, bool INSTR = false>
 __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     const DecMmvqArgs &a = ba.d;
+    const int probe = INSTR ? ba.probe : 0;
+    long long *const ts = INSTR ? ba.ts : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_part[16];
     __shared__ float s_rope[EPI == EPI_QKV ? 256 : 2];  // cos/sin of the RoPE angle of every pair of a head (D <= 256)
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     // those drains the whole in-order load queue at every step
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const long long t_entry = ba.ts ? big_now() : 0;
+    const long long t_entry = ts ? big_now() : 0;
     // ---- 1. the activation's loads go first (see BigX); so does the position (needed by the QKV epilogue only)
     int n_past = 0;
     if constexpr (EPI == EPI_QKV) n_past = a.prm->n_past;
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
         }
     };
 
-    if (ba.probe == 1) return;  // here, not at entry: a check at entry costs every launch one more scalar-cache round trip
+    if (probe == 1) return;  // here, not at entry: a check at entry costs every launch one more scalar-cache round trip
     // ---- 2. weight prologue, part 1: PF0 steps.  Enough to cover the latency of x, little enough that x is not
     //         queued behind tens of MB of weight requests in the fabric (measured with the in-kernel timeline:
     //         with the full ring requested up front x took 3..6 us to arrive)
@@ -343,7 +347,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
         issue(ring[k], pj, k >= S);
         advance(k);
     }
-    const long long t_issued = ba.ts ? big_now() : 0;
+    const long long t_issued = ts ? big_now() : 0;
 
     // ---- 3. norm / re-quantization of x into LDS; meanwhile the last two waves (not stagers) park the RoPE table
     if constexpr (EPI == EPI_QKV) {
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
         }
     }
     big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, T, s_lo, s_hi, s_d, s_sum, s_part);
-    const long long t_staged = ba.ts ? big_now() : 0;
+    const long long t_staged = ts ? big_now() : 0;
     // ---- 2b. the rest of the ring
 #pragma unroll
     for (int k = PF0; k < PF; k++) {
@@ -362,9 +366,9 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
         advance(k);
     }
     __syncthreads();
-    const long long t_barrier = ba.ts ? big_now() : 0;
+    const long long t_barrier = ts ? big_now() : 0;
     long long t_first = 0;
-    if (ba.probe == 2) return;
+    if (probe == 2) return;
 
     // ---- 4. dots.  The unrolled body only accumulates; when a unit's last column is done its NR sums are reduced
     //         across the wave and parked in lane `unit index` (myv), the epilogues run afterwards, one lane each.
@@ -383,7 +387,7 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
                 const BigStep<QT, NR> &st = ring[k];
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    if (ba.probe == 4 && (k & 1)) continue;  // measurement: half the dots
+                    if (probe == 4 && (k & 1)) continue;  // measurement: half the dots
                     u32x4 p2 = st.q[r];
                     uint32_t hh = 0;
                     float mw = 0.0f;
@@ -392,12 +396,12 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
                     if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mw = __half2float(st.mw[r]);
                     acc[r] += block_dot<QT>(st.q[r], p2, hh, __half2float(st.dw[r]), mw, lo, hi, xd, xs);
                 }
-                if (ba.ts && s + k == 0) t_first = acc[0] != 12345.678f ? big_now() : 1;  // first step's weights landed
+                if (ts && s + k == 0) t_first = acc[0] != 12345.678f ? big_now() : 1;  // first step's weights landed
                 if (++cj == nbl) {
                     cj = 0;
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
-                        const float v = ba.probe == 5 ? acc[r] : wave_sum_f32(acc[r]);  // 5: measurement, no reduction
+                        const float v = probe == 5 ? acc[r] : wave_sum_f32(acc[r]);  // 5: measurement, no reduction
                         myv[r] = lane == ci ? v : myv[r];
                         acc[r] = 0.0f;
                     }
@@ -413,10 +417,10 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
             }
         }
     }
-    const long long t_dots = ba.ts ? big_now() : 0;
+    const long long t_dots = ts ? big_now() : 0;
 
     // ---- 5. epilogues: lane i finishes unit i
-    if (lane < nu && ba.probe != 3) {
+    if (lane < nu && probe != 3) {
         int sg, m0;
         resolve(lane, sg, m0);
         if constexpr (EPI == EPI_STORE) {
@@ -444,10 +448,10 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
             }
         }
     }
-    if (ba.ts && wave == 0 && lane == 0) {
+    if (ts && wave == 0 && lane == 0) {
         const int q = (int)gridDim.x / ba.ts_wgs;
         if (q > 0 && blockIdx.x % q == 0 && (int)blockIdx.x / q < ba.ts_wgs) {
-            long long *o = ba.ts + ((int)blockIdx.x / q) * 8;
+            long long *o = ts + ((int)blockIdx.x / q) * 8;
             o[0] = t_entry; o[1] = t_issued; o[2] = t_staged; o[3] = t_barrier; o[4] = t_first; o[5] = big_now();
             o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = blockIdx.x;
         }

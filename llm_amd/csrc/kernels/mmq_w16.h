@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256) k_dequant_w16(const QWeight w, _Float16 *
     for (int k = 0; k < 4; k++) dst[k] = o[k];
 }
 
+#define W16_MIN_TOKENS 64  /* generic mul_mat: token count from which a resident weight gets its f16 copy */
 #define W16_X 0
 #define W16_W 16384
 #define W16_SLOT 32768
