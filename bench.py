@@ -72,10 +72,13 @@ def weight_bytes_per_token(hp, wtype_bytes, blck=32):
 
 
 def cpu_baseline(args, hp, w, budget_s):
-    """Restated ggml CPU path (oracle mode 0 = upstream's scalar code, OpenMP over rows) timed on this host's cores.
-    A LOWER BOUND on the reference: its build runs ggml's hand-written AVX2 kernels, this is a scalar restatement
-    compiled -O3 -mavx2."""
+    """ggml's CPU path as the reference's build selects it (crates/ggml/sys/build.rs:46-62: -mavx2 -mfma -mf16c), restated
+    with the AVX2 intrinsics themselves (oracle mode 3: _mm256_maddubs_epi16 / _mm256_madd_epi16 block dots, 8-lane fmadd,
+    _mm256_round_ps activation quantizer, F16C attention dots; bit-identical to the order restatement the CPU tests pin),
+    OpenMP over rows where ggml uses its thread pool, timed on this host's cores.  Falls back to the scalar restatement
+    (mode 0, kind "port") on a host without AVX2."""
     from oracle import oracle
+    mode = 3 if oracle.have_avx2() else 0
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     ncpu = len(os.sched_getaffinity(0))
     orc = oracle.Llama(hp, w, 256)
@@ -83,10 +86,10 @@ def cpu_baseline(args, hp, w, budget_s):
     best, tried = None, {}
     spent = 0.0
     # calibrate the team size on one token each (containers often expose more cpus than they may use)
-    for thr in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu} | {min(ncpu, 8)}):
+    for thr in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu} | {min(ncpu, 8)}):
         oracle.lib().orc_set_num_threads(thr)
         t = time.perf_counter()
-        orc.evaluate(tok, mode=0)
+        orc.evaluate(tok, mode=mode)
         dt = time.perf_counter() - t
         spent += dt
         tried[thr] = round(dt, 3)
@@ -99,14 +102,16 @@ def cpu_baseline(args, hp, w, budget_s):
     n = int(max(1, min(40, (budget_s - spent) / max(dt1, 1e-3))))
     t = time.perf_counter()
     for _ in range(n):
-        orc.evaluate(tok, mode=0)
+        orc.evaluate(tok, mode=mode)
     el = time.perf_counter() - t
-    return {"value": round(n / el, 3), "unit": "tokens/s", "cores": thr, "kind": "port",
+    return {"value": round(n / el, 3), "unit": "tokens/s", "cores": thr, "kind": "port-avx2" if mode == 3 else "port",
             "sample": f"{n} single-token decode steps of the same {args.model} {args.wtype} weights at short context "
-                      f"(oracle mode 0, OpenMP, {thr} threads = the fastest of the calibrated team sizes)",
+                      f"(oracle mode {mode}, OpenMP, {thr} threads = the fastest of the calibrated team sizes)",
             "calibration_s_per_token": {str(k): v for k, v in tried.items()}, "host_cpus": ncpu,
-            "note": "scalar restatement of ggml's CPU path (-O3 -mavx2): a lower bound on the reference, whose build runs "
-                    "ggml's hand-written AVX2 kernels"}
+            "note": ("ggml's AVX2 code path restated with the same intrinsics (block dots by maddubs/madd, fmadd lanes, F16C), "
+                     "bit-identical to oracle mode 2; not ggml's binary (its C sources are an empty submodule in the reference "
+                     "tree), so thread pool and cache blocking are this port's") if mode == 3 else
+                    "scalar restatement of ggml's CPU path (-O3 -mavx2): a lower bound on the reference"}
 
 
 MMQ_KERNELS = (  # stat key suffix -> what the launch is (ggml_hip_get_stat("mmq_launches_<key>"))
@@ -141,36 +146,51 @@ PARITY_EDGE = 4e-2  # tests/test_llama_gpu.py EDGE: one int8 activation quant on
 def parity_check(args, hp, w, sess):
     """The token the timed loop would evaluate next, evaluated by the device AND by the CPU oracle (mode 0 = ggml's scalar
     path) from the same K/V state: the session's K/V cache (what the timed steps wrote) is copied into the oracle, both
-    evaluate argmax(last logits) at the session's n_past.  The run fails if the logits differ by more than PARITY_EDGE
-    standard deviations.  The oracle is the checker here, never the thing measured."""
+    evaluate argmax(last logits) at the session's n_past.  The yardstick is the reference's OWN ambiguity measured in the
+    same run: the oracle with its f32 block sums added in reverse order (a second legal order of ggml's vec_dot; upstream's
+    scalar and AVX2 branches differ by as much) gives `band`, the math mode (no activation quantization) the noise floor.
+    With the gaussian weights of BASELINE.md section 4 a LLaMA-7B is far more sensitive than with random blocks (band
+    ~1e-1 std vs ~3e-3, tests/test_c3_gpu.py).  The run FAILS if the device is further from the oracle than
+    max(PARITY_EDGE, 2 * band) or than the floor.  The oracle is the checker here, never the thing measured."""
     from oracle import oracle
     ctx = sess.model.context_size
     n_past = sess.n_past
     tok = np.array([int(np.argmax(sess.last_logits()))], np.int32)
     k, v = sess.get_kv()
-    orc = oracle.Llama(hp, w, ctx)
-    orc.memory_k[:] = k
-    orc.memory_v[:] = v
-    orc.n_past = n_past
+    orcs = [oracle.Llama(hp, w, ctx) for _ in range(3)]
+    for o in orcs:
+        o.memory_k[:] = k
+        o.memory_v[:] = v
+        o.n_past = n_past
     assert sess.infer_next_token() == int(tok[0])  # InferenceSession::infer_next_token: argmax of the last logits, evaluated
     got = sess.last_logits()
     t = time.perf_counter()
-    ref = orc.evaluate(tok, mode=0)[-1]
+    ref = orcs[0].evaluate(tok, mode=0)[-1]
     ref_s = time.perf_counter() - t
+    rev = orcs[1].evaluate(tok, mode=0, reverse_blocks=True)[-1]
+    mth = orcs[2].evaluate(tok, mode=1)[-1]
     k2, v2 = sess.get_kv()
-    std = float(ref.std())
+    std = float(mth.std())
     d = float(np.max(np.abs(got - ref))) / std
     rms = float(np.sqrt(np.mean((got - ref) ** 2))) / std
-    kv_equal = bool(np.array_equal(k2, orc.memory_k) and np.array_equal(v2, orc.memory_v))
+    band = float(np.max(np.abs(ref - rev))) / std
+    floor = float(np.max(np.abs(ref - mth))) / std
+    nk = int(np.count_nonzero(k2 != orcs[0].memory_k)) + int(np.count_nonzero(v2 != orcs[0].memory_v))
+    bound = max(PARITY_EDGE, 2.0 * band)
+    ok = d <= bound and d <= max(floor, PARITY_EDGE)
     out = {"max_over_std": float(f"{d:.3e}"), "rms_over_std": float(f"{rms:.3e}"),
            "argmax_equal": bool(int(np.argmax(got)) == int(np.argmax(ref))),
-           "kv_rows_written_bit_equal": kv_equal, "n_past": int(n_past), "bound": PARITY_EDGE,
+           "oracle_fwd_vs_rev_band_over_std": float(f"{band:.3e}"), "oracle_exact_vs_math_floor_over_std": float(f"{floor:.3e}"),
+           "bound_over_std": float(f"{bound:.3e}"), "passed": bool(ok),
+           "kv_halves_written_that_differ": nk, "kv_halves_written": int(2 * hp["n_layer"] * hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])),
+           "n_past": int(n_past),
            "oracle": "oracle/ggml_oracle.c mode 0 (ggml scalar path restated; parity unpinned, DESIGN.md section 5)",
            "oracle_s": round(ref_s, 2),
-           "what": "logits of the next decode token after the timed steps, device vs CPU oracle on the session's own K/V"}
-    if not (d <= PARITY_EDGE):
+           "what": "logits of the next decode token after the timed steps, device vs CPU oracle on the session's own K/V; band = "
+                   "the oracle against itself with the block sums in reverse order, floor = against its math mode"}
+    if not ok:
         print(json.dumps({"parity_check": out}), flush=True)
-        raise SystemExit(f"bench.py: parity check failed: max |dlogit| = {d:.3e} std > {PARITY_EDGE}")
+        raise SystemExit(f"bench.py: parity check failed: max |dlogit| = {d:.3e} std > bound {bound:.3e} (band {band:.3e}, floor {floor:.3e})")
     return out
 
 

@@ -153,6 +153,7 @@ struct Backend {
     uint64_t w16_gen = 1;    // bumped when copies are released: cached prompt plans re-resolve their pointers
     int opt_w16_headroom_gb = 16;  // HBM that must stay free after a copy is made (KV caches, workspaces, other models)
     int opt_mmq_t256 = 1;    // prompt GEMM on 256 x 256 tiles (kernels/mmq_w16_256.h) where the launch fills the chip with them; 2 = wherever legal (tests)
+    int opt_mmq_t256_var = 0;  // measurement variants of k_mmq_w16_256 (see the kernel)
     int opt_mmq_waves = 8;   // waves per workgroup of the persistent prompt GEMM: 4 (mmq_dmap.h) or 8 (mmq_dmap8.h)
     int opt_mmq_fuse = 3;    // prompt plan: wq|wk|wv (bit 0) and w1|w3 (bit 1) as one GEMM launch each
     int opt_big = 1;        // decode mat-vec as one wave of 1024-thread workgroups (kernels/decode_big.h)
@@ -1135,13 +1136,22 @@ void mmq_w16_256_launch(int nseg, const MmqSegHost *segs, const _Float16 *x16, i
         for (int i = 0; i < nseg; i++) HIP_CHECK(hipMemsetAsync(segs[i].dst, 0, (size_t)segs[i].w.M * N * 4, g.stream));
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
         attr_set = true;
     }
     const int tiles_total = tiles_m * a.tiles_n, n_items = tiles_total * splits;
     Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * rows * (double)N * (double)(nb * 32));
     g.stat_mmq[Backend::MMQ_K_W16_256]++;
-    hipLaunchKernelGGL(k_mmq_w16_256, dim3((unsigned)std::min(n_items, g.num_cus)), dim3(512), T256_LDS, g.stream, a, n_items, tiles_total, splits);
+    const dim3 grid((unsigned)std::min(n_items, g.num_cus));
+    switch (g.opt_mmq_t256_var & 3) {
+        case 1: hipLaunchKernelGGL(k_mmq_w16_256<1>, grid, dim3(512), T256_LDS, g.stream, a, n_items, tiles_total, splits); break;
+        case 2: hipLaunchKernelGGL(k_mmq_w16_256<2>, grid, dim3(512), T256_LDS, g.stream, a, n_items, tiles_total, splits); break;
+        case 3: hipLaunchKernelGGL(k_mmq_w16_256<3>, grid, dim3(512), T256_LDS, g.stream, a, n_items, tiles_total, splits); break;
+        default: hipLaunchKernelGGL(k_mmq_w16_256<0>, grid, dim3(512), T256_LDS, g.stream, a, n_items, tiles_total, splits); break;
+    }
     HIP_CHECK(hipGetLastError());
 }
 void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float16 *x16, const int8_t *x8, const _Float16 *dx,
@@ -2390,6 +2400,8 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_mmq_persist = value;
     else if (k == "mmq_waves")
         g.opt_mmq_waves = value;
+    else if (k == "mmq_t256_var")
+        g.opt_mmq_t256_var = value;
     else if (k == "mmq_splits")
         g.opt_mmq_splits = value;
     else if (k == "mmq_t256") {

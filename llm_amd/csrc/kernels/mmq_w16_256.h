@@ -34,7 +34,11 @@
 // and the asm after (volatile asm statements and barriers keep their order).
 #define T256_PIN(t) asm volatile("" : "+v"(t))
 
+// VAR (measurement variants, option mmq_t256_var; 0 = production): bit 0 = the counted DMA wait sits behind the phase's MFMAs
+// (issued, still executing) instead of in front of the barrier that precedes them; bit 1 = no s_setprio around the MFMAs.
+template <int VAR>
 __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_items, int tiles_total, int splits) {
+    constexpr bool WAIT_LATE = (VAR & 1) != 0, PRIO = (VAR & 2) == 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,13 +179,13 @@ __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_i
                 fa[1][ks] = *(const f16x8 *)(S + xbase + 32 * 128 + off[ks]);
             }
             issue_w(1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (!WAIT_LATE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             T256_PIN(acc[0][0]);
             T256_PIN(acc[1][0]);
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb[0][ks], acc[0][0], 0, 0, 0);
@@ -189,7 +193,8 @@ __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_i
             }
             T256_PIN(acc[0][0]);
             T256_PIN(acc[1][0]);
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if (WAIT_LATE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -197,13 +202,13 @@ __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_i
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) fb[1][ks] = *(const f16x8 *)(S + wbase + 32 * 128 + off[ks]);
             issue_x(1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (!WAIT_LATE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             T256_PIN(acc[0][1]);
             T256_PIN(acc[1][1]);
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb[1][ks], acc[0][1], 0, 0, 0);
@@ -211,7 +216,8 @@ __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_i
             }
             T256_PIN(acc[0][1]);
             T256_PIN(acc[1][1]);
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if (WAIT_LATE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_i
             __builtin_amdgcn_sched_barrier(0);
             T256_PIN(acc[2][1]);
             T256_PIN(acc[3][1]);
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb[1][ks], acc[2][1], 0, 0, 0);
@@ -236,19 +242,19 @@ __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_i
             }
             T256_PIN(acc[2][1]);
             T256_PIN(acc[3][1]);
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // ---- phase 3: tokens half 1 x weights half 0 (both fragment sets are in registers)
             issue_w(0);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // X0 and W0 of the next stage
+            if (!WAIT_LATE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // X0 and W0 of the next stage
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             T256_PIN(acc[2][0]);
             T256_PIN(acc[3][0]);
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb[0][ks], acc[2][0], 0, 0, 0);
@@ -256,7 +262,8 @@ __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_i
             }
             T256_PIN(acc[2][0]);
             T256_PIN(acc[3][0]);
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if (WAIT_LATE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);

@@ -34,6 +34,10 @@
  *                  separate scalar float; (c) ggml_vec_dot_f16's F16C branch for the two attention
  *                  products — 4 accumulators of 8 f32 lanes, fma, pairwise reduce.  Everything else (rms_norm,
  *                  rope, soft_max, silu table, adds) is scalar code in both builds.
+ *   mode 3 "avx2":  mode 2 executed with the intrinsics themselves (_mm256_maddubs_epi16 / _mm256_madd_epi16 block dots,
+ *                  _mm256_fmadd_ps lanes, _mm256_round_ps quantizers, F16C vec_dot_f16) — the code shape of upstream's
+ *                  `#elif defined(__AVX2__)` branches, i.e. what the reference's build executes on this host.  Bit-identical
+ *                  to mode 2 (tests/test_oracle.py); it exists to be TIMED (bench.py cpu_baseline, kind "port-avx2").
  *   mode 1 "math":  dequantized weights × f32 activations, f64 accumulation, exact expf — the
  *           yardstick that says how much of a difference is activation-quantization noise.
  *
@@ -47,6 +51,10 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+#if defined(__AVX2__) && defined(__FMA__) && defined(__F16C__)
+#include <immintrin.h>
+#define ORC_HAVE_AVX2 1
 #endif
 
 #define QK 32
@@ -931,12 +939,209 @@ static float vec_dot_f16_simd(int64_t n, const float *x /* f16 values as f32 */,
     for (int64_t i = np; i < n; i++) sumf += (double)(x[i] * y[i]);
     return (float)sumf;
 }
+
+#ifdef ORC_HAVE_AVX2
+/* ---- mode 3: upstream's AVX2 branch written with the intrinsics (helpers named as in ggml.c) ----------------------- */
+static inline float hsum_float_8_avx(const __m256 x) {
+    __m128 res = _mm256_extractf128_ps(x, 1);
+    res = _mm_add_ps(res, _mm256_castps256_ps128(x));
+    res = _mm_add_ps(res, _mm_movehl_ps(res, res));
+    res = _mm_add_ss(res, _mm_movehdup_ps(res));
+    return _mm_cvtss_f32(res);
+}
+static inline int hsum_i32_8_avx(const __m256i a) {
+    const __m128i sum128 = _mm_add_epi32(_mm256_castsi256_si128(a), _mm256_extractf128_si256(a, 1));
+    const __m128i hi64 = _mm_unpackhi_epi64(sum128, sum128);
+    const __m128i sum64 = _mm_add_epi32(hi64, sum128);
+    const __m128i hi32 = _mm_shuffle_epi32(sum64, _MM_SHUFFLE(2, 3, 0, 1));
+    return _mm_cvtsi128_si32(_mm_add_epi32(sum64, hi32));
+}
+static inline __m256i bytes_from_nibbles_32(const uint8_t *rsi) {
+    const __m128i tmp = _mm_loadu_si128((const __m128i *)rsi);
+    const __m256i bytes = _mm256_set_m128i(_mm_srli_epi16(tmp, 4), tmp);
+    return _mm256_and_si256(_mm256_set1_epi8(0xF), bytes);
+}
+static inline __m256i bytes_from_bits_32(const uint8_t *x) {
+    uint32_t x32;
+    memcpy(&x32, x, sizeof(uint32_t));
+    const __m256i shuf_mask = _mm256_set_epi64x(0x0303030303030303, 0x0202020202020202, 0x0101010101010101, 0x0000000000000000);
+    __m256i bytes = _mm256_shuffle_epi8(_mm256_set1_epi32((int)x32), shuf_mask);
+    const __m256i bit_mask = _mm256_set1_epi64x(0x7fbfdfeff7fbfdfe);
+    bytes = _mm256_or_si256(bytes, bit_mask);
+    return _mm256_cmpeq_epi8(bytes, _mm256_set1_epi64x(-1));
+}
+static inline __m256 sum_i16_pairs_float(const __m256i x) {
+    const __m256i summed_pairs = _mm256_madd_epi16(_mm256_set1_epi16(1), x);
+    return _mm256_cvtepi32_ps(summed_pairs);
+}
+static inline __m256 mul_sum_us8_pairs_float(const __m256i ax, const __m256i sy) {
+    return sum_i16_pairs_float(_mm256_maddubs_epi16(ax, sy));
+}
+static inline __m256 mul_sum_i8_pairs_float(const __m256i x, const __m256i y) {
+    const __m256i ax = _mm256_sign_epi8(x, x);
+    const __m256i sy = _mm256_sign_epi8(y, x);
+    return mul_sum_us8_pairs_float(ax, sy);
+}
+/* GGML_FP16_TO_FP32 under -mf16c: _cvtsh_ss (same values as fp16_to_fp32: both are exact) */
+static inline float f16c_to_f32(fp16_t h) { return _cvtsh_ss(h); }
+static float vec_dot_avx2(int type, int n, const void *vx, const void *vy) {
+    const int nb = n / QK;
+    __m256 acc = _mm256_setzero_ps();
+    float summs = 0.0f;
+    switch (type) {
+        case T_Q4_0: {
+            const block_q4_0 *x = (const block_q4_0 *)vx;
+            const block_q8_0 *y = (const block_q8_0 *)vy;
+            for (int i = 0; i < nb; ++i) {
+                const __m256 d = _mm256_set1_ps(f16c_to_f32(x[i].d) * f16c_to_f32(y[i].d));
+                __m256i bx = bytes_from_nibbles_32(x[i].qs);
+                bx = _mm256_sub_epi8(bx, _mm256_set1_epi8(8));
+                const __m256i by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                acc = _mm256_fmadd_ps(d, mul_sum_i8_pairs_float(bx, by), acc);
+            }
+        } break;
+        case T_Q4_1: {
+            const block_q4_1 *x = (const block_q4_1 *)vx;
+            const block_q8_1 *y = (const block_q8_1 *)vy;
+            for (int i = 0; i < nb; ++i) {
+                const float d0 = f16c_to_f32(x[i].d), d1 = y[i].d;
+                summs += f16c_to_f32(x[i].m) * y[i].s;
+                const __m256 d0d1 = _mm256_mul_ps(_mm256_set1_ps(d0), _mm256_set1_ps(d1));
+                const __m256i bx = bytes_from_nibbles_32(x[i].qs);
+                const __m256i by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                acc = _mm256_fmadd_ps(d0d1, mul_sum_us8_pairs_float(bx, by), acc);
+            }
+        } break;
+        case T_Q5_0: {
+            const block_q5_0 *x = (const block_q5_0 *)vx;
+            const block_q8_0 *y = (const block_q8_0 *)vy;
+            for (int i = 0; i < nb; ++i) {
+                const __m256 d = _mm256_set1_ps(f16c_to_f32(x[i].d) * f16c_to_f32(y[i].d));
+                __m256i bx = bytes_from_nibbles_32(x[i].qs);
+                __m256i bxhi = bytes_from_bits_32(x[i].qh);
+                bxhi = _mm256_andnot_si256(bxhi, _mm256_set1_epi8((char)0xF0));
+                bx = _mm256_or_si256(bx, bxhi);
+                const __m256i by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                acc = _mm256_fmadd_ps(d, mul_sum_i8_pairs_float(bx, by), acc);
+            }
+        } break;
+        case T_Q5_1: {
+            const block_q5_1 *x = (const block_q5_1 *)vx;
+            const block_q8_1 *y = (const block_q8_1 *)vy;
+            for (int i = 0; i < nb; ++i) {
+                const __m256 dx = _mm256_set1_ps(f16c_to_f32(x[i].d));
+                summs += f16c_to_f32(x[i].m) * y[i].s;
+                __m256i bx = bytes_from_nibbles_32(x[i].qs);
+                __m256i bxhi = bytes_from_bits_32(x[i].qh);
+                bxhi = _mm256_and_si256(bxhi, _mm256_set1_epi8(0x10));
+                bx = _mm256_or_si256(bx, bxhi);
+                const __m256 dy = _mm256_set1_ps(y[i].d);
+                const __m256i by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                acc = _mm256_fmadd_ps(mul_sum_us8_pairs_float(bx, by), _mm256_mul_ps(dx, dy), acc);
+            }
+        } break;
+        case T_Q8_0: {
+            const block_q8_0 *x = (const block_q8_0 *)vx;
+            const block_q8_0 *y = (const block_q8_0 *)vy;
+            for (int i = 0; i < nb; ++i) {
+                const __m256 d = _mm256_set1_ps(f16c_to_f32(x[i].d) * f16c_to_f32(y[i].d));
+                const __m256i bx = _mm256_loadu_si256((const __m256i *)x[i].qs);
+                const __m256i by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                acc = _mm256_fmadd_ps(d, mul_sum_i8_pairs_float(bx, by), acc);
+            }
+        } break;
+        default: fprintf(stderr, "vec_dot_avx2: bad type %d\n", type); abort();
+    }
+    return hsum_float_8_avx(acc) + summs;
+}
+/* quantize_row_q8_0 / q8_1, AVX2 branch */
+static void quantize_row_q8_avx2_intr(const float *x, void *vy, int k, int q81) {
+    const int nb = k / QK;
+    block_q8_0 *y0 = (block_q8_0 *)vy;
+    block_q8_1 *y1 = (block_q8_1 *)vy;
+    for (int i = 0; i < nb; i++) {
+        __m256 v0 = _mm256_loadu_ps(x), v1 = _mm256_loadu_ps(x + 8), v2 = _mm256_loadu_ps(x + 16), v3 = _mm256_loadu_ps(x + 24);
+        x += 32;
+        const __m256 signBit = _mm256_set1_ps(-0.0f);
+        __m256 maxAbs = _mm256_andnot_ps(signBit, v0);
+        maxAbs = _mm256_max_ps(maxAbs, _mm256_andnot_ps(signBit, v1));
+        maxAbs = _mm256_max_ps(maxAbs, _mm256_andnot_ps(signBit, v2));
+        maxAbs = _mm256_max_ps(maxAbs, _mm256_andnot_ps(signBit, v3));
+        __m128 max4 = _mm_max_ps(_mm256_extractf128_ps(maxAbs, 1), _mm256_castps256_ps128(maxAbs));
+        max4 = _mm_max_ps(max4, _mm_movehl_ps(max4, max4));
+        max4 = _mm_max_ss(max4, _mm_movehdup_ps(max4));
+        const float maxScalar = _mm_cvtss_f32(max4);
+        const float d = maxScalar / 127.f;
+        const float id = (maxScalar != 0.0f) ? 127.f / maxScalar : 0.0f;
+        const __m256 mul = _mm256_set1_ps(id);
+        v0 = _mm256_round_ps(_mm256_mul_ps(v0, mul), _MM_ROUND_NEAREST);
+        v1 = _mm256_round_ps(_mm256_mul_ps(v1, mul), _MM_ROUND_NEAREST);
+        v2 = _mm256_round_ps(_mm256_mul_ps(v2, mul), _MM_ROUND_NEAREST);
+        v3 = _mm256_round_ps(_mm256_mul_ps(v3, mul), _MM_ROUND_NEAREST);
+        __m256i i0 = _mm256_cvtps_epi32(v0), i1 = _mm256_cvtps_epi32(v1), i2 = _mm256_cvtps_epi32(v2), i3 = _mm256_cvtps_epi32(v3);
+        if (q81) {
+            y1[i].d = d;
+            y1[i].s = d * (float)hsum_i32_8_avx(_mm256_add_epi32(_mm256_add_epi32(i0, i1), _mm256_add_epi32(i2, i3)));
+        } else {
+            y0[i].d = fp32_to_fp16(d);
+        }
+        i0 = _mm256_packs_epi32(i0, i1);
+        i2 = _mm256_packs_epi32(i2, i3);
+        i0 = _mm256_packs_epi16(i0, i2);
+        const __m256i perm = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7);
+        i0 = _mm256_permutevar8x32_epi32(i0, perm);
+        _mm256_storeu_si256((__m256i *)(q81 ? y1[i].qs : y0[i].qs), i0);
+    }
+}
+/* ggml_vec_dot_f16, GGML_SIMD branch (F16C): both operands are fp16 arrays */
+static float vec_dot_f16_avx2(int64_t n, const fp16_t *x, const fp16_t *y) {
+    __m256 sum[4] = {_mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps()};
+    const int64_t np = n & ~(int64_t)31;
+    for (int64_t i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; j++) {
+            const __m256 ax = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(x + i + j * 8)));
+            const __m256 ay = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(y + i + j * 8)));
+            sum[j] = _mm256_fmadd_ps(ax, ay, sum[j]);
+        }
+    sum[0] = _mm256_add_ps(sum[0], sum[2]);
+    sum[1] = _mm256_add_ps(sum[1], sum[3]);
+    sum[0] = _mm256_add_ps(sum[0], sum[1]);
+    const __m128 t0 = _mm_add_ps(_mm256_castps256_ps128(sum[0]), _mm256_extractf128_ps(sum[0], 1));
+    const __m128 t1 = _mm_hadd_ps(t0, t0);
+    double sumf = (double)_mm_cvtss_f32(_mm_hadd_ps(t1, t1));
+    for (int64_t i = np; i < n; i++) sumf += (double)(fp16_to_fp32(x[i]) * fp16_to_fp32(y[i]));
+    return (float)sumf;
+}
+#endif /* ORC_HAVE_AVX2 */
+EXPORT int orc_have_avx2(void) {
+#ifdef ORC_HAVE_AVX2
+    return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma") && __builtin_cpu_supports("f16c");
+#else
+    return 0;
+#endif
+}
 EXPORT float orc_vec_dot_simd(int type, int n, const void *x, const void *y) { return vec_dot_simd(type, n, x, y); }
+EXPORT float orc_vec_dot_avx2(int type, int n, const void *x, const void *y) {
+#ifdef ORC_HAVE_AVX2
+    return vec_dot_avx2(type, n, x, y);
+#else
+    return vec_dot_simd(type, n, x, y);
+#endif
+}
 EXPORT void orc_quantize_row(int type, const float *x, void *y, int k);
 EXPORT void orc_quantize_row_simd(int type, const float *x, void *y, int k) {
     if (type == T_Q8_0) quantize_row_q8_0_avx2(x, (block_q8_0 *)y, k);
     else if (type == T_Q8_1) quantize_row_q8_1_avx2(x, (block_q8_1 *)y, k);
     else orc_quantize_row(type, x, y, k);
+}
+EXPORT void orc_quantize_row_avx2(int type, const float *x, void *y, int k) {
+#ifdef ORC_HAVE_AVX2
+    if (type == T_Q8_0 || type == T_Q8_1) {
+        quantize_row_q8_avx2_intr(x, y, k, type == T_Q8_1);
+        return;
+    }
+#endif
+    orc_quantize_row_simd(type, x, y, k);
 }
 
 EXPORT float orc_vec_dot(int type, int n, const void *x, const void *y) {
@@ -961,12 +1166,13 @@ EXPORT void orc_mul_mat(int type, const void *A, int64_t M, int64_t K, const flo
                         float *dst, int mode) {
     const size_t row_bytes = (size_t)(K / orc_blck_size(type)) * (size_t)orc_type_size(type);
     if (mode != 1 && type != T_F32) {
-        const int simd = mode == 2 && type != T_F16 && type != T_Q4_K && type != T_Q6_K;
+        const int simd = (mode == 2 || mode == 3) && type != T_F16 && type != T_Q4_K && type != T_Q6_K;
+        const int intr = simd && mode == 3;
         const int vdt = orc_vec_dot_type(type);
         const size_t qrow = (size_t)(K / orc_blck_size(vdt)) * (size_t)orc_type_size(vdt);
         uint8_t *wdata = (uint8_t *)malloc(qrow * (size_t)N); /* ggml: cplan.work_data, INIT phase */
         for (int64_t n = 0; n < N; n++)
-            (simd ? orc_quantize_row_simd : orc_quantize_row)(vdt, B + n * ldb, wdata + (size_t)n * qrow, (int)K);
+            (intr ? orc_quantize_row_avx2 : simd ? orc_quantize_row_simd : orc_quantize_row)(vdt, B + n * ldb, wdata + (size_t)n * qrow, (int)K);
 #pragma omp parallel for schedule(static)
         for (int64_t m = 0; m < M; m++) {
             const uint8_t *a = (const uint8_t *)A + (size_t)m * row_bytes;
@@ -980,7 +1186,7 @@ EXPORT void orc_mul_mat(int type, const void *A, int64_t M, int64_t K, const flo
                     for (int64_t k = 0; k < K; k++) s += (double)(fp16_to_fp32(x[k]) * fp16_to_fp32(y[k]));
                     r = (float)s;
                 } else {
-                    r = simd ? vec_dot_simd(type, (int)K, a, b) : orc_vec_dot(type, (int)K, a, b);
+                    r = intr ? orc_vec_dot_avx2(type, (int)K, a, b) : simd ? vec_dot_simd(type, (int)K, a, b) : orc_vec_dot(type, (int)K, a, b);
                 }
                 dst[n * M + m] = r;
             }
@@ -1243,10 +1449,21 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
                 const float *qrow = q + ((size_t)n * H + h) * D;
                 float qh[512]; /* D <= 512 */
                 for (int64_t d = 0; d < D; d++) qh[d] = mode != 1 ? fp16_to_fp32(fp32_to_fp16(qrow[d])) : qrow[d];
+#ifdef ORC_HAVE_AVX2
+                fp16_t q16[512];
+                if (mode == 3)
+                    for (int64_t d = 0; d < D; d++) q16[d] = fp32_to_fp16(qrow[d]);
+#endif
                 for (int64_t t = 0; t < T; t++) {
                     const fp16_t *krow = m->memory_k + ((size_t)il * C + t) * Egqa + hk * D;
                     double s = 0.0;
-                    if (mode == 2) {
+#ifdef ORC_HAVE_AVX2
+                    if (mode == 3) {
+                        kq[((size_t)h * N + n) * T + t] = vec_dot_f16_avx2(D, krow, q16);
+                        continue;
+                    }
+#endif
+                    if (mode == 2 || mode == 3) {
                         float kf[512];
                         for (int64_t d = 0; d < D; d++) kf[d] = fp16_to_fp32(krow[d]);
                         s = (double)vec_dot_f16_simd(D, kf, qh);
@@ -1268,10 +1485,23 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
             for (int64_t n = 0; n < N; n++) {
                 const int64_t hk = h / (H / Hkv);
                 const float *prow = kq + ((size_t)h * N + n) * T;
+#ifdef ORC_HAVE_AVX2
+                fp16_t *p16 = NULL;
+                if (mode == 3) {
+                    p16 = (fp16_t *)malloc((size_t)T * 2 + 64);
+                    for (int64_t t = 0; t < T; t++) p16[t] = fp32_to_fp16(prow[t]);
+                }
+#endif
                 for (int64_t d = 0; d < D; d++) {
                     const fp16_t *vrow = m->memory_v + (size_t)il * C * Egqa + (size_t)(hk * D + d) * C;
                     double s = 0.0;
-                    if (mode == 2) {
+#ifdef ORC_HAVE_AVX2
+                    if (mode == 3) {
+                        kqv[((size_t)n * H + h) * D + d] = vec_dot_f16_avx2(T, vrow, p16);
+                        continue;
+                    }
+#endif
+                    if (mode == 2 || mode == 3) {
                         float *vf = (float *)malloc((size_t)T * 8), *pf = vf + T;
                         for (int64_t t = 0; t < T; t++) {
                             vf[t] = fp16_to_fp32(vrow[t]);
@@ -1287,6 +1517,9 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
                     }
                     kqv[((size_t)n * H + h) * D + d] = (float)s;
                 }
+#ifdef ORC_HAVE_AVX2
+                free(p16);
+#endif
             }
         }
         /* out proj + residual (:310-314) */

@@ -57,6 +57,10 @@ def lib():
         L.orc_vec_dot_simd.restype = C.c_float
         L.orc_vec_dot_simd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_quantize_row_simd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_vec_dot_avx2.restype = C.c_float
+        L.orc_vec_dot_avx2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_quantize_row_avx2.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_have_avx2.restype = C.c_int
         L.orc_mul_mat.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_int]
         L.orc_rms_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float]
@@ -113,14 +117,20 @@ def quantize(t, x, k=None):
 
 def quantize_row(t, x, simd=False):
     """quantize_row_q*; simd=True: the AVX2 branch's arithmetic for Q8_0 / Q8_1 (id = 127/amax, round-half-even),
-    i.e. the activation quantizer of oracle mode 2."""
+    i.e. the activation quantizer of oracle mode 2; simd="avx2": the same with the intrinsics (mode 3)."""
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
     out = np.zeros(row_bytes(t, x.size), dtype=np.uint8)
-    (lib().orc_quantize_row_simd if simd else lib().orc_quantize_row)(t, _p(x), _p(out), x.size)
+    f = lib().orc_quantize_row_avx2 if simd == "avx2" else lib().orc_quantize_row_simd if simd else lib().orc_quantize_row
+    f(t, _p(x), _p(out), x.size)
     return out
 
 
-MODE_SCALAR, MODE_MATH, MODE_AVX2 = 0, 1, 2  # see the header of ggml_oracle.c
+MODE_SCALAR, MODE_MATH, MODE_AVX2, MODE_AVX2_INTRINSICS = 0, 1, 2, 3  # see the header of ggml_oracle.c
+
+
+def have_avx2():
+    """True when mode 3 really runs the AVX2 / FMA / F16C intrinsics (built with them and the host has them)."""
+    return bool(lib().orc_have_avx2())
 
 
 def dequantize(t, raw, n):

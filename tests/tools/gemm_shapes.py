@@ -8,6 +8,11 @@ from llm_amd import ggml as G
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 SHAPES = [("wq|wk|wv", 12288, 4096, 2), ("wo", 4096, 4096, 2), ("w1|w3", 22016, 4096, 1), ("w2", 4096, 11008, 2),
           ("lm_head", 32000, 4096, 1)]
+if len(sys.argv) > 2 and sys.argv[2] == "big":
+    SHAPES = [("4096^3", 4096, 4096, 1), ("8192x4096", 8192, 4096, 1)]
+VARIANTS = (("t256", {"mmq_t256": 2}), ("t256 late-wait", {"mmq_t256": 2, "mmq_t256_var": 1}), ("t256 no-prio", {"mmq_t256": 2, "mmq_t256_var": 2}),
+            ("w16_128", {"mmq_t256": 0}), ("dma_p8", {"mmq_t256": 0, "mmq_w16": 0}))
+RESET = {"mmq_t256": 1, "mmq_t256_var": 0, "mmq_w16": 1}
 L = G.lib()
 rng = np.random.default_rng(1)
 for name, M, K, sp in SHAPES:
@@ -27,7 +32,7 @@ for name, M, K, sp in SHAPES:
         y = ctx.op_mul_mat(w, x)
         g = ctx.graph().build_forward_expand(y)
         line = f"{name:9s} M={M:6d} K={K:6d} N={N} splits={sp}:"
-        for label, opts in (("t256", {"mmq_t256": 2}), ("w16_128", {"mmq_t256": 0}), ("dma_p8", {"mmq_t256": 0, "mmq_w16": 0})):
+        for label, opts in VARIANTS:
             G.set_option("mmq_splits", sp)
             for k, v in opts.items():
                 G.set_option(k, v)
@@ -40,7 +45,7 @@ for name, M, K, sp in SHAPES:
                 if it >= 1:
                     best = min(best, ms)
             for k in opts:
-                G.set_option(k, 1)
+                G.set_option(k, RESET[k])
             G.set_option("mmq_splits", 0)
-            line += f"  {label} {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF"
+            line += f"\n      {label:15s} {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF"
         print(line, flush=True)
