@@ -175,14 +175,21 @@ def parity_check(args, hp, w, sess):
     rms = float(np.sqrt(np.mean((got - ref) ** 2))) / std
     band = float(np.max(np.abs(ref - rev))) / std
     floor = float(np.max(np.abs(ref - mth))) / std
+    # K/V rows the token wrote: layer 0 depends on the embedding and wk / wv only (must agree up to a last-bit rounding of a few
+    # halves); deeper layers of a random-init model amplify a last-bit difference chaotically (that is what `band` measures)
+    Eg = hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])
+    kg, ko = k2[n_past * Eg:(n_past + 1) * Eg], orcs[0].memory_k[n_past * Eg:(n_past + 1) * Eg]
+    vg, vo = v2[:ctx * Eg].reshape(Eg, ctx)[:, n_past], orcs[0].memory_v[:ctx * Eg].reshape(Eg, ctx)[:, n_past]
+    nk0 = int(np.count_nonzero(kg != ko)) + int(np.count_nonzero(vg != vo))
     nk = int(np.count_nonzero(k2 != orcs[0].memory_k)) + int(np.count_nonzero(v2 != orcs[0].memory_v))
     bound = max(PARITY_EDGE, 2.0 * band)
-    ok = d <= bound and d <= max(floor, PARITY_EDGE)
+    ok = d <= bound and d <= max(floor, PARITY_EDGE) and nk0 <= 0.01 * 2 * Eg
     out = {"max_over_std": float(f"{d:.3e}"), "rms_over_std": float(f"{rms:.3e}"),
            "argmax_equal": bool(int(np.argmax(got)) == int(np.argmax(ref))),
            "oracle_fwd_vs_rev_band_over_std": float(f"{band:.3e}"), "oracle_exact_vs_math_floor_over_std": float(f"{floor:.3e}"),
            "bound_over_std": float(f"{bound:.3e}"), "passed": bool(ok),
-           "kv_halves_written_that_differ": nk, "kv_halves_written": int(2 * hp["n_layer"] * hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])),
+           "kv_layer0_halves_that_differ": nk0, "kv_layer0_halves_written": int(2 * Eg),
+           "kv_all_layers_halves_that_differ": nk, "kv_all_layers_halves_written": int(2 * hp["n_layer"] * Eg),
            "n_past": int(n_past),
            "oracle": "oracle/ggml_oracle.c mode 0 (ggml scalar path restated; parity unpinned, DESIGN.md section 5)",
            "oracle_s": round(ref_s, 2),

@@ -48,6 +48,7 @@
 #include "kernels/decode_big8.h"
 #include "kernels/decode_attn_split.h"
 #include "kernels/prompt.h"
+#include "kernels/prompt_attn.h"
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -146,6 +147,7 @@ struct Backend {
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
+    int opt_attn_fused = 1;  // prompt plan: K.Q, softmax and V.P as one launch with the scores in LDS (kernels/prompt_attn.h)
     int opt_plan_prompt = 1; // fused plan for prompt batches of >= mmq_min tokens (kernels/prompt.h)
     int opt_mmq_persist = 1; // prompt GEMM as a persistent kernel (kernels/mmq_dmap.h)
     int opt_mmq_w16 = 1;     // prompt GEMM on resident f16 copies of the quantized weights when HBM has room (kernels/mmq_w16.h)
@@ -223,6 +225,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_BIG")) g.opt_big = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN_MULTI")) g.opt_plan_multi = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN_PROMPT")) g.opt_plan_prompt = atoi(v);
+    if (const char *v = getenv("GGML_HIP_ATTN_FUSED")) g.opt_attn_fused = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_FUSE")) g.opt_mmq_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_PERSIST")) g.opt_mmq_persist = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_WAVES")) g.opt_mmq_waves = atoi(v);
@@ -2417,6 +2420,8 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_w16_headroom_gb = value;
     else if (k == "w16_release")  // drop the resident f16 weight copies now (they come back with the next prompt batch)
         release_w16_copies();
+    else if (k == "attn_fused")
+        g.opt_attn_fused = value;
     else if (k == "plan_prompt") {
         if (g.opt_plan_prompt != value) drop_all_plans();
         g.opt_plan_prompt = value;

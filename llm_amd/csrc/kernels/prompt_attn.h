@@ -1,0 +1,161 @@
+// prompt_attn.h — attention of a prompt batch in ONE launch: K.Q, scale + causal mask + softmax and V.P with the scores kept
+// in LDS (crates/models/llama/src/lib.rs:246-299: mul_mat(K, Q) -> scale -> diag_mask_inf -> soft_max -> mul_mat(V, P) ->
+// permute -> cpy, 7 graph nodes per layer).  The prompt plan ran them as three launches that moved the [H][N][T] scores
+// through HBM twice (k_gemm_f16, k_p_soft_max, k_gemm_f16_b16: ~70 us of a 7B layer's ~480 at N = 512).
+//
+// ggml's softmax fixes its rounding points (row max first, e = f16(exp(f16(s*scale - max))), exact f64 sum, p = e * (1/sum),
+// src1 of the V mat-mul rounded to f16), so this is not an online-softmax kernel: a workgroup owns 32 queries of one head,
+// computes ALL their scores into LDS (32 rows x T f32), runs the row softmax there exactly as k_p_soft_max does, overwrites
+// each row in place with its f16 probabilities and multiplies by V.  Both products use v_mfma_f32_32x32x16_f16 with the
+// operand roles and k order of k_gemm_f16 (A = queries, B = keys / value channels, 16 k per instruction, ascending), so
+// the result is bit-identical to the three-launch path (tests/test_prompt_plan_gpu.py).
+//
+//   grid = (ceil(N / 32) * H), 256 threads.  Dynamic LDS = 32 x (Tp * 4 + 16) bytes, Tp = (n_past + N) rounded up to 64.
+//   S phase: wave w takes key tiles w, w+4, ... of 32 keys (8 MFMAs for D = 128), K fragments straight from global / L2,
+//            the next tile's fragments requested before the current tile's MFMAs.
+//   softmax: wave w takes rows 8w .. 8w+7.
+//   V.P    : wave w takes value channels 32w .. 32w+31 (D / 32 waves), V^T fragments from global, P fragments from LDS.
+#pragma once
+#include "gemm_f16.h"
+
+struct PAttnArgs {
+    const float *q;      // [N][E] f32, RoPE applied
+    const __half *mem_k; // this layer: [C][Egqa]
+    const __half *mem_v; // this layer: [Egqa][C]
+    float *out;          // [N][E] f32, merged heads
+    int N, E, Egqa, H, r, n_past;
+    int64_t C;
+    float scale;
+    int row_bytes;       // LDS bytes per score row
+};
+
+#define PATTN_Q 32
+
+template <int D>
+__global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KS = D / 16;      // MFMA k steps of a K.Q tile
+    constexpr int NWV = D / 32;     // waves that take part in V.P
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ntile = (a.N + PATTN_Q - 1) / PATTN_Q;
+    const int h = (int)blockIdx.x % a.H, qt = ntile - 1 - (int)blockIdx.x / a.H;  // the longest rows first
+    const int hk = h / a.r;
+    const int q0 = qt * PATTN_Q;
+    const int Ttot = a.n_past + a.N;                        // keys written so far
+    const int T_hi = min(a.n_past + q0 + PATTN_Q, Ttot);    // keys 0 .. T_hi - 1 are visible to some query of the tile
+    const int nkt = (T_hi + 31) >> 5;
+    const int rb = a.row_bytes;
+
+    // ---- Q fragments (A operand): row fr of the tile, 8 channels per k step and lane half
+    f16x8 qa[KS];
+    {
+        const int qn = min(q0 + fr, a.N - 1);
+        const float *qp = a.q + (int64_t)qn * a.E + h * D + fh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const f32x4_u x0 = *(const f32x4_u *)(qp + ks * 16), x1 = *(const f32x4_u *)(qp + ks * 16 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                qa[ks][e] = (_Float16)x0[e];
+                qa[ks][4 + e] = (_Float16)x1[e];
+            }
+        }
+    }
+    // ---- S phase
+    auto load_k = [&](int kt, f16x8 (&kb)[KS]) {
+        const int64_t t = min((int64_t)kt * 32 + fr, a.C - 1);
+        const __half *kp = a.mem_k + t * a.Egqa + hk * D + fh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) kb[ks] = *(const f16x8 *)(kp + ks * 16);
+    };
+    {
+        f16x8 kb[2][KS];
+        if (wave < nkt) load_k(wave, kb[0]);
+        int cur = 0;
+        for (int kt = wave; kt < nkt; kt += 4) {
+            // two named buffers: the index is made static by unrolling the pair
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if (half == cur) {
+                    if (kt + 4 < nkt) load_k(kt + 4, kb[half ^ 1]);
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kb[half][ks], acc, 0, 0, 0);
+                    float *sp = (float *)(lds + 4 * fh * rb) + kt * 32 + fr;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) *(float *)((char *)sp + ((r & 3) + 8 * (r >> 2)) * rb) = acc[r];
+                }
+            }
+            cur ^= 1;
+        }
+    }
+    __syncthreads();
+    // ---- softmax: the operations of k_p_soft_max, row by row; the row is then overwritten with its f16 probabilities
+    const int npad = ((T_hi + 15) >> 4) << 4;  // V.P reads whole 16-key chunks: zeros behind the last visible key
+    for (int rr = 0; rr < 8; rr++) {
+        const int row = wave * 8 + rr;
+        if (q0 + row >= a.N) break;  // ragged last tile (wave-uniform)
+        float *p = (float *)(lds + row * rb);
+        const int lim = a.n_past + q0 + row;  // keys > lim are masked
+        float mx = -INFINITY;
+        for (int i = lane; i <= lim; i += 64) mx = fmaxf(mx, p[i] * a.scale);
+        mx = wave_max_f32(mx);
+        double sum = 0.0;
+        for (int i = lane; i <= lim; i += 64) {
+            const float e = round_f16(expf(round_f16(p[i] * a.scale - mx)));
+            sum += (double)e;
+            p[i] = e;
+        }
+        sum = wave_sum_f64(sum);
+        const float inv = (float)(1.0 / sum);
+        _Float16 *p16 = (_Float16 *)p;
+        for (int i0 = 0; i0 < npad; i0 += 64) {  // f16 element i lands on f32 element i / 2, which this wave read in an earlier
+            const int i = i0 + lane;             // (or this) iteration: LDS operations of a wave execute in order
+            const float e = i <= lim ? p[i] : 0.0f;
+            if (i < npad) p16[i] = (_Float16)(e * inv);
+        }
+    }
+    __syncthreads();
+    // ---- V.P
+    if (wave < NWV) {
+        const int nch = npad >> 4;
+        const int d0 = wave * 32;
+        const __half *vp = a.mem_v + ((int64_t)hk * D + d0 + fr) * a.C + fh * 8;
+        const char *pa = lds + fr * rb + fh * 16;
+        auto load_v = [&](int c) {
+            u32x4 v = *(const u32x4 *)(vp + c * 16);
+            const int valid = Ttot - (c * 16 + fh * 8);  // the cache beyond the last written key may hold anything
+            if (valid < 8) v = gf16_mask_tail(v, valid < 0 ? 0 : valid);
+            return __builtin_bit_cast(f16x8, v);
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        constexpr int PF = 4;  // chunks in flight
+        f16x8 vb[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++)
+            if (k < nch) vb[k] = load_v(k);
+        for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                if (c0 + k < nch) {
+                    const f16x8 pf = *(const f16x8 *)(pa + (c0 + k) * 32);
+                    const f16x8 v = vb[k];
+                    if (c0 + k + PF < nch) vb[k] = load_v(c0 + k + PF);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, v, acc, 0, 0, 0);
+                }
+            }
+        }
+        float *op = a.out + (int64_t)(q0 + 4 * fh) * a.E + h * D + d0 + fr;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2);
+            if (q0 + 4 * fh + row < a.N) op[(int64_t)row * a.E] = acc[r];
+        }
+    }
+}

@@ -167,12 +167,17 @@ def test_c3_decode_full_size_7b_gaussian_at_the_bench_operating_point(G, O):
         assert d <= 2 * band + 1e-5 and d <= max(floor, 1e-5), (d, band, floor)
         if d <= 1e-3:
             assert int(np.argmax(got)) == int(np.argmax(ref))
-        k2, v2 = sess.get_kv()  # the new token's K/V rows: f16 roundings of mat-vec sums that differ in f32 summation order
-        nk = int(np.count_nonzero(k2 != orc.memory_k)) + int(np.count_nonzero(v2 != orc.memory_v))
-        dk = max(float(np.max(np.abs(k2.view(np.float16).astype(np.float32) - orc.memory_k.view(np.float16).astype(np.float32)))),
-                 float(np.max(np.abs(v2.view(np.float16).astype(np.float32) - orc.memory_v.view(np.float16).astype(np.float32)))))
-        print(f"   K/V halves that differ from the oracle's: {nk} of {2 * hp['n_layer'] * hp['n_embd']}, max |d| {dk:.2e}")
-        assert nk <= 0.05 * 2 * hp["n_layer"] * hp["n_embd"] and dk <= 2e-2
+        # the new token's K/V rows of LAYER 0 depend on the embedding and wk / wv only: f16 roundings of mat-vec sums that differ
+        # in f32 summation order at most.  (Deeper layers of this random-init model amplify a last-bit difference chaotically —
+        # that is what `band` measures — so their rows differ in most halves for ANY two legal implementations.)
+        k2, v2 = sess.get_kv()
+        C, Eg = ctx, hp["n_embd"]
+        pos = orc.n_past - 1
+        krow_g, krow_o = k2[pos * Eg:(pos + 1) * Eg], orc.memory_k[pos * Eg:(pos + 1) * Eg]
+        vcol_g, vcol_o = v2[:C * Eg].reshape(Eg, C)[:, pos], orc.memory_v[:C * Eg].reshape(Eg, C)[:, pos]
+        nk = int(np.count_nonzero(krow_g != krow_o)) + int(np.count_nonzero(vcol_g != vcol_o))
+        print(f"   layer-0 K/V halves of the new token that differ from the oracle's: {nk} of {2 * Eg}")
+        assert nk <= 0.01 * 2 * Eg
     assert _stat(G, "plan_tokens") - p0 == 3
     sess.free()
     model.free()

@@ -639,15 +639,20 @@ def test_gqa_split_attention_and_layer_split(G, O):
 
 
 def test_decode_plan_with_a_16k_context_needs_more_than_64k_of_lds(G, O):
-    """The decode attention keeps context_size scores + probabilities in LDS: 16384 positions need 98 KB (above the
-    64 KB a kernel gets without asking).  The plan must run (not abort inside graph capture) and match the oracle;
-    a context that cannot fit the CU's LDS at all (32768) must fall back to the generic executor, not fail."""
+    """k_attn_decode keeps the scores + probabilities of the longest row it can meet in LDS.  A prompt chunk (2..8 tokens)
+    can meet the whole context: 16384 positions need 98 KB (above the 64 KB a kernel gets without asking) — the plan must
+    run (not abort inside graph capture) and match the oracle; 32768 positions do not fit the CU's LDS at all and the chunk
+    falls back to the generic executor.  Single-token decode sizes its LDS by the split threshold (longer rows run on
+    kernels/decode_attn_split.h), so it stays on the fused plan at ANY context."""
     toks = np.random.default_rng(46).integers(0, 256, 12).astype(np.int32)
-    for ctx, on_plan in ((16384, True), (32768, False)):
+    for ctx, chunk_on_plan in ((16384, True), (32768, False)):
         hp, w, model = _mk(G, 2, ctx=ctx, seed=7)
         sess = model.start_session(n_batch=8)
         orc = O.Llama(hp, w, 64)
+        c0 = _stat(G, "plan_tokens")
         sess.feed_prompt(toks[:8])
+        assert (_stat(G, "plan_tokens") - c0 == 8) == chunk_on_plan, ctx
+        on_plan = True
         orc.evaluate(toks[:8], mode=0)
         p0 = _stat(G, "plan_tokens")
         for i in range(4):

@@ -239,3 +239,31 @@ def test_prompt_plan_with_a_k_split_on_wk_wv_only(G):
         assert np.isfinite(la).all() and np.array_equal(la, lb), float(np.max(np.abs(la - lb)))
     assert np.array_equal(ka, kb) and np.array_equal(va, vb)
     model.free()
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "gqa", "wide", "splitk"])
+def test_fused_prompt_attention_is_bit_identical_to_the_three_launch_path(G, cfg):
+    """kernels/prompt_attn.h (K.Q, scale + mask + softmax and V.P in one launch, scores in LDS) against k_gemm_f16 ->
+    k_p_soft_max -> k_gemm_f16_b16: head sizes 32 / 64 / 128, grouped-query attention, ragged batches (N % 32 != 0),
+    rows up to ~1000 keys (the LDS limit of the fused kernel is 1184), a batch beyond it (falls back to the three launches)."""
+    from llm_amd import llama, synth
+    hp0 = {"tiny": synth.TINY, "gqa": GQA, "wide": WIDE, "splitk": SPLITK}[cfg]
+    hp, w = synth.make_llama(hp0, 2, seed=21)
+    model = llama.Llama(hp, w, context_size=1536)
+    toks = np.random.default_rng(len(cfg)).integers(0, hp["n_vocab"], 1400).astype(np.int32)
+    chunks = [toks[0:70], toks[70:326], toks[326:371], toks[371:883], toks[883:1010], toks[1010:1400]]  # last: T = 1400 > limit
+    res = {}
+    for fused in (1, 0):
+        G.set_option("attn_fused", fused)
+        try:
+            sess = model.start_session(n_batch=512)
+            outs = [sess.evaluate(c) for c in chunks]
+            k, v = sess.get_kv()
+            sess.free()
+        finally:
+            G.set_option("attn_fused", 1)
+        res[fused] = (outs, k, v)
+    for i, (a, b) in enumerate(zip(res[1][0], res[0][0])):
+        assert np.array_equal(a, b), (cfg, i, float(np.max(np.abs(a - b))))
+    assert np.array_equal(res[1][1], res[0][1]) and np.array_equal(res[1][2], res[0][2])
+    model.free()
