@@ -550,6 +550,12 @@ GGML_API int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct gg
  * wall clock ticks), steps of wave 0, workgroup id}; 4 (or "timeline" = n) sampled workgroups per launch, launch order.
  * Returns the number of records copied. */
 GGML_API size_t ggml_hip_read_timeline(int64_t *dst, size_t max_records);
+/* Test hook (no reference counterpart): the attention of a prompt batch — mul_mat(K, Q), scale, diag_mask_inf, soft_max,
+ * mul_mat(V, P), merge heads (crates/models/llama/src/lib.rs:246-307) — on host arrays, through the fused kernel
+ * (fused != 0) or the three-launch path of the prompt plan.  q [N][E] f32 (RoPE applied), mem_k [C][Egqa] f16,
+ * mem_v [Egqa][C] f16, out [N][E] f32.  0 on success, -1 if the shape is not accepted. */
+GGML_API int ggml_hip_debug_prompt_attention(const float *q, const uint16_t *mem_k, const uint16_t *mem_v, float *out, int N, int E,
+                                             int Egqa, int H, int n_past, int64_t C, float scale, int fused);
 GGML_API const char *ggml_hip_version(void);
 
 #ifdef __cplusplus

@@ -46,6 +46,7 @@
 #include "kernels/decode.h"
 #include "kernels/decode_big.h"
 #include "kernels/decode_big8.h"
+#include "kernels/mmq_cols.h"
 #include "kernels/decode_attn_split.h"
 #include "kernels/prompt.h"
 #include "kernels/prompt_attn.h"
@@ -147,6 +148,7 @@ struct Backend {
     int opt_fuse = 1;
     int opt_mmvq_rows = 0;  // 0 = auto
     int opt_plan_multi = 1; // fused plan for prompt chunks of 2..8 tokens (kernels/decode_big8.h)
+    int opt_mmq_cols = 1;    // prompt chunks of 2..8 tokens: mat-muls on the integer matrix cores (kernels/mmq_cols.h) instead of k_mmvq_big8
     int opt_attn_fused = 1;  // prompt plan: K.Q, softmax and V.P as one launch with the scores in LDS (kernels/prompt_attn.h)
     int opt_plan_prompt = 1; // fused plan for prompt batches of >= mmq_min tokens (kernels/prompt.h)
     int opt_mmq_persist = 1; // prompt GEMM as a persistent kernel (kernels/mmq_dmap.h)
@@ -226,6 +228,7 @@ void ensure_init() {
     if (const char *v = getenv("GGML_HIP_PLAN_MULTI")) g.opt_plan_multi = atoi(v);
     if (const char *v = getenv("GGML_HIP_PLAN_PROMPT")) g.opt_plan_prompt = atoi(v);
     if (const char *v = getenv("GGML_HIP_ATTN_FUSED")) g.opt_attn_fused = atoi(v);
+    if (const char *v = getenv("GGML_HIP_MMQ_COLS")) g.opt_mmq_cols = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_FUSE")) g.opt_mmq_fuse = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_PERSIST")) g.opt_mmq_persist = atoi(v);
     if (const char *v = getenv("GGML_HIP_MMQ_WAVES")) g.opt_mmq_waves = atoi(v);
@@ -2420,6 +2423,10 @@ void ggml_hip_set_option(const char *key, int value) {
         g.opt_w16_headroom_gb = value;
     else if (k == "w16_release")  // drop the resident f16 weight copies now (they come back with the next prompt batch)
         release_w16_copies();
+    else if (k == "mmq_cols") {
+        if (g.opt_mmq_cols != value) drop_all_plans();
+        g.opt_mmq_cols = value;
+    }
     else if (k == "attn_fused")
         g.opt_attn_fused = value;
     else if (k == "plan_prompt") {
@@ -2722,6 +2729,42 @@ int ggml_hip_bench_empty(int wgs, int threads, int lds_bytes, int kernarg_bytes,
     HIP_CHECK(hipGraphExecDestroy(ex));
     HIP_CHECK(hipGraphDestroy(gr));
     HIP_CHECK(hipFree(ts));
+    return 0;
+}
+
+// Test hook: the attention of a prompt batch on host arrays through either path of the prompt plan (llama_plan.inc
+// prompt_attention): q [N][E] f32 with RoPE applied, mem_k [C][Egqa] / mem_v [Egqa][C] f16 of one layer, out [N][E] f32.
+// Returns 0, or -1 when `fused` is asked for a shape the fused kernel does not take.
+int ggml_hip_debug_prompt_attention(const float *q, const uint16_t *mem_k, const uint16_t *mem_v, float *out, int N, int E, int Egqa,
+                                    int H, int n_past, int64_t C, float scale, int fused) {
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    ensure_init();
+    finish_pending();
+    const int64_t D = E / H, Hkv = Egqa / D, T = (int64_t)n_past + N, Tp = (T + 7) & ~(int64_t)7;
+    if (T > C || (fused && !prompt_attn_fits(D, T))) return -1;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_f16, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_f16_b16, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
+        attr = true;
+    }
+    char *dq, *dk, *dv, *dout, *dsc, *dp;
+    const size_t nq = (size_t)N * E * 4, nkv = (size_t)C * Egqa * 2, nsc = (size_t)H * N * T * 4, np = (size_t)H * N * Tp * 2;
+    dev_malloc((void **)&dq, nq, "debug q");
+    dev_malloc((void **)&dk, nkv, "debug k");
+    dev_malloc((void **)&dv, nkv, "debug v");
+    dev_malloc((void **)&dout, nq, "debug out");
+    dev_malloc((void **)&dsc, nsc, "debug scores");
+    dev_malloc((void **)&dp, np, "debug probabilities");
+    h2d_bulk(dq, q, nq);
+    h2d_bulk(dk, mem_k, nkv);
+    h2d_bulk(dv, mem_v, nkv);
+    HIP_CHECK(hipMemsetAsync(dout, 0xFF, nq, g.stream));
+    prompt_attention(fused != 0, (const float *)dq, (const __half *)dk, (const __half *)dv, (float *)dout, (float *)dsc, (_Float16 *)dp, N, E,
+                     Egqa, H, Hkv, D, n_past, C, scale);
+    d2h_queue(out, dout, nq);
+    d2h_finish();
+    for (char *b : {dq, dk, dv, dout, dsc, dp}) HIP_CHECK(hipFree(b));
     return 0;
 }
 

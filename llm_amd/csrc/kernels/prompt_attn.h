@@ -127,8 +127,9 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         const __half *vp = a.mem_v + ((int64_t)hk * D + d0 + fr) * a.C + fh * 8;
         const char *pa = lds + fr * rb + fh * 16;
         auto load_v = [&](int c) {
-            u32x4 v = *(const u32x4 *)(vp + c * 16);
-            const int valid = Ttot - (c * 16 + fh * 8);  // the cache beyond the last written key may hold anything
+            const int valid = Ttot - (c * 16 + fh * 8);  // the cache beyond the last written key may hold anything,
+            u32x4 v = {0, 0, 0, 0};                      // and a row ends at C (C % 8 == 0: a group of 8 is inside or outside)
+            if (valid > 0) v = *(const u32x4 *)(vp + c * 16);
             if (valid < 8) v = gf16_mask_tail(v, valid < 0 ? 0 : valid);
             return __builtin_bit_cast(f16x8, v);
         };
