@@ -453,6 +453,16 @@ GGML_API bool ggml_cuda_compute_forward(struct ggml_compute_params *params, stru
 /* ---- HIP-backend extensions (no reference counterpart; measurement and multi-GPU plumbing) ---- */
 /* Number of visible devices (0 when no GPU / HIP runtime unusable). Never aborts. */
 GGML_API int ggml_hip_device_count(void);
+/* Several devices in one process (the ggml-style layer split of one InferenceSession).  A device
+ * "slot" owns a stream, the device shadows of the host arenas, the weights uploaded while it was current and its plan cache;
+ * ggml_hip_set_main_device (cuda.rs:62) makes a slot current for every following call.  GGML_HIP_VIRTUAL_DEVICES=n maps n
+ * slots onto the visible GPUs round-robin (several slots on one GPU: how the split is tested on a 1-GPU box). */
+GGML_API int ggml_hip_get_main_device(void);
+/* the fractions last given to ggml_hip_set_tensor_split (cuda.rs:11), one per slot; returns the number written */
+GGML_API int ggml_hip_get_tensor_split(float *out, int cap);
+/* dst (on slot dst_device) = src (on slot src_device), ordered after src_device's enqueued work and before dst_device's
+ * later work: the residual hop of a layer split inside one process (peer copy over xGMI between two GPUs). */
+GGML_API void ggml_hip_copy_between_devices(int dst_device, void *dst, int src_device, const void *src, size_t nbytes);
 /* Blocks until all device work queued by this library has finished. */
 GGML_API void ggml_hip_synchronize(void);
 /* Copies nbytes of a tensor's device mirror to/from host memory (host pointer != tensor->data allowed).

@@ -81,6 +81,7 @@ namespace {
     abort();
 }
 
+int g_cur_slot();
 struct Arena {
     uintptr_t base = 0;
     size_t size = 0;
@@ -92,6 +93,7 @@ struct Arena {
 // Record behind ggml_tensor.extra (and behind auto-uploaded persistent leaves).
 struct DevTensor {
     uint32_t magic = 0x48495054;  // 'HIPT'
+    int slot = (int)(g_cur_slot());  // the device slot that owns the copy
     uintptr_t host = 0;           // host data range this record mirrors
     size_t nbytes = 0;
     char *dev = nullptr;          // base of the device allocation
@@ -120,8 +122,16 @@ struct Timing {
     int64_t launches[GGML_HIP_KCLASS_COUNT] = {0, 0, 0, 0};
 };
 
+// One instance per device a process drives ("slot").  The reference's hooks address devices by index
+// (ggml_cuda_set_main_device, crates/ggml/sys/src/cuda.rs:62; the split fractions of ggml_cuda_set_tensor_split, :11): here
+// set_main_device makes a slot CURRENT and every entry point acts on the current slot — its stream, arena shadows, weight
+// records, plan cache, options.  A session that spans several GPUs (the ggml-style layer split, host/llm_host.cpp) keeps the
+// layers of a stage on one slot and switches slots between stages; the residual crosses with ggml_hip_copy_between_devices.
+// GGML_HIP_VIRTUAL_DEVICES=n maps n slots onto the visible devices round-robin (several slots on ONE GPU: how the split is
+// tested on a 1-GPU box).  One thread drives the library at a time (g_mu).
+#define GGML_HIP_MAX_BACKENDS 16
 struct Backend {
-    std::recursive_mutex mu;
+    int slot = 0;
     bool inited = false;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -188,7 +198,23 @@ struct Backend {
     bool pending_wait = false;  // a decode plan was launched by graph_compute_begin and not yet waited for
     uint64_t ns_match = 0, ns_launch = 0, ns_wait = 0, ns_compute = 0;  // host-side time split of plan tokens
     size_t dead_shadow_bytes = 0;
-} g;
+};
+std::recursive_mutex g_mu;
+float g_tensor_split[GGML_HIP_MAX_BACKENDS] = {1.0f};
+Backend g_backends[GGML_HIP_MAX_BACKENDS];
+Backend *g_cur = &g_backends[0];
+#define g (*g_cur)
+int g_cur_slot() { return (int)(g_cur - g_backends); }
+// a flag per slot for things done once per DEVICE (hipFuncSetAttribute acts on the current device's copy of a kernel)
+struct DevOnce {
+    bool done[GGML_HIP_MAX_BACKENDS] = {};
+    bool first() {
+        bool &d = done[g.slot];
+        if (d) return false;
+        d = true;
+        return true;
+    }
+};
 
 int kt_of(ggml_type t) { return t == GGML_TYPE_Q4_K ? KT_Q4_K : t == GGML_TYPE_Q6_K ? KT_Q6_K : -1; }
 int qt_of(ggml_type t) {
@@ -202,16 +228,51 @@ int qt_of(ggml_type t) {
     }
 }
 
+thread_local int tl_device = -1;  // the device this thread last made current
+void bind_device() {
+    if (tl_device != g.device) {
+        HIP_CHECK(hipSetDevice(g.device));
+        tl_device = g.device;
+    }
+}
+// slots this process may address: GGML_HIP_VIRTUAL_DEVICES if set, else the visible devices
+int slot_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    if (const char *v = getenv("GGML_HIP_VIRTUAL_DEVICES")) n = std::max(n, atoi(v));
+    return std::min(n, GGML_HIP_MAX_BACKENDS);
+}
+// runs f with every slot current in turn (host-side bookkeeping that all slots share: arenas, options)
+template <typename F>
+void for_each_slot(F f) {
+    Backend *keep = g_cur;
+    for (int i = 0; i < GGML_HIP_MAX_BACKENDS; i++) {
+        g_cur = &g_backends[i];
+        g.slot = i;
+        if (g.inited) bind_device();
+        f();
+    }
+    g_cur = keep;
+    if (g.inited) bind_device();
+}
 void ensure_init() {
-    if (g.inited) return;
+    if (g.inited) {
+        bind_device();
+        return;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         die("no HIP device available (hipGetDeviceCount -> %d, n=%d). This library has no CPU compute path.", (int)e, n);
-    // one process per GPU: honour LOCAL_RANK when the launcher did not restrict visibility
-    if (const char *lr = getenv("GGML_HIP_DEVICE")) g.device = atoi(lr);
-    if (g.device >= n) g.device = g.device % n;
+    // slot s drives physical device (base + s) mod n.  base: GGML_HIP_DEVICE (one process per GPU launchers set it to the
+    // local rank when they did not restrict visibility); several slots on one device when GGML_HIP_VIRTUAL_DEVICES asks
+    // for more slots than there are devices.
+    g.slot = (int)(g_cur - g_backends);
+    int base = 0;
+    if (const char *lr = getenv("GGML_HIP_DEVICE")) base = atoi(lr);
+    g.device = (base + g.slot) % n;
     HIP_CHECK(hipSetDevice(g.device));
+    tl_device = g.device;
     HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (const char *v = getenv("GGML_HIP_PREFETCH")) g.opt_prefetch = atoi(v);
     if (const char *v = getenv("GGML_HIP_PREFETCH_WO")) g.opt_prefetch_wo = atoi(v);
@@ -307,6 +368,8 @@ void evict_overlapping(std::map<uintptr_t, DevTensor *> &m, uintptr_t b, size_t 
 DevTensor *extra_of(const ggml_tensor *t) {
     DevTensor *e = (DevTensor *)t->extra;
     if (e && e->magic != 0x48495054) die("tensor '%s': extra does not belong to this backend", t->name);
+    if (e && e->slot != g_cur_slot())
+        die("tensor '%s' lives on device slot %d but slot %d is current (ggml_hip_set_main_device)", t->name, e->slot, g_cur_slot());
     return e;
 }
 char *arena_dev(Arena *a) {
@@ -354,7 +417,8 @@ struct QActBuf {
     int64_t nb = 0, ncols = 0;
     QAct act{};
     bool valid = false;
-} g_qact;
+} g_qact_[GGML_HIP_MAX_BACKENDS];
+#define g_qact (g_qact_[g.slot])
 struct XF16Buf {  // the prefill GEMM's activation operand (kernels/mmq.h), cached like g_qact
     const void *src_data = nullptr;
     size_t src_bytes = 0;
@@ -362,7 +426,8 @@ struct XF16Buf {  // the prefill GEMM's activation operand (kernels/mmq.h), cach
     int64_t nb = 0, ncols = 0;
     const _Float16 *x = nullptr;
     bool valid = false;
-} g_xf16;
+} g_xf16_[GGML_HIP_MAX_BACKENDS];
+#define g_xf16 (g_xf16_[g.slot])
 struct XQ8Buf {  // int8 + f16-scale activations of the X8 prompt GEMM (kernels/mmq_dma.h)
     const void *src_data = nullptr;
     size_t src_bytes = 0;
@@ -371,7 +436,8 @@ struct XQ8Buf {  // int8 + f16-scale activations of the X8 prompt GEMM (kernels/
     const int8_t *q8 = nullptr;
     const _Float16 *dx = nullptr;
     bool valid = false;
-} g_xq8;
+} g_xq8_[GGML_HIP_MAX_BACKENDS];
+#define g_xq8 (g_xq8_[g.slot])
 
 char *ws_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -425,7 +491,8 @@ struct Staging {
         size_t n;
     };
     std::vector<Pending> pending;  // D2H copies whose staging → user memcpy happens after the stream sync
-} stg;
+} stg_[GGML_HIP_MAX_BACKENDS];
+#define stg (stg_[g.slot])
 
 void staging_init() {
     if (stg.small) return;
@@ -903,7 +970,8 @@ struct XI8Buf {  // int8 activations + f32 block scale + zero-point term of the 
     const int8_t *q8 = nullptr;
     const float *dx = nullptr, *xs = nullptr;
     bool valid = false;
-} g_xi8;
+} g_xi8_[GGML_HIP_MAX_BACKENDS];
+#define g_xi8 (g_xi8_[g.slot])
 void quantize_activation_i8(const ggml_tensor *src1, int qt, const int8_t **q8, const float **dx, const float **xs) {
     BK_ASSERT(src1->type == GGML_TYPE_F32 && src1->nb[0] == 4 && src1->ne[2] == 1 && src1->ne[3] == 1);
     const int64_t K = src1->ne[0], N = src1->ne[1], nb = K / 32;
@@ -940,9 +1008,8 @@ void quantize_activation_i8(const ggml_tensor *src1, int qt, const int8_t **q8, 
 }
 template <int QT>
 void launch_mmq_i8(const MmqI8Args &a, dim3 grid) {
-    static bool attr = false;
-    if (!attr) {
-        attr = true;
+    static DevOnce attr;
+    if (attr.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_i8<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS));
     }
     g.stat_mmq[Backend::MMQ_K_I8]++;
@@ -958,7 +1025,8 @@ struct XKBuf {
     int64_t nsb = 0, ncols = 0;
     KAct act{};
     bool valid = false;
-} g_xk;
+} g_xk_[GGML_HIP_MAX_BACKENDS];
+#define g_xk (g_xk_[g.slot])
 KAct quantize_activation_k(const ggml_tensor *src1) {
     BK_ASSERT(src1->type == GGML_TYPE_F32 && src1->nb[0] == 4 && src1->ne[2] == 1 && src1->ne[3] == 1);
     const int64_t K = src1->ne[0], N = src1->ne[1], nsb = K / 256;
@@ -1140,13 +1208,12 @@ void mmq_w16_256_launch(int nseg, const MmqSegHost *segs, const _Float16 *x16, i
     a.split_stride = splits > 1 ? split_stride : 0;
     if (splits > 1 && zero_dst && !split_stride)
         for (int i = 0; i < nseg; i++) HIP_CHECK(hipMemsetAsync(segs[i].dst, 0, (size_t)segs[i].w.M * N * 4, g.stream));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS));
-        attr_set = true;
     }
     const int tiles_total = tiles_m * a.tiles_n, n_items = tiles_total * splits;
     Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * rows * (double)N * (double)(nb * 32));
@@ -1201,35 +1268,32 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
         for (int i = 0; i < nseg; i++) HIP_CHECK(hipMemsetAsync(segs[i].dst, 0, (size_t)segs[i].w.M * N * 4, g.stream));
     a.xcd_by_n = g.opt_mmq_xcdn == 2 ? 1 : g.opt_mmq_xcdn && (a.tiles_n == 1 || a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && tiles_m % (8 / a.tiles_n) == 0;
     const dim3 grid((unsigned)(tiles_m * a.tiles_n), (unsigned)splits);
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {  // 73.7 KB of dynamic LDS: above the 64 KB a kernel gets without opting in
+    static DevOnce lds_attr_set;
+    if (lds_attr_set.first()) {  // 73.7 KB of dynamic LDS: above the 64 KB a kernel gets without opting in
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
-        lds_attr_set = true;
     }
     Timed tm(GGML_HIP_KCLASS_MMQ_MFMA, 2.0 * rows * (double)N * (double)(nb * 32));
     if (use_dma && !use_x8 && g.opt_mmq_persist) {  // one workgroup per CU walks the tiles (kernels/mmq_dmap.h)
-        static bool p_attr_set = false;
-        if (!p_attr_set) {
+        static DevOnce p_attr_set;
+        if (p_attr_set.first()) {
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
-            p_attr_set = true;
         }
         const int tiles_total = tiles_m * a.tiles_n, n_items = tiles_total * splits;
         const dim3 pgrid((unsigned)std::min(n_items, g.num_cus));
         bool all_w16 = g.opt_mmq_w16 != 0;
         for (int i = 0; i < nseg; i++) all_w16 = all_w16 && segs[i].w.w16 != nullptr;
         if (all_w16) {  // both operands by DMA from resident f16 copies (kernels/mmq_w16.h)
-            static bool w16_attr_set = false;
-            if (!w16_attr_set) {
+            static DevOnce w16_attr_set;
+            if (w16_attr_set.first()) {
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_w16_p8, hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS));
-                w16_attr_set = true;
             }
             g.stat_mmq[Backend::MMQ_K_W16_P8]++;
             hipLaunchKernelGGL(k_mmq_w16_p8, pgrid, dim3(512), W16_LDS, g.stream, a, n_items, tiles_total, splits);
@@ -1237,14 +1301,13 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
             return;
         }
         if (g.opt_mmq_waves == 8) {  // two waves per SIMD on the same tile (kernels/mmq_dmap8.h)
-            static bool p8_attr_set = false;
-            if (!p8_attr_set) {
+            static DevOnce p8_attr_set;
+            if (p8_attr_set.first()) {
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q4_0>::LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q4_1>::LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q5_0>::LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q5_1>::LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma_p8<QT_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, Dma8<QT_Q8_0>::LDS));
-                p8_attr_set = true;
             }
             g.stat_mmq[Backend::MMQ_K_DMA_P8]++;
             switch (qt) {
@@ -1271,8 +1334,8 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
         return;
     }
     if (use_dma) {
-        static bool dma_attr_set = false;
-        if (!dma_attr_set) {
+        static DevOnce dma_attr_set;
+        if (dma_attr_set.first()) {
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q4_1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
@@ -1283,7 +1346,6 @@ void mmq_f16_launch_multi(int qt, int nseg, const MmqSegHost *segs, const _Float
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q5_1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
             HIP_CHECK(hipFuncSetAttribute((const void *)k_mmq_dma<QT_Q8_0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, D8_LDS));
-            dma_attr_set = true;
         }
         g.stat_mmq[Backend::MMQ_K_DMA]++;
 #define LAUNCH_DMA(QT_)                                                                                             \
@@ -1461,10 +1523,9 @@ void op_mul_mat(ggml_tensor *dst) {
             ga.causal = 0;
             ga.causal_past = 0;
             const int tiles_m = (int)((ga.M + 127) / 128);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DevOnce attr_set;
+            if (attr_set.first()) {
                 HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_f16, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
-                attr_set = true;
             }
             hipLaunchKernelGGL(k_gemm_f16, dim3((unsigned)(tiles_m * ga.tiles_n), (unsigned)(b->ne[2] * b->ne[3])), dim3(256),
                                MMQ_LDS, g.stream, ga);
@@ -1888,8 +1949,19 @@ void execute_graph(ggml_cgraph *gr) {
 // ===================================================================================================
 // exported: internal seam
 // ===================================================================================================
+// Host arenas are known to every slot (a context made while one device is current may be used while another is): the
+// registry is per slot, so that each slot owns its shadows, and both calls are applied to all of them.
+static void register_arena_here(void *host_base, size_t size, int is_scratch);
+static void unregister_arena_here(void *host_base);
 extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size, int is_scratch) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    for_each_slot([&] { register_arena_here(host_base, size, is_scratch); });
+}
+extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    for_each_slot([&] { unregister_arena_here(host_base); });
+}
+static void register_arena_here(void *host_base, size_t size, int is_scratch) {
     const uintptr_t b = (uintptr_t)host_base;
     if (size == 0) return;
     auto it = g.arenas.find(b);
@@ -1921,8 +1993,7 @@ extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size, i
     g.arenas[b] = a;
 }
 
-extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+static void unregister_arena_here(void *host_base) {
     const uintptr_t b = (uintptr_t)host_base;
     auto it = g.arenas.find(b);
     if (it == g.arenas.end()) return;
@@ -1961,7 +2032,7 @@ extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
 }
 
 extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     const uint64_t t0 = now_ns();
     execute_graph(cgraph);
     g.ns_compute += now_ns() - t0;
@@ -1971,7 +2042,7 @@ extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
 // (fused decode plan), 0 if it was executed synchronously (any other graph); end() waits and finishes the
 // read-back of the host-visible results.  Nothing else may read results before end().
 extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     const uint64_t t0 = now_ns();
     ensure_init();
     finish_pending();
@@ -1991,7 +2062,7 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     return async;
 }
 extern "C" void ggml_hip_graph_compute_end(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     const uint64_t t0 = now_ns();
     finish_pending();
     g.ns_compute += now_ns() - t0;
@@ -2003,25 +2074,36 @@ extern "C" void ggml_hip_graph_compute_end(void) {
 extern "C" {
 
 void ggml_init_hipblas(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
 }
 void ggml_hip_set_main_device(int main_device) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
-    if (g.inited && main_device != g.device)
-        die("ggml_hip_set_main_device(%d) after initialisation on device %d: one process drives one GPU", main_device,
-            g.device);
-    g.device = main_device;
+    // crates/ggml/sys/src/cuda.rs:62 (accelerator/mod.rs:72): the slot every following call acts on
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (main_device < 0 || main_device >= std::max(1, slot_count()))
+        die("ggml_hip_set_main_device(%d): %d device slot(s) available", main_device, slot_count());
+    g_cur = &g_backends[main_device];
+    g.slot = main_device;
+    if (g.inited) bind_device();
 }
 void ggml_hip_set_tensor_split(const float *tensor_split) {
-    // The reference always passes a single 1.0 (crates/ggml/src/accelerator/mod.rs:74-75). Multi-GPU here is a
-    // layer split across processes (one per GPU, RCCL send/recv of the residual), not an intra-tensor row split.
-    (void)tensor_split;
+    // crates/ggml/sys/src/cuda.rs:11.  The reference passes a single 1.0 (crates/ggml/src/accelerator/mod.rs:74-75).
+    // Here the fractions (one per slot, ggml's convention: device i takes the share split[i] / sum) are kept for the host
+    // side, which turns them into a LAYER split (llm_split_layers, host/llm_host.cpp): rows of one tensor are never split.
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    const int n = std::max(1, slot_count());
+    for (int i = 0; i < GGML_HIP_MAX_BACKENDS; i++) g_tensor_split[i] = tensor_split && i < n ? tensor_split[i] : 0.0f;
+}
+int ggml_hip_get_tensor_split(float *out, int cap) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    const int n = std::min(cap, std::max(1, slot_count()));
+    for (int i = 0; i < n; i++) out[i] = g_tensor_split[i];
+    return n;
 }
 void ggml_hip_set_mul_mat_q(bool) {}  // quantized kernels are always used
 void ggml_hip_set_scratch_size(size_t) {}  // activations live in arena shadows, there is no scratch pool
 void ggml_hip_free_scratch(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g.inited) return;
     HIP_CHECK(hipStreamSynchronize(g.stream));
     // Cached decode plans (and the plan a greedy chain may continue) hold device addresses inside these shadows
@@ -2048,7 +2130,7 @@ void ggml_hip_free_scratch(void) {
     g.dead_shadow_bytes = 0;
 }
 void *ggml_hip_host_malloc(size_t size) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     void *p = nullptr;
     if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess) return nullptr;
@@ -2058,7 +2140,7 @@ void ggml_hip_host_free(void *ptr) {
     if (ptr) HIP_CHECK(hipHostFree(ptr));
 }
 void ggml_hip_transform_tensor(void *data, struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (extra_of(tensor)) return;
     tensor->backend = GGML_BACKEND_GPU;
     tensor->extra = upload_tensor(data, tensor, false);
@@ -2078,7 +2160,7 @@ static void launch_quantize_blocks(const void *src_dev, bool f16_src, int type, 
     HIP_CHECK(hipGetLastError());
 }
 size_t ggml_hip_quantize(enum ggml_type type, const float *src, void *dst, int64_t n, int64_t k, int64_t *hist) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     if (!quantizable(type)) die("ggml_hip_quantize: %s has no device encoder", ggml_type_name(type));
     if (k % 32 != 0 || n % k != 0) die("ggml_hip_quantize: n = %lld must be rows of k = %lld, k %% 32 == 0", (long long)n, (long long)k);
@@ -2109,7 +2191,7 @@ size_t ggml_hip_quantize(enum ggml_type type, const float *src, void *dst, int64
     return (size_t)nblocks * bs;
 }
 int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor *dst, int64_t *hist) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     if (!quantizable(dst->type) || (src->type != GGML_TYPE_F32 && src->type != GGML_TYPE_F16)) return -1;
     if (!ggml_is_contiguous(src) || src->ne[2] != 1 || src->ne[3] != 1 || src->ne[0] % 32 != 0 || src->ne[0] != dst->ne[0] ||
@@ -2156,7 +2238,7 @@ int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor
 // ---- device top-k prefilter (kernels/topk.h) ----
 int ggml_hip_topk(const struct ggml_tensor *t, int64_t row, int k, const int32_t *extra_ids, int n_extra, float *out_vals,
                   int32_t *out_ids) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     if (!t || t->type != GGML_TYPE_F32 || t->nb[0] != 4 || row < 0 || row >= t->ne[1] * t->ne[2] * t->ne[3] || t->ne[2] != 1 ||
         t->ne[3] != 1 || k < 1 || k > TOPK_MAX || k > t->ne[0] || n_extra < 0 || t->ne[0] > 0x7FFFFFFF || !out_vals || !out_ids ||
@@ -2186,7 +2268,7 @@ int ggml_hip_topk(const struct ggml_tensor *t, int64_t row, int k, const int32_t
 }
 
 void ggml_hip_free_data(struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!tensor || !tensor->extra) return;
     DevTensor *e = (DevTensor *)tensor->extra;
     if (e->magic != 0x48495054) return;  // scratch-assigned node: nothing to free (as in the reference)
@@ -2200,7 +2282,7 @@ void ggml_hip_assign_buffers(struct ggml_tensor *tensor) {
 }
 void ggml_hip_assign_buffers_force_inplace(struct ggml_tensor *tensor) { tensor->backend = GGML_BACKEND_GPU; }
 void ggml_hip_assign_buffers_no_scratch(struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     tensor->backend = GGML_BACKEND_GPU;
     if (tensor->op != GGML_OP_NONE || extra_of(tensor)) return;
     // persistent, zero-initialised device tensor (the K/V memory: inference_session.rs:996-1021)
@@ -2219,13 +2301,13 @@ size_t ggml_hip_mul_mat_get_wsize(const struct ggml_tensor *, const struct ggml_
 }
 void ggml_hip_mul_mat(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst, void *,
                       size_t) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     BK_ASSERT(dst->src[0] == src0 && dst->src[1] == src1);
     op_mul_mat(dst);
 }
 void ggml_hip_mul(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     BK_ASSERT(dst->src[0] == src0 && dst->src[1] == src1);
     op_bin(dst, BIN_MUL);
@@ -2233,7 +2315,7 @@ void ggml_hip_mul(const struct ggml_tensor *src0, const struct ggml_tensor *src1
 bool ggml_hip_compute_forward(struct ggml_compute_params *params, struct ggml_tensor *tensor) {
     // Per-node hook of the reference's CPU executor. This library executes whole graphs itself
     // (ggml_graph_compute), so the hook only has to answer for callers that drive nodes one by one.
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (params && (params->ith != 0 || params->type != GGML_TASK_COMPUTE)) return true;
     ensure_init();
     ggml_cgraph *gr = (ggml_cgraph *)calloc(1, sizeof(ggml_cgraph));
@@ -2274,23 +2356,49 @@ bool ggml_cuda_compute_forward(struct ggml_compute_params *p, struct ggml_tensor
 // ===================================================================================================
 // exported: extensions
 // ===================================================================================================
-int ggml_hip_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+int ggml_hip_device_count(void) { return slot_count(); }
+int ggml_hip_get_main_device(void) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return (int)(g_cur - g_backends);
+}
+// The residual of a layer split crossing from one slot to another: dst on slot dst_device's stream waits for what
+// src_device's stream has enqueued so far, then copies (peer copy over xGMI between two GPUs, a device copy when both slots
+// sit on one GPU).  Asynchronous; ordered with both slots' later work on their own streams.
+void ggml_hip_copy_between_devices(int dst_device, void *dst, int src_device, const void *src, size_t nbytes) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (dst_device < 0 || src_device < 0 || dst_device >= GGML_HIP_MAX_BACKENDS || src_device >= GGML_HIP_MAX_BACKENDS)
+        die("ggml_hip_copy_between_devices: bad slot");
+    Backend &S = g_backends[src_device], &D = g_backends[dst_device];
+    if (!S.inited || !D.inited) die("ggml_hip_copy_between_devices: slot not initialised");
+    Backend *keep = g_cur;
+    g_cur = &S;
+    bind_device();
+    hipEvent_t ev;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ev, S.stream));
+    g_cur = &D;
+    bind_device();
+    HIP_CHECK(hipStreamWaitEvent(D.stream, ev, 0));
+    if (S.device == D.device)
+        HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, D.stream));
+    else
+        HIP_CHECK(hipMemcpyPeerAsync(dst, D.device, src, S.device, nbytes, D.stream));
+    HIP_CHECK(hipEventDestroy(ev));  // released once the recorded work completes
+    g_cur = keep;
+    if (g.inited) bind_device();
 }
 void ggml_hip_synchronize(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (g.inited) HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void ggml_hip_tensor_get(const struct ggml_tensor *tensor, void *host_dst, size_t offset, size_t nbytes) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     d2h_queue(host_dst, dev_ptr(tensor) + offset, nbytes);
     d2h_finish();
 }
 void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_t offset, size_t nbytes) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     h2d_bulk(dev_ptr(tensor) + offset, host_src, nbytes);
     HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -2298,7 +2406,7 @@ void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_
 // Raw copies on the backend stream, synchronous (layer-split driver: moving the residual between a stage's
 // hand-off buffer and the communication library's buffers). kind: 0 = host→device, 1 = device→host, 2 = device→device.
 void ggml_hip_memcpy(void *dst, const void *src, size_t nbytes, int kind) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     if (kind == 0) {
         h2d_bulk((char *)dst, src, nbytes);
@@ -2312,12 +2420,12 @@ void ggml_hip_memcpy(void *dst, const void *src, size_t nbytes, int kind) {
     }
 }
 void *ggml_hip_tensor_device_ptr(const struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     return dev_ptr(tensor);
 }
 void ggml_hip_timing_begin(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     HIP_CHECK(hipStreamSynchronize(g.stream));
     for (int k = 0; k < GGML_HIP_KCLASS_COUNT; k++) {
@@ -2329,12 +2437,12 @@ void ggml_hip_timing_begin(void) {
     g.timing.on = true;
 }
 void ggml_hip_timing_end(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     g.timing.on = false;
     if (g.inited) HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     double total = 0;
     if (kclass >= 0 && kclass < GGML_HIP_KCLASS_COUNT) {
         for (auto &r : g.timing.recs[kclass]) {
@@ -2347,8 +2455,12 @@ void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *al
         if (algo_bytes) *algo_bytes = g.timing.bytes[kclass];
     }
 }
-void ggml_hip_set_option(const char *key, int value) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+static void set_option_here(const char *key, int value);
+void ggml_hip_set_option(const char *key, int value) {  // options are process-wide: every slot gets them
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    for_each_slot([&] { set_option_here(key, value); });
+}
+static void set_option_here(const char *key, int value) {
     const std::string k(key);
     if (k == "fuse")
         g.opt_fuse = value;
@@ -2465,7 +2577,7 @@ void ggml_hip_set_option(const char *key, int value) {
 // included, which rocprof's per-kernel durations exclude).  KV writes of the replay go to the last cache slot.
 int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
                               double *algo_bytes_per_replay) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     unsigned kind_mask = ~0u;
     if (kclass >= GGML_HIP_KKIND_BASE && kclass < GGML_HIP_KKIND_BASE + 5) {  // one kind of mat-vec launch alone
         kind_mask = 1u << (kclass - GGML_HIP_KKIND_BASE);
@@ -2584,7 +2696,7 @@ void comm_need() {
 }  // namespace
 extern "C" {
 int ggml_hip_comm_unique_id(void *id_out) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     rccl_load();
     ncclUniqueId id;
@@ -2593,7 +2705,7 @@ int ggml_hip_comm_unique_id(void *id_out) {
     return (int)sizeof(id);
 }
 int ggml_hip_comm_init(int rank, int world, const void *id_in) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     rccl_load();
     if (rccl.comm) die("ggml_hip_comm_init: a communicator already exists");
@@ -2609,7 +2721,7 @@ int ggml_hip_comm_init(int rank, int world, const void *id_in) {
     return n;
 }
 void ggml_hip_comm_destroy(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!rccl.comm) return;
     HIP_CHECK(hipStreamSynchronize(g.stream));
     RCCL_CHECK(rccl.CommDestroy(rccl.comm));
@@ -2618,24 +2730,24 @@ void ggml_hip_comm_destroy(void) {
     rccl.world = 0;
 }
 int ggml_hip_comm_ranks(void) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!rccl.comm) return 0;
     int n = 0;
     RCCL_CHECK(rccl.CommCount(rccl.comm, &n));
     return n;
 }
 void ggml_hip_comm_send(const void *dev_src, size_t nbytes, int peer) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     comm_need();
     RCCL_CHECK(rccl.Send(dev_src, nbytes, ncclUint8, peer, rccl.comm, g.stream));
 }
 void ggml_hip_comm_recv(void *dev_dst, size_t nbytes, int peer) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     comm_need();
     RCCL_CHECK(rccl.Recv(dev_dst, nbytes, ncclUint8, peer, rccl.comm, g.stream));
 }
 void ggml_hip_comm_sendrecv(const void *dev_src, int send_peer, void *dev_dst, int recv_peer, size_t nbytes) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     comm_need();
     RCCL_CHECK(rccl.GroupStart());
     RCCL_CHECK(rccl.Send(dev_src, nbytes, ncclUint8, send_peer, rccl.comm, g.stream));
@@ -2678,9 +2790,8 @@ void empty_launch(int wgs, int threads, int lds, long long *ts, int idx) {
     memset(&a, 0, sizeof(a));
     a.ts = ts;
     a.idx = idx;
-    static bool attr = false;
-    if (!attr) {
-        attr = true;
+    static DevOnce attr;
+    if (attr.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_empty<NARG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     hipLaunchKernelGGL(k_empty<NARG>, dim3(wgs), dim3(threads), (size_t)lds, g.stream, a, 0);
@@ -2688,7 +2799,7 @@ void empty_launch(int wgs, int threads, int lds, long long *ts, int idx) {
 }  // namespace
 extern "C" {
 int ggml_hip_bench_empty(int wgs, int threads, int lds_bytes, int kernarg_bytes, int n_launch, int replays, double *out) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     if (n_launch < 2 || n_launch > 512 || replays < 1 || threads < 64 || threads > 1024 || lds_bytes > 160 * 1024) return -1;
     long long *ts = nullptr;
@@ -2737,16 +2848,15 @@ int ggml_hip_bench_empty(int wgs, int threads, int lds_bytes, int kernarg_bytes,
 // Returns 0, or -1 when `fused` is asked for a shape the fused kernel does not take.
 int ggml_hip_debug_prompt_attention(const float *q, const uint16_t *mem_k, const uint16_t *mem_v, float *out, int N, int E, int Egqa,
                                     int H, int n_past, int64_t C, float scale, int fused) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     ensure_init();
     finish_pending();
     const int64_t D = E / H, Hkv = Egqa / D, T = (int64_t)n_past + N, Tp = (T + 7) & ~(int64_t)7;
     if (T > C || (fused && !prompt_attn_fits(D, T))) return -1;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;
+    if (attr.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_f16, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_f16_b16, hipFuncAttributeMaxDynamicSharedMemorySize, MMQ_LDS));
-        attr = true;
     }
     char *dq, *dk, *dv, *dout, *dsc, *dp;
     const size_t nq = (size_t)N * E * 4, nkv = (size_t)C * Egqa * 2, nsc = (size_t)H * N * T * 4, np = (size_t)H * N * Tp * 2;
@@ -2769,12 +2879,12 @@ int ggml_hip_debug_prompt_attention(const float *q, const uint16_t *mem_k, const
 }
 
 int ggml_hip_decode_greedy_chain(struct ggml_cgraph *last, int n, int32_t *out_tokens, float *last_logits) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     return decode_greedy_chain(last, n, out_tokens, last_logits);
 }
 
 int64_t ggml_hip_get_stat(const char *key) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     const std::string k(key);
     if (k == "attn_split_tokens") return (int64_t)g.stat_split_tokens;  // tokens whose attention ran split over positions
     if (k == "w16_bytes") return (int64_t)g.w16_bytes;  // HBM held by resident f16 weight copies
@@ -2800,7 +2910,7 @@ int64_t ggml_hip_get_stat(const char *key) {
     return -1;
 }
 size_t ggml_hip_read_timeline(int64_t *dst, size_t max_records) {
-    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g.timeline) return 0;
     const size_t n = std::min(max_records, g.timeline_bytes / 64);
     HIP_CHECK(hipStreamSynchronize(g.stream));

@@ -484,13 +484,70 @@ class Llama {
 // C entry points
 // ---------------------------------------------------------------------------------------------------
 struct llm_ggml_file;
+// A model is one Llama — or, for the ggml-style layer split of ONE session over several GPUs of this process (SURVEY.md
+// section 8e; ModelParameters / ggml_cuda_set_tensor_split, crates/ggml/src/accelerator/mod.rs:68-77), one Llama per device
+// slot, each owning a contiguous layer range [layer_begin, layer_end) and its K/V on its own device.  `llama` / `s` are
+// the LAST stage's (final norm, lm_head, logits, token history), so everything that reads hyperparameters or logits is
+// unchanged; evaluation walks the stages in order and hands the residual on with ggml_hip_copy_between_devices.
 struct llm_model {
     llm::Llama *llama;
     llm_ggml_file *file = nullptr;  // mmap'd container the weights point into (llm_llama_load)
+    std::vector<llm::Llama *> stages;  // empty: unsplit
+    std::vector<int> devices;          // device slot of each stage
 };
 struct llm_session {
     llm::InferenceSession *s;
+    std::vector<llm::InferenceSession *> stage_sessions;  // parallel to llm_model::stages
+    std::vector<int> devices;
 };
+
+namespace {
+// Model::evaluate for both kinds of model
+void model_evaluate(llm_model *m, llm_session *s, const std::vector<llm::TokenId> &toks, llm::OutputRequest &req) {
+    if (m->stages.empty()) {
+        m->llama->evaluate(*s->s, toks, req);
+        return;
+    }
+    const size_t G = m->stages.size();
+    const size_t hop_bytes = (size_t)m->llama->hyperparameters.n_embd * toks.size() * sizeof(float);
+    for (size_t i = 0; i < G; i++) {
+        ggml_hip_set_main_device(m->devices[i]);
+        llm::InferenceSession &ss = *s->stage_sessions[i];
+        if (i > 0) {  // the residual [n_embd, N] f32 of the previous stage -> this stage's hand-off buffer, device to device
+            void *dst = ggml_hip_tensor_device_ptr(ss.stage_in.ptr());
+            ggml_hip_set_main_device(m->devices[i - 1]);
+            const void *src = ggml_hip_tensor_device_ptr(s->stage_sessions[i - 1]->stage_out.ptr());
+            ggml_hip_copy_between_devices(m->devices[i], dst, m->devices[i - 1], src, hop_bytes);
+            ggml_hip_set_main_device(m->devices[i]);
+        }
+        llm::OutputRequest none;
+        m->stages[i]->evaluate(ss, toks, i + 1 == G ? req : none);
+    }
+}
+// contiguous layer ranges for G stages in proportion to `split` (ggml's convention: device i takes split[i] / sum; all
+// zero or NULL = equal shares); every stage gets at least one layer
+std::vector<size_t> split_layers(size_t n_layer, int G, const float *split) {
+    std::vector<double> w(G, 1.0);
+    double sum = 0;
+    bool any = false;
+    for (int i = 0; i < G; i++) any = any || (split && split[i] > 0.0f);
+    for (int i = 0; i < G; i++) {
+        if (any) w[i] = std::max(0.0f, split[i]);
+        sum += w[i];
+    }
+    std::vector<size_t> bounds(G + 1, 0);
+    double acc = 0;
+    for (int i = 0; i < G; i++) {
+        acc += w[i];
+        size_t b = (size_t)std::llround(acc / sum * (double)n_layer);
+        b = std::max(b, bounds[i] + 1);                       // at least one layer per stage
+        b = std::min(b, n_layer - (size_t)(G - 1 - i));       // ... and one left for each later stage
+        bounds[i + 1] = b;
+    }
+    bounds[G] = n_layer;
+    return bounds;
+}
+}  // namespace
 
 extern "C" {
 
@@ -518,13 +575,83 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
         fprintf(stderr, "llm_llama_new: use_gpu=0 requested, but libggml_hip has no CPU compute path\n");
         abort();
     }
-    llm::TensorLoader tl(tensors, n_tensors);
+    // Layer split inside this process: more than one device slot with a positive share in ggml_hip_set_tensor_split
+    // (the reference's hook for a split, crates/ggml/sys/src/cuda.rs:11), or GGML_HIP_LAYER_SPLIT=G for equal shares.
+    // A caller that passes its own layer range (one process per GPU, llm_amd/pipeline.py) is left alone.
+    std::vector<int> slots;     // the device slots that take part, in order
+    std::vector<float> shares;  // their fractions (all zero = equal)
+    {
+        float split[16] = {0};
+        const int nslot = ggml_hip_get_tensor_split(split, 16);
+        for (int i = 0; i < nslot; i++)
+            if (split[i] > 0.0f) {
+                slots.push_back(i);
+                shares.push_back(split[i]);
+            }
+        if (slots.size() < 2) {
+            slots.clear();
+            shares.clear();
+            if (const char *v = getenv("GGML_HIP_LAYER_SPLIT"))
+                for (int i = 0; i < std::min(atoi(v), ggml_hip_device_count()); i++) {
+                    slots.push_back(i);
+                    shares.push_back(0.0f);
+                }
+        }
+    }
+    const bool whole = p.layer_begin == 0 && p.layer_end == (size_t)-1;
+    while (slots.size() > (size_t)h.n_layer) {
+        slots.pop_back();
+        shares.pop_back();
+    }
     llm_model *m = new llm_model();
+    if (slots.size() > 1 && whole) {
+        const int G = (int)slots.size();
+        const std::vector<size_t> bounds = split_layers(h.n_layer, G, shares.data());
+        const int home = ggml_hip_get_main_device();
+        for (int i = 0; i < G; i++) {
+            llm::ModelParameters ps = p;
+            ps.layer_begin = bounds[i];
+            ps.layer_end = bounds[i + 1];
+            ggml_hip_set_main_device(slots[i]);
+            m->stages.push_back(new llm::Llama(h, ps, llm::TensorLoader(tensors, n_tensors)));
+            m->devices.push_back(slots[i]);
+        }
+        ggml_hip_set_main_device(home);
+        m->llama = m->stages.back();
+        return m;
+    }
+    llm::TensorLoader tl(tensors, n_tensors);
     m->llama = new llm::Llama(h, p, std::move(tl));
     return m;
 }
+// the layer range and device slot of every stage of a model (1 entry for an unsplit one); returns the stage count
+int llm_model_stages(const llm_model *m, int *layer_begin, int *layer_end, int *device, int cap) {
+    if (m->stages.empty()) {
+        if (cap > 0) {
+            if (layer_begin) layer_begin[0] = (int)m->llama->params.layer_begin;
+            if (layer_end) layer_end[0] = (int)std::min(m->llama->params.layer_end, m->llama->hyperparameters.n_layer);
+            if (device) device[0] = ggml_hip_get_main_device();
+        }
+        return 1;
+    }
+    for (size_t i = 0; i < m->stages.size() && (int)i < cap; i++) {
+        if (layer_begin) layer_begin[i] = (int)m->stages[i]->params.layer_begin;
+        if (layer_end) layer_end[i] = (int)m->stages[i]->params.layer_end;
+        if (device) device[i] = m->devices[i];
+    }
+    return (int)m->stages.size();
+}
 void llm_model_free(llm_model *m) {
     if (!m) return;
+    if (!m->stages.empty()) {
+        const int home = ggml_hip_get_main_device();
+        for (size_t i = 0; i < m->stages.size(); i++) {
+            ggml_hip_set_main_device(m->devices[i]);
+            delete m->stages[i];
+        }
+        ggml_hip_set_main_device(home);
+        m->llama = nullptr;
+    }
     delete m->llama;
     if (m->file) llm_ggml_file_close(m->file);
     delete m;
@@ -721,11 +848,31 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
         c.n_threads = cfg->n_threads > 0 ? (size_t)cfg->n_threads : 8;
     }
     llm_session *s = new llm_session();
+    if (!m->stages.empty()) {
+        const int home = ggml_hip_get_main_device();
+        for (size_t i = 0; i < m->stages.size(); i++) {
+            ggml_hip_set_main_device(m->devices[i]);
+            s->stage_sessions.push_back(m->stages[i]->start_session(c));
+        }
+        ggml_hip_set_main_device(home);
+        s->s = s->stage_sessions.back();
+        s->devices = m->devices;
+        return s;
+    }
     s->s = m->llama->start_session(c);
     return s;
 }
 void llm_session_free(llm_session *s) {
     if (!s) return;
+    if (!s->stage_sessions.empty()) {
+        const int home = ggml_hip_get_main_device();
+        for (size_t i = 0; i < s->stage_sessions.size(); i++) {
+            ggml_hip_set_main_device(s->devices[i]);
+            delete s->stage_sessions[i];
+        }
+        ggml_hip_set_main_device(home);
+        s->s = nullptr;
+    }
     delete s->s;
     delete s;
 }
@@ -735,7 +882,7 @@ void llm_evaluate(llm_model *m, llm_session *s, const int32_t *tokens, int n, fl
     llm::OutputRequest req;
     if (all_logits) req.all_logits = &logits;
     if (embeddings) req.embeddings = &emb;
-    m->llama->evaluate(*s->s, toks, req);
+    model_evaluate(m, s, toks, req);
     if (all_logits) memcpy(all_logits, logits.data(), logits.size() * sizeof(float));
     if (embeddings) memcpy(embeddings, emb.data(), emb.size() * sizeof(float));
 }
@@ -750,7 +897,7 @@ void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *tokens, int n)
     for (size_t i = 0; i < (size_t)n; i += nb) {
         const size_t len = std::min(nb, (size_t)n - i);
         std::vector<llm::TokenId> batch(tokens + i, tokens + i + len);
-        m->llama->evaluate(*s->s, batch, req);
+        model_evaluate(m, s, batch, req);
         for (auto tk : batch) s->s->tokens.push_back(tk);
     }
 }
@@ -769,7 +916,7 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
     s->s->tokens.push_back(next);
     llm::OutputRequest req;
     const double t1 = llm::InferenceSession::now_ns();
-    m->llama->evaluate(*s->s, std::vector<llm::TokenId>{next}, req);
+    model_evaluate(m, s, std::vector<llm::TokenId>{next}, req);
     llm::InferenceSession::host_ns[5] += t1 - t0;                                // argmax
     llm::InferenceSession::host_ns[6] += llm::InferenceSession::now_ns() - t1;  // evaluate, all of it
     return next;
@@ -787,7 +934,7 @@ int llm_infer_tokens_greedy_device(llm_model *m, llm_session *s, int n, int32_t 
     int done = 0;
     // the chain continues a single-token fused-plan run; after a prompt chunk (or a fresh session) one normal step arms it
     for (int attempt = 0; attempt < 2 && done < n; attempt++) {
-        if (s->s->last_graph &&
+        if (m->stages.empty() && s->s->last_graph &&
             ggml_hip_decode_greedy_chain(s->s->last_graph, n - done, out + done, s->s->last_logits.data()) == 0) {
             s->s->advance_device_chain((const llm::TokenId *)(out + done), (size_t)(n - done));
             return n;
@@ -807,6 +954,7 @@ int llm_session_rewind(llm_session *s, int num) {
     if ((size_t)num >= s->s->n_past) return -1;  // RewindError::NotEnoughTokens
     if ((size_t)num <= s->s->tokens.size()) s->s->tokens.resize(s->s->tokens.size() - (size_t)num);
     s->s->n_past -= (size_t)num;
+    for (size_t i = 0; i + 1 < s->stage_sessions.size(); i++) s->stage_sessions[i]->n_past -= (size_t)num;
     return 0;
 }
 const float *llm_session_last_logits(const llm_session *s) { return s->s->last_logits.data(); }
@@ -829,6 +977,24 @@ void llm_session_stage_buffers(llm_session *s, void **in_dev, void **out_dev, si
 // InferenceSnapshot (inference_session.rs:599-646), which reads `memory_k.data()` on the host; here the
 // authoritative copy lives on the device, so the snapshot goes through the backend.  set=0 reads, set=1 writes.
 size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbytes) {
+    if (!s->stage_sessions.empty()) {  // the stages' caches in layer order = the whole model's layout (layer-major)
+        size_t total = 0, off = 0;
+        for (auto *ss : s->stage_sessions) total += (which == 0 ? ss->memory_k : ss->memory_v).nbytes();
+        if (!buf) return total;
+        const int home = ggml_hip_get_main_device();
+        for (size_t i = 0; i < s->stage_sessions.size() && off < nbytes; i++) {
+            ggml::Tensor &t = which == 0 ? s->stage_sessions[i]->memory_k : s->stage_sessions[i]->memory_v;
+            const size_t n = std::min(t.nbytes(), nbytes - off);
+            ggml_hip_set_main_device(s->devices[i]);
+            if (set)
+                ggml_hip_tensor_set(t.ptr(), (char *)buf + off, 0, n);
+            else
+                ggml_hip_tensor_get(t.ptr(), (char *)buf + off, 0, n);
+            off += n;
+        }
+        ggml_hip_set_main_device(home);
+        return off;
+    }
     ggml::Tensor &t = which == 0 ? s->s->memory_k : s->s->memory_v;
     const size_t n = t.nbytes();
     if (!buf) return n;

@@ -57,6 +57,12 @@ typedef struct llm_session llm_session;
 GGML_API llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *params,
                                   const llm_tensor_desc *tensors, int n_tensors);
 GGML_API void llm_model_free(llm_model *m);
+/* Layer split of ONE model over several device slots of this process: llm_llama_new / llm_llama_load
+ * split the layers into contiguous ranges, one per slot, when ggml_hip_set_tensor_split gave more than one slot a
+ * positive share (the reference's hook, crates/ggml/src/accelerator/mod.rs:68-77) or GGML_HIP_LAYER_SPLIT=G asks for
+ * equal shares; sessions of such a model walk the stages, the residual crosses with ggml_hip_copy_between_devices.
+ * Returns the number of stages and, for the first `cap`, their layer ranges [begin, end) and device slots. */
+GGML_API int llm_model_stages(const llm_model *m, int *layer_begin, int *layer_end, int *device, int cap);
 
 /* GGML / GGMF v1 / GGJT v1-3 container reader with an mmap'd tensor section:
  * crates/ggml/src/format/loader.rs:160-281 (container walk, 32-byte alignment of GGJT tensor data, the

@@ -39,6 +39,8 @@ def _lib():
         L.llm_llama_new.restype = C.c_void_p
         L.llm_llama_new.argtypes = [C.POINTER(_HP), C.POINTER(_MP), C.POINTER(_TD), C.c_int]
         L.llm_model_free.argtypes = [C.c_void_p]
+        L.llm_model_stages.restype = C.c_int
+        L.llm_model_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.llm_ggml_file_open.restype = C.c_void_p
         L.llm_ggml_file_open.argtypes = [C.c_char_p]
         L.llm_ggml_file_close.argtypes = [C.c_void_p]
@@ -172,6 +174,13 @@ class Llama:
         self.is_first = self.is_last = True
         self.context_size = context_size
         return self
+
+    def stages(self):
+        """[(layer_begin, layer_end, device_slot)] — one entry for an unsplit model, one per device slot for a model that
+        llm_llama_new split over the GPUs of this process (ggml_hip_set_tensor_split / GGML_HIP_LAYER_SPLIT)."""
+        lb, le, dv = ((C.c_int * 16)() for _ in range(3))
+        n = _lib().llm_model_stages(self.ptr, lb, le, dv, 16)
+        return [(lb[i], le[i], dv[i]) for i in range(n)]
 
     def start_session(self, n_batch=8, kv_type=ggml.TYPE_F16):
         return Session(self, n_batch, kv_type)
