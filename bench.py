@@ -272,6 +272,18 @@ def run_single(args):
     sess.feed_prompt(prompt)  # untimed for the metric; reported as config.prompt_feed (n_batch = 8: multi-token plan)
     L.ggml_hip_synchronize()
     prompt_s = time.perf_counter() - tp
+    # the same chunks again (rewind to the first chunk, feed the rest): the plan of the 8-token chunk is cached and captured
+    # now, this is the steady-state rate of InferenceSession::feed_prompt at the reference's default n_batch = 8
+    n_again = (args.prompt - 8) // 8 * 8
+    prompt2_s = 0.0
+    if n_again > 0 and sess.rewind(args.prompt - 8) == 0:
+        L.ggml_hip_synchronize()
+        tp2 = time.perf_counter()
+        sess.feed_prompt(prompt[8:8 + n_again])
+        L.ggml_hip_synchronize()
+        prompt2_s = time.perf_counter() - tp2
+        if 8 + n_again < args.prompt:
+            sess.feed_prompt(prompt[8 + n_again:])
     for _ in range(args.warmup):
         sess.infer_next_token()
     L.ggml_hip_synchronize()
@@ -401,7 +413,10 @@ def run_single(args):
                                   "library's counter-based generator)") if args.weights == "gaussian" else "random valid GGML blocks",
                       "prompt_feed": {"tokens": int(args.prompt), "n_batch": 8, "ms": round(prompt_s * 1e3, 1),
                                       "tokens_per_s": round(args.prompt / prompt_s, 1),
-                                      "note": "first call of the process: includes hipGraph capture of the plans"}, "prep": {k: round(v, 2) for k, v in prep.items()}},
+                                      "note": "first call of the process: includes hipGraph capture of the plans",
+                                      "steady": {"tokens": n_again, "ms": round(prompt2_s * 1e3, 2),
+                                                 "tokens_per_s": round(n_again / prompt2_s, 1) if prompt2_s > 0 else None,
+                                                 "note": "the same 8-token chunks fed again after a rewind (plans cached)"}}, "prep": {k: round(v, 2) for k, v in prep.items()}},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if sess is not None:

@@ -598,7 +598,7 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
                 }
         }
     }
-    const bool whole = p.layer_begin == 0 && p.layer_end == (size_t)-1;
+    const bool whole = p.layer_begin == 0 && p.layer_end >= (size_t)h.n_layer;  // the caller did not ask for a stage
     while (slots.size() > (size_t)h.n_layer) {
         slots.pop_back();
         shares.pop_back();

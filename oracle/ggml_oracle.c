@@ -157,7 +157,7 @@ _Static_assert(sizeof(block_q8_0) == 34, "q8_0");
 _Static_assert(sizeof(block_q8_1) == 40, "q8_1");
 
 enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9,
-       T_Q4_K = 12, T_Q6_K = 14, T_Q8_K = 15 };
+       T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15 };
 
 /* ---- K-quants (k_quants.c upstream): the checker of the product's Q4_K / Q6_K mat-vec and get_rows
  * (llm_amd/csrc/kernels/kquant.h, tests/test_kquant_gpu.py).  Struct layouts ARE in tree (bindgen: crates/ggml/sys/src/lib.rs:3103-3108,
@@ -170,6 +170,10 @@ enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q
 typedef struct { fp16_t d; fp16_t dmin; uint8_t scales[12]; uint8_t qs[QK_K / 2]; } block_q4_K;           /* 144 B */
 typedef struct { uint8_t ql[QK_K / 2]; uint8_t qh[QK_K / 4]; int8_t scales[QK_K / 16]; fp16_t d; } block_q6_K; /* 210 B */
 typedef struct { float d; int8_t qs[QK_K]; int16_t bsums[QK_K / 16]; } block_q8_K;                         /* 292 B */
+/* crates/ggml/sys/src/lib.rs:2977-2982 (84 B asserted :2989), :3040-3045 (110 B, :3052), :3166-3172 (176 B, :3178) */
+typedef struct { uint8_t scales[QK_K / 16]; uint8_t qs[QK_K / 4]; fp16_t d; fp16_t dmin; } block_q2_K;          /* 84 B */
+typedef struct { uint8_t hmask[QK_K / 8]; uint8_t qs[QK_K / 4]; uint8_t scales[12]; fp16_t d; } block_q3_K;     /* 110 B */
+typedef struct { fp16_t d; fp16_t dmin; uint8_t scales[12]; uint8_t qh[QK_K / 8]; uint8_t qs[QK_K / 2]; } block_q5_K; /* 176 B */
 #pragma pack(pop)
 _Static_assert(sizeof(block_q4_K) == 144, "q4_K");
 _Static_assert(sizeof(block_q6_K) == 210, "q6_K");
@@ -185,6 +189,9 @@ EXPORT int orc_type_size(int type) {
         case T_Q5_1: return 24;
         case T_Q8_0: return 34;
         case T_Q8_1: return 40;
+        case T_Q2_K: return 84;
+        case T_Q3_K: return 110;
+        case T_Q5_K: return 176;
         case T_Q4_K: return 144;
         case T_Q6_K: return 210;
         case T_Q8_K: return 292;
@@ -192,7 +199,7 @@ EXPORT int orc_type_size(int type) {
     return 0;
 }
 EXPORT int orc_blck_size(int type) {
-    if (type == T_Q4_K || type == T_Q6_K || type == T_Q8_K) return QK_K;
+    if (type == T_Q2_K || type == T_Q3_K || type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q8_K) return QK_K;
     return (type == T_F32 || type == T_F16) ? 1 : QK;
 }
 /* vec_dot_type column of ggml's type_traits table (shape visible at sys/src/lib.rs:2900-2906) */
@@ -200,7 +207,7 @@ EXPORT int orc_vec_dot_type(int type) {
     switch (type) {
         case T_Q4_0: case T_Q5_0: case T_Q8_0: return T_Q8_0;
         case T_Q4_1: case T_Q5_1: return T_Q8_1;
-        case T_Q4_K: case T_Q6_K: return T_Q8_K;
+        case T_Q2_K: case T_Q3_K: case T_Q4_K: case T_Q5_K: case T_Q6_K: return T_Q8_K;
         case T_F16: return T_F16;
     }
     return T_F32;
@@ -568,6 +575,356 @@ static void dequantize_row_q8_K(const block_q8_K *x, float *y, int k) {
     for (int i = 0; i < k / QK_K; i++)
         for (int j = 0; j < QK_K; ++j) *y++ = x[i].d * x[i].qs[j];
 }
+
+/* ---- Q2_K / Q3_K / Q5_K.  Decoders and dot products restate upstream k_quants.c (scalar branches);
+ * the ENCODERS below are simple min/max (abs-max) fits that produce VALID blocks for tests — not upstream's iterative
+ * make_qkx / make_q3 searches (oracle/SEMANTICS.md). ---------------------------------------------------------------- */
+/* Q2_K: x = d*(sc&15)*q - dmin*(sc>>4), 16 sub-blocks of 16, q in 0..3.  Element e: n = e/128, j = (e%128)/32, h = (e%32)/16:
+ * byte qs[32n + 16h + e%16], bits 2j..2j+1; scale byte scales[8n + 2j + h]. */
+static void quantize_row_q2_K(const float *x, block_q2_K *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        float sc[16], mn[16], max_sc = 0.0f, max_mn = 0.0f;
+        for (int j = 0; j < 16; j++) {
+            float lo = 0.0f, hi = 0.0f;
+            for (int l = 0; l < 16; l++) {
+                const float v = x[i * QK_K + 16 * j + l];
+                if (v < lo) lo = v;
+                if (v > hi) hi = v;
+            }
+            sc[j] = (hi - lo) / 3.0f;
+            mn[j] = -lo;
+            if (sc[j] > max_sc) max_sc = sc[j];
+            if (mn[j] > max_mn) max_mn = mn[j];
+        }
+        const float isc = max_sc > 0 ? 15.0f / max_sc : 0.0f, imn = max_mn > 0 ? 15.0f / max_mn : 0.0f;
+        y[i].d = fp32_to_fp16(max_sc / 15.0f);
+        y[i].dmin = fp32_to_fp16(max_mn / 15.0f);
+        uint8_t L[QK_K];
+        for (int j = 0; j < 16; j++) {
+            const int ls = MIN(15, nearest_int(isc * sc[j])), lm = MIN(15, nearest_int(imn * mn[j]));
+            y[i].scales[j] = (uint8_t)(ls | (lm << 4));
+            const float d = fp16_to_fp32(y[i].d) * ls, dm = fp16_to_fp32(y[i].dmin) * lm;
+            for (int l = 0; l < 16; l++) {
+                int q = d != 0.0f ? nearest_int((x[i * QK_K + 16 * j + l] + dm) / d) : 0;
+                L[16 * j + l] = (uint8_t)(q < 0 ? 0 : q > 3 ? 3 : q);
+            }
+        }
+        for (int j = 0; j < QK_K; j += 128)
+            for (int l = 0; l < 32; l++)
+                y[i].qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+    }
+}
+static void dequantize_row_q2_K(const block_q2_K *x, float *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        const float d = fp16_to_fp32(x[i].d), min = fp16_to_fp32(x[i].dmin);
+        const uint8_t *q = x[i].qs;
+        int is = 0;
+        for (int n = 0; n < QK_K; n += 128) {
+            int shift = 0;
+            for (int j = 0; j < 4; ++j) {
+                uint8_t sc = x[i].scales[is++];
+                float dl = d * (sc & 0xF), ml = min * (sc >> 4);
+                for (int l = 0; l < 16; ++l) *y++ = dl * ((int8_t)((q[l] >> shift) & 3)) - ml;
+                sc = x[i].scales[is++];
+                dl = d * (sc & 0xF);
+                ml = min * (sc >> 4);
+                for (int l = 0; l < 16; ++l) *y++ = dl * ((int8_t)((q[l + 16] >> shift) & 3)) - ml;
+                shift += 2;
+            }
+            q += 32;
+        }
+    }
+}
+static float vec_dot_q2_K_q8_K(int n, const block_q2_K *x, const block_q8_K *y) {
+    const int nb = n / QK_K;
+    float sumf = 0.0f;
+    for (int i = 0; i < nb; ++i) {
+        const uint8_t *q2 = x[i].qs;
+        const int8_t *q8 = y[i].qs;
+        const uint8_t *sc = x[i].scales;
+        int summs = 0;
+        for (int j = 0; j < 16; ++j) summs += y[i].bsums[j] * (sc[j] >> 4);
+        const float dall = y[i].d * fp16_to_fp32(x[i].d), dmin = y[i].d * fp16_to_fp32(x[i].dmin);
+        int isum = 0, is = 0;
+        for (int kk = 0; kk < QK_K / 128; ++kk) {
+            int shift = 0;
+            for (int j = 0; j < 4; ++j) {
+                int d = sc[is++] & 0xF, isuml = 0;
+                for (int l = 0; l < 16; ++l) isuml += q8[l] * ((q2[l] >> shift) & 3);
+                isum += d * isuml;
+                d = sc[is++] & 0xF;
+                isuml = 0;
+                for (int l = 16; l < 32; ++l) isuml += q8[l] * ((q2[l] >> shift) & 3);
+                isum += d * isuml;
+                shift += 2;
+                q8 += 32;
+            }
+            q2 += 32;
+        }
+        sumf += dall * isum - dmin * summs;
+    }
+    return sumf;
+}
+/* Q3_K: x = d*(sc_j - 32)*q, 16 sub-blocks of 16, q in -4..3: two low bits in qs (as Q2_K), the third in hmask (bit
+ * 4n + j of hmask[16h + e%16]; bit CLEAR means subtract 4); sc_j: 6 bits packed in 12 bytes. */
+static void q3_unpack_scales(const uint8_t *packed, int8_t *scales /*16*/) {
+    const uint32_t kmask1 = 0x03030303, kmask2 = 0x0f0f0f0f;
+    uint32_t aux[4];
+    memcpy(aux, packed, 12);
+    const uint32_t tmp = aux[2];
+    aux[2] = ((aux[0] >> 4) & kmask2) | (((tmp >> 4) & kmask1) << 4);
+    aux[3] = ((aux[1] >> 4) & kmask2) | (((tmp >> 6) & kmask1) << 4);
+    aux[0] = (aux[0] & kmask2) | (((tmp >> 0) & kmask1) << 4);
+    aux[1] = (aux[1] & kmask2) | (((tmp >> 2) & kmask1) << 4);
+    memcpy(scales, aux, 16);
+}
+static void quantize_row_q3_K(const float *x, block_q3_K *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        float sc[16], max_abs = 0.0f, max_sc = 0.0f;
+        for (int j = 0; j < 16; j++) {
+            float amax = 0.0f, vmax = 0.0f;
+            for (int l = 0; l < 16; l++) {
+                const float v = x[i * QK_K + 16 * j + l];
+                if (fabsf(v) > amax) { amax = fabsf(v); vmax = v; }
+            }
+            sc[j] = amax > 0 ? vmax / -4.0f : 0.0f; /* the extreme value maps to -4 */
+            if (fabsf(sc[j]) > max_abs) { max_abs = fabsf(sc[j]); max_sc = sc[j]; }
+        }
+        memset(&y[i], 0, sizeof(block_q3_K));
+        if (max_abs == 0.0f) {
+            for (int j = 0; j < 16; j++) { /* scales 32 -> (32 - 32) = 0 */
+                const int l = 32;
+                if (j < 8) y[i].scales[j] = l & 0xF; else y[i].scales[j - 8] |= ((l & 0xF) << 4);
+                y[i].scales[j % 4 + 8] |= ((l >> 4) << (2 * (j / 4)));
+            }
+            for (int j = 0; j < QK_K / 8; j++) y[i].hmask[j] = 0xFF; /* q = 0 */
+            continue;
+        }
+        const float iscale = -32.0f / max_sc;
+        y[i].d = fp32_to_fp16(1.0f / iscale);
+        int8_t ls[16];
+        for (int j = 0; j < 16; j++) {
+            int l = nearest_int(iscale * sc[j]);
+            l = l < -32 ? -32 : l > 31 ? 31 : l;
+            ls[j] = (int8_t)l;
+            l += 32;
+            if (j < 8) y[i].scales[j] = l & 0xF; else y[i].scales[j - 8] |= ((l & 0xF) << 4);
+            y[i].scales[j % 4 + 8] |= ((l >> 4) << (2 * (j / 4)));
+        }
+        uint8_t L[QK_K]; /* q + 4 in 0..7 */
+        for (int j = 0; j < 16; j++) {
+            const float d = fp16_to_fp32(y[i].d) * ls[j];
+            for (int l = 0; l < 16; l++) {
+                int q = d != 0.0f ? nearest_int(x[i * QK_K + 16 * j + l] / d) : 0;
+                q = q < -4 ? -4 : q > 3 ? 3 : q;
+                L[16 * j + l] = (uint8_t)(q + 4);
+            }
+        }
+        int m = 0;
+        uint8_t hm = 1;
+        for (int j = 0; j < QK_K; ++j) { /* upstream's order: bit hm of hmask[j % 32] for elements j = 32*bit .. */
+            if (L[j] > 3) {
+                y[i].hmask[m] |= hm;
+                L[j] -= 4;
+            }
+            if (++m == QK_K / 8) {
+                m = 0;
+                hm <<= 1;
+            }
+        }
+        for (int j = 0; j < QK_K; j += 128)
+            for (int l = 0; l < 32; l++)
+                y[i].qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+    }
+}
+static void dequantize_row_q3_K(const block_q3_K *x, float *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        const float d_all = fp16_to_fp32(x[i].d);
+        const uint8_t *q = x[i].qs, *hm = x[i].hmask;
+        uint8_t m = 1;
+        int8_t scales[16];
+        q3_unpack_scales(x[i].scales, scales);
+        int is = 0;
+        for (int n = 0; n < QK_K; n += 128) {
+            int shift = 0;
+            for (int j = 0; j < 4; ++j) {
+                float dl = d_all * (scales[is++] - 32);
+                for (int l = 0; l < 16; ++l) *y++ = dl * ((int8_t)((q[l + 0] >> shift) & 3) - ((hm[l + 0] & m) ? 0 : 4));
+                dl = d_all * (scales[is++] - 32);
+                for (int l = 0; l < 16; ++l) *y++ = dl * ((int8_t)((q[l + 16] >> shift) & 3) - ((hm[l + 16] & m) ? 0 : 4));
+                shift += 2;
+                m <<= 1;
+            }
+            q += 32;
+        }
+    }
+}
+/* upstream's scalar K dots keep EIGHT running f32 sums (sums[l], l = element index mod 8) and add them at the end */
+static float vec_dot_q3_K_q8_K(int n, const block_q3_K *x, const block_q8_K *y) {
+    const int nb = n / QK_K;
+    int8_t aux8[QK_K];
+    int16_t aux16[8];
+    float sums[8];
+    int32_t aux32[8];
+    memset(sums, 0, sizeof(sums));
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i) {
+        const uint8_t *q3 = x[i].qs, *hm = x[i].hmask;
+        const int8_t *q8 = y[i].qs;
+        memset(aux32, 0, sizeof(aux32));
+        int8_t *a = aux8;
+        uint8_t m = 1;
+        for (int j = 0; j < QK_K; j += 128) {
+            for (int sh = 0; sh < 8; sh += 2) {
+                for (int l = 0; l < 32; ++l) a[l] = (int8_t)((q3[l] >> sh) & 3);
+                for (int l = 0; l < 32; ++l) a[l] -= (hm[l] & m ? 0 : 4);
+                a += 32;
+                m <<= 1;
+            }
+            q3 += 32;
+        }
+        a = aux8;
+        int8_t scales[16];
+        q3_unpack_scales(x[i].scales, scales);
+        for (int j = 0; j < QK_K / 16; ++j) {
+            for (int half = 0; half < 2; half++) {
+                for (int l = 0; l < 8; ++l) aux16[l] = (int16_t)(q8[l] * a[l]);
+                for (int l = 0; l < 8; ++l) aux32[l] += (scales[j] - 32) * aux16[l];
+                q8 += 8;
+                a += 8;
+            }
+        }
+        const float d = fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+    }
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
+    return sumf;
+}
+/* Q5_K: Q4_K with a fifth bit: x = d*sc_j*q - dmin*m_j, q in 0..31; bit (2*(e/64) + (e%64)/32) of qh[e%32] */
+static void quantize_row_q5_K(const float *x, block_q5_K *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        float scales[8], mins[8], max_scale = 0.0f, max_min = 0.0f;
+        for (int j = 0; j < 8; j++) {
+            float lo = 0.0f, hi = 0.0f;
+            for (int l = 0; l < 32; l++) {
+                const float v = x[i * QK_K + 32 * j + l];
+                if (v < lo) lo = v;
+                if (v > hi) hi = v;
+            }
+            scales[j] = (hi - lo) / 31.0f;
+            mins[j] = -lo;
+            if (scales[j] > max_scale) max_scale = scales[j];
+            if (mins[j] > max_min) max_min = mins[j];
+        }
+        const float inv_scale = max_scale > 0 ? 63.0f / max_scale : 0.0f, inv_min = max_min > 0 ? 63.0f / max_min : 0.0f;
+        memset(y[i].scales, 0, 12);
+        for (int j = 0; j < 8; j++) {
+            const int ls = MIN(63, nearest_int(inv_scale * scales[j])), lm = MIN(63, nearest_int(inv_min * mins[j]));
+            set_scale_min_k4(j, y[i].scales, (uint8_t)ls, (uint8_t)lm);
+        }
+        y[i].d = fp32_to_fp16(max_scale / 63.0f);
+        y[i].dmin = fp32_to_fp16(max_min / 63.0f);
+        uint8_t L[QK_K];
+        for (int j = 0; j < 8; j++) {
+            uint8_t sc, m;
+            get_scale_min_k4(j, y[i].scales, &sc, &m);
+            const float d = fp16_to_fp32(y[i].d) * sc, dm = fp16_to_fp32(y[i].dmin) * m;
+            for (int l = 0; l < 32; l++) {
+                int q = d != 0.0f ? nearest_int((x[i * QK_K + 32 * j + l] + dm) / d) : 0;
+                L[32 * j + l] = (uint8_t)(q < 0 ? 0 : q > 31 ? 31 : q);
+            }
+        }
+        uint8_t *qh = y[i].qh, *ql = y[i].qs;
+        memset(qh, 0, QK_K / 8);
+        uint8_t m1 = 1, m2 = 2;
+        for (int n2 = 0; n2 < QK_K; n2 += 64) {
+            for (int j = 0; j < 32; ++j) {
+                int l1 = L[n2 + j];
+                if (l1 > 15) { l1 -= 16; qh[j] |= m1; }
+                int l2 = L[n2 + j + 32];
+                if (l2 > 15) { l2 -= 16; qh[j] |= m2; }
+                ql[j] = (uint8_t)(l1 | (l2 << 4));
+            }
+            m1 <<= 2;
+            m2 <<= 2;
+            ql += 32;
+        }
+    }
+}
+static void dequantize_row_q5_K(const block_q5_K *x, float *y, int k) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; i++) {
+        const uint8_t *ql = x[i].qs, *qh = x[i].qh;
+        const float d = fp16_to_fp32(x[i].d), min = fp16_to_fp32(x[i].dmin);
+        int is = 0;
+        uint8_t sc, m, u1 = 1, u2 = 2;
+        for (int j = 0; j < QK_K; j += 64) {
+            get_scale_min_k4(is + 0, x[i].scales, &sc, &m);
+            const float d1 = d * sc, m1 = min * m;
+            get_scale_min_k4(is + 1, x[i].scales, &sc, &m);
+            const float d2 = d * sc, m2 = min * m;
+            for (int l = 0; l < 32; ++l) *y++ = d1 * ((ql[l] & 0xF) + (qh[l] & u1 ? 16 : 0)) - m1;
+            for (int l = 0; l < 32; ++l) *y++ = d2 * ((ql[l] >> 4) + (qh[l] & u2 ? 16 : 0)) - m2;
+            ql += 32;
+            is += 2;
+            u1 <<= 2;
+            u2 <<= 2;
+        }
+    }
+}
+static float vec_dot_q5_K_q8_K(int n, const block_q5_K *x, const block_q8_K *y) {
+    const int nb = n / QK_K;
+    int8_t aux8[QK_K];
+    int16_t aux16[8];
+    float sums[8];
+    int32_t aux32[8];
+    memset(sums, 0, sizeof(sums));
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i) {
+        const uint8_t *q4 = x[i].qs, *hm = x[i].qh;
+        const int8_t *q8 = y[i].qs;
+        memset(aux32, 0, sizeof(aux32));
+        int8_t *a = aux8;
+        uint8_t m = 1;
+        for (int j = 0; j < QK_K / 64; ++j) {
+            for (int l = 0; l < 32; ++l) a[l] = (int8_t)(q4[l] & 0xF);
+            for (int l = 0; l < 32; ++l) a[l] += (hm[l] & m ? 16 : 0);
+            a += 32;
+            m <<= 1;
+            for (int l = 0; l < 32; ++l) a[l] = (int8_t)(q4[l] >> 4);
+            for (int l = 0; l < 32; ++l) a[l] += (hm[l] & m ? 16 : 0);
+            a += 32;
+            m <<= 1;
+            q4 += 32;
+        }
+        uint8_t scales[8], mins[8];
+        for (int j = 0; j < 8; j++) get_scale_min_k4(j, x[i].scales, &scales[j], &mins[j]);
+        int sumi = 0;
+        for (int j = 0; j < QK_K / 16; ++j) sumi += y[i].bsums[j] * mins[j / 2];
+        a = aux8;
+        int is = 0;
+        for (int j = 0; j < QK_K / 32; ++j) {
+            const int32_t scale = scales[is++];
+            for (int g = 0; g < 4; g++) {
+                for (int l = 0; l < 8; ++l) aux16[l] = (int16_t)(q8[l] * a[l]);
+                for (int l = 0; l < 8; ++l) aux32[l] += scale * aux16[l];
+                q8 += 8;
+                a += 8;
+            }
+        }
+        const float d = fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+        const float dmin = fp16_to_fp32(x[i].dmin) * y[i].d;
+        sumf -= dmin * sumi;
+    }
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
+    return sumf;
+}
 /* ggml_vec_dot_q4_K_q8_K, scalar branch: sumf = sum_i d8*d*(sum_j sc_j * <q4_j, q8_j>) - d8*dmin*(sum_j m_j * bsum_j) */
 static float vec_dot_q4_K_q8_K(int n, const block_q4_K *x, const block_q8_K *y) {
     const int nb = n / QK_K;
@@ -629,6 +986,9 @@ EXPORT void orc_quantize_row(int type, const float *x, void *y, int k) {
         case T_Q5_1: quantize_row_q5_1(x, (block_q5_1 *)y, k); break;
         case T_Q8_0: quantize_row_q8_0(x, (block_q8_0 *)y, k); break;
         case T_Q8_1: quantize_row_q8_1(x, (block_q8_1 *)y, k); break;
+        case T_Q2_K: quantize_row_q2_K(x, (block_q2_K *)y, k); break;
+        case T_Q3_K: quantize_row_q3_K(x, (block_q3_K *)y, k); break;
+        case T_Q5_K: quantize_row_q5_K(x, (block_q5_K *)y, k); break;
         case T_Q4_K: quantize_row_q4_K(x, (block_q4_K *)y, k); break;
         case T_Q6_K: quantize_row_q6_K(x, (block_q6_K *)y, k); break;
         case T_Q8_K: quantize_row_q8_K(x, (block_q8_K *)y, k); break;
@@ -643,6 +1003,9 @@ EXPORT void orc_quantize_row(int type, const float *x, void *y, int k) {
 EXPORT void orc_dequantize_row(int type, const void *vx, float *y, int k) {
     const int nb = k / QK;
     switch (type) {
+        case T_Q2_K: dequantize_row_q2_K((const block_q2_K *)vx, y, k); return;
+        case T_Q3_K: dequantize_row_q3_K((const block_q3_K *)vx, y, k); return;
+        case T_Q5_K: dequantize_row_q5_K((const block_q5_K *)vx, y, k); return;
         case T_Q4_K: dequantize_row_q4_K((const block_q4_K *)vx, y, k); return;
         case T_Q6_K: dequantize_row_q6_K((const block_q6_K *)vx, y, k); return;
         case T_Q8_K: dequantize_row_q8_K((const block_q8_K *)vx, y, k); return;
@@ -1151,6 +1514,9 @@ EXPORT float orc_vec_dot(int type, int n, const void *x, const void *y) {
         case T_Q5_0: return vec_dot_q5_0_q8_0(n, (const block_q5_0 *)x, (const block_q8_0 *)y);
         case T_Q5_1: return vec_dot_q5_1_q8_1(n, (const block_q5_1 *)x, (const block_q8_1 *)y);
         case T_Q8_0: return vec_dot_q8_0_q8_0(n, (const block_q8_0 *)x, (const block_q8_0 *)y);
+        case T_Q2_K: return vec_dot_q2_K_q8_K(n, (const block_q2_K *)x, (const block_q8_K *)y);
+        case T_Q3_K: return vec_dot_q3_K_q8_K(n, (const block_q3_K *)x, (const block_q8_K *)y);
+        case T_Q5_K: return vec_dot_q5_K_q8_K(n, (const block_q5_K *)x, (const block_q8_K *)y);
         case T_Q4_K: return vec_dot_q4_K_q8_K(n, (const block_q4_K *)x, (const block_q8_K *)y);
         case T_Q6_K: return vec_dot_q6_K_q8_K(n, (const block_q6_K *)x, (const block_q8_K *)y);
     }
@@ -1166,7 +1532,7 @@ EXPORT void orc_mul_mat(int type, const void *A, int64_t M, int64_t K, const flo
                         float *dst, int mode) {
     const size_t row_bytes = (size_t)(K / orc_blck_size(type)) * (size_t)orc_type_size(type);
     if (mode != 1 && type != T_F32) {
-        const int simd = (mode == 2 || mode == 3) && type != T_F16 && type != T_Q4_K && type != T_Q6_K;
+        const int simd = (mode == 2 || mode == 3) && type != T_F16 && !(type >= T_Q2_K && type <= T_Q6_K);
         const int intr = simd && mode == 3;
         const int vdt = orc_vec_dot_type(type);
         const size_t qrow = (size_t)(K / orc_blck_size(vdt)) * (size_t)orc_type_size(vdt);
