@@ -925,56 +925,89 @@ static float vec_dot_q5_K_q8_K(int n, const block_q5_K *x, const block_q8_K *y) 
     for (int l = 0; l < 8; ++l) sumf += sums[l];
     return sumf;
 }
-/* ggml_vec_dot_q4_K_q8_K, scalar branch: sumf = sum_i d8*d*(sum_j sc_j * <q4_j, q8_j>) - d8*dmin*(sum_j m_j * bsum_j) */
+/* ggml_vec_dot_q4_K_q8_K, scalar branch: sumf = sum_i d8*d*(sum_j sc_j * <q4_j, q8_j>) - d8*dmin*(sum_j m_j * bsum_j), with the
+ * integer products gathered in EIGHT lanes (element index mod 8) that each keep a running f32 sum, added at the end */
 static float vec_dot_q4_K_q8_K(int n, const block_q4_K *x, const block_q8_K *y) {
     const int nb = n / QK_K;
-    float sumf = 0.0f;
-    for (int i = 0; i < nb; i++) {
+    int8_t aux8[QK_K];
+    int16_t aux16[8];
+    float sums[8];
+    int32_t aux32[8];
+    memset(sums, 0, sizeof(sums));
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i) {
         const uint8_t *q4 = x[i].qs;
         const int8_t *q8 = y[i].qs;
-        int32_t isum = 0, msum = 0;
-        for (int j = 0; j < QK_K / 64; j++) {
-            uint8_t sc1, m1, sc2, m2;
-            get_scale_min_k4(2 * j + 0, x[i].scales, &sc1, &m1);
-            get_scale_min_k4(2 * j + 1, x[i].scales, &sc2, &m2);
-            int32_t s1 = 0, s2 = 0;
-            for (int l = 0; l < 32; l++) s1 += (q4[l] & 0xF) * q8[l];
-            for (int l = 0; l < 32; l++) s2 += (q4[l] >> 4) * q8[l + 32];
-            isum += sc1 * s1 + sc2 * s2;
-            msum += m1 * (y[i].bsums[4 * j + 0] + y[i].bsums[4 * j + 1]) + m2 * (y[i].bsums[4 * j + 2] + y[i].bsums[4 * j + 3]);
+        memset(aux32, 0, sizeof(aux32));
+        int8_t *a = aux8;
+        for (int j = 0; j < QK_K / 64; ++j) {
+            for (int l = 0; l < 32; ++l) a[l] = (int8_t)(q4[l] & 0xF);
+            a += 32;
+            for (int l = 0; l < 32; ++l) a[l] = (int8_t)(q4[l] >> 4);
+            a += 32;
             q4 += 32;
-            q8 += 64;
         }
-        const float d = fp16_to_fp32(x[i].d) * y[i].d, dmin = fp16_to_fp32(x[i].dmin) * y[i].d;
-        sumf += d * (float)isum - dmin * (float)msum;
+        uint8_t scales[8], mins[8];
+        for (int j = 0; j < 8; j++) get_scale_min_k4(j, x[i].scales, &scales[j], &mins[j]);
+        int sumi = 0;
+        for (int j = 0; j < QK_K / 16; ++j) sumi += y[i].bsums[j] * mins[j / 2];
+        a = aux8;
+        for (int j = 0; j < QK_K / 32; ++j) {
+            const int32_t scale = scales[j];
+            for (int g = 0; g < 4; g++) {
+                for (int l = 0; l < 8; ++l) aux16[l] = (int16_t)(q8[l] * a[l]);
+                for (int l = 0; l < 8; ++l) aux32[l] += scale * aux16[l];
+                q8 += 8;
+                a += 8;
+            }
+        }
+        const float d = fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+        const float dmin = fp16_to_fp32(x[i].dmin) * y[i].d;
+        sumf -= dmin * sumi;
     }
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
     return sumf;
 }
-/* ggml_vec_dot_q6_K_q8_K, scalar branch: sumf = sum_i d8*d * sum_{16-blocks} sc * <q6, q8> */
+/* ggml_vec_dot_q6_K_q8_K, scalar branch: sumf = sum_i d8*d * sum_{16-blocks} sc * <q6, q8>, eight lanes as above */
 static float vec_dot_q6_K_q8_K(int n, const block_q6_K *x, const block_q8_K *y) {
     const int nb = n / QK_K;
-    float sumf = 0.0f;
-    for (int i = 0; i < nb; i++) {
-        int8_t a[QK_K];
+    int8_t aux8[QK_K];
+    int16_t aux16[8];
+    float sums[8];
+    int32_t aux32[8];
+    memset(sums, 0, sizeof(sums));
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i) {
         const uint8_t *ql = x[i].ql, *qh = x[i].qh;
-        for (int j = 0, o = 0; j < QK_K; j += 128, o += 128) {
+        const int8_t *q8 = y[i].qs;
+        memset(aux32, 0, sizeof(aux32));
+        int8_t *a = aux8;
+        for (int j = 0; j < QK_K; j += 128) {
             for (int l = 0; l < 32; ++l) {
-                a[o + l + 0] = (int8_t)((ql[l + 0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
-                a[o + l + 32] = (int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
-                a[o + l + 64] = (int8_t)((ql[l + 0] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
-                a[o + l + 96] = (int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                a[l + 0] = (int8_t)((ql[l + 0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                a[l + 32] = (int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                a[l + 64] = (int8_t)((ql[l + 0] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                a[l + 96] = (int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
             }
+            a += 128;
             ql += 64;
             qh += 32;
         }
-        int32_t isum = 0;
-        for (int j = 0; j < QK_K / 16; j++) {
-            int32_t s = 0;
-            for (int l = 0; l < 16; l++) s += a[16 * j + l] * y[i].qs[16 * j + l];
-            isum += x[i].scales[j] * s;
+        a = aux8;
+        for (int j = 0; j < QK_K / 16; ++j) {
+            const int scale = x[i].scales[j];
+            for (int half = 0; half < 2; half++) {
+                for (int l = 0; l < 8; ++l) aux16[l] = (int16_t)(q8[l] * a[l]);
+                for (int l = 0; l < 8; ++l) aux32[l] += scale * aux16[l];
+                q8 += 8;
+                a += 8;
+            }
         }
-        sumf += fp16_to_fp32(x[i].d) * y[i].d * (float)isum;
+        const float d = fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
     }
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
     return sumf;
 }
 

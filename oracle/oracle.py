@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libggml_oracle.so")
 
 T_F32, T_F16, T_Q4_0, T_Q4_1, T_Q5_0, T_Q5_1, T_Q8_0, T_Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9
-T_Q4_K, T_Q6_K, T_Q8_K = 12, 14, 15  # K-quant groundwork: oracle only, the product aborts on these
+T_Q2_K, T_Q3_K, T_Q4_K, T_Q5_K, T_Q6_K, T_Q8_K = 10, 11, 12, 13, 14, 15  # K-quants
 QUANT_TYPES = (T_Q4_0, T_Q4_1, T_Q5_0, T_Q5_1, T_Q8_0)
 TYPE_NAMES = {T_F32: "f32", T_F16: "f16", T_Q4_0: "q4_0", T_Q4_1: "q4_1", T_Q5_0: "q5_0", T_Q5_1: "q5_1",
               T_Q8_0: "q8_0", T_Q8_1: "q8_1"}

@@ -19,7 +19,7 @@ def _three_launch_attention(request, G):
     V.P as three kernels: the plan does the same here.  The fused attention kernel (kernels/prompt_attn.h, the default)
     equals that path up to one f16 rounding of about one probability per hundred rows; it has its own test below and is
     what every oracle comparison elsewhere runs on."""
-    fused = "fused" in request.node.name
+    fused = "fused_prompt_attention" in request.node.name
     G.set_option("attn_fused", 1 if fused else 0)
     yield
     G.set_option("attn_fused", 1)
