@@ -39,6 +39,7 @@
 #include "kernels/mmq_w16_256.h"
 #include "kernels/mmq_i8.h"
 #include "kernels/kquant.h"
+#include "kernels/kquant2.h"
 #include "kernels/quantize.h"
 #include "kernels/topk.h"
 #include "kernels/gemm_f16.h"
@@ -105,6 +106,7 @@ struct DevTensor {
     uintptr_t owner_hdr = 0;      // auto-uploaded only: address of the ggml_tensor header that named this data
     QWeight qw{};
     char *w16 = nullptr;          // resident f16 copy of a quantized weight for the prompt GEMM (ensure_w16); qw.w16 names it
+    size_t w16_size = 0;
     bool ksoa = false;            // K-quant planar layout (see KWeight, kernels/kquant.h)
     KWeight kw{};
     ggml_type type = GGML_TYPE_F32;
@@ -216,7 +218,16 @@ struct DevOnce {
     }
 };
 
-int kt_of(ggml_type t) { return t == GGML_TYPE_Q4_K ? KT_Q4_K : t == GGML_TYPE_Q6_K ? KT_Q6_K : -1; }
+int kt_of(ggml_type t) {
+    switch (t) {
+        case GGML_TYPE_Q2_K: return KT_Q2_K;
+        case GGML_TYPE_Q3_K: return KT_Q3_K;
+        case GGML_TYPE_Q4_K: return KT_Q4_K;
+        case GGML_TYPE_Q5_K: return KT_Q5_K;
+        case GGML_TYPE_Q6_K: return KT_Q6_K;
+        default: return -1;
+    }
+}
 int qt_of(ggml_type t) {
     switch (t) {
         case GGML_TYPE_Q4_0: return QT_Q4_0;
@@ -674,19 +685,42 @@ bool wants_soa(const ggml_tensor *t) {
     return qt_of(t->type) >= 0 && t->ne[2] == 1 && t->ne[3] == 1 && t->ne[0] % 32 == 0 && ggml_is_contiguous(t);
 }
 
-// K-quants (kernels/kquant.h): planes {qs, aux (Q6_K), sc, d}
+// K-quants (kernels/kquant.h, kquant2.h): planes {qs, aux (Q6_K high bits / Q3_K hmask / Q5_K qh), sc, d}; bytes per super-block
+struct KPlanes { int qs, aux, sc, d; };
+KPlanes k_planes(int kt) {
+    switch (kt) {
+        case KT_Q4_K: return {128, 0, 16, 4};
+        case KT_Q6_K: return {128, 64, 16, 2};
+        case KT_Q2_K: return {64, 0, 16, 4};
+        case KT_Q3_K: return {64, 32, 16, 4};
+        default: return {128, 32, 16, 4};  // KT_Q5_K
+    }
+}
+double k_block_bytes(int kt) { return kt == KT_Q4_K ? 144.0 : kt == KT_Q6_K ? 210.0 : kt == KT_Q2_K ? 84.0 : kt == KT_Q3_K ? 110.0 : 176.0; }
 size_t kw_layout(int kt, int64_t nsbt, size_t off[4]) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const KPlanes pl = k_planes(kt);
     size_t o = 0;
     off[0] = o;
-    o = al(o + (size_t)nsbt * 128);
+    o = al(o + (size_t)nsbt * pl.qs);
     off[1] = o;
-    if (kt == KT_Q6_K) o = al(o + (size_t)nsbt * 64);
+    if (pl.aux) o = al(o + (size_t)nsbt * pl.aux);
     off[2] = o;
-    o = al(o + (size_t)nsbt * 16);
+    o = al(o + (size_t)nsbt * pl.sc);
     off[3] = o;
-    o = al(o + (size_t)nsbt * (kt == KT_Q4_K ? 4 : 2));
+    o = al(o + (size_t)nsbt * pl.d);
     return o;
+}
+// rows row0 .. of a planar K weight (every plane is row-major)
+KWeight kw_rows(KWeight w, int64_t row0, int64_t rows) {
+    const KPlanes pl = k_planes(w.kt);
+    const int64_t s = row0 * w.nsb;
+    w.qs += s * pl.qs;
+    w.aux += s * pl.aux / 4;
+    w.sc += s * pl.sc;
+    w.d += s * pl.d / 2;
+    w.M = rows;
+    return w;
 }
 KWeight kw_at(char *base, int kt, int64_t M, int64_t nsb) {
     size_t off[4];
@@ -703,8 +737,12 @@ KWeight kw_at(char *base, int kt, int64_t M, int64_t nsb) {
 }
 void relayout_k_launch(const char *raw_dev, int kt, int64_t M, int64_t nsb, char *base) {
     const KWeight w = kw_at(base, kt, M, nsb);
-    hipLaunchKernelGGL(k_relayout_k, grid1(M * nsb * 8), dim3(256), 0, g.stream, (const uint8_t *)raw_dev, kt, M * nsb,
-                       (uint8_t *)w.qs, (uint32_t *)w.aux, (uint8_t *)w.sc, (__half *)w.d);
+    if (kt == KT_Q4_K || kt == KT_Q6_K)
+        hipLaunchKernelGGL(k_relayout_k, grid1(M * nsb * 8), dim3(256), 0, g.stream, (const uint8_t *)raw_dev, kt, M * nsb,
+                           (uint8_t *)w.qs, (uint32_t *)w.aux, (uint8_t *)w.sc, (__half *)w.d);
+    else
+        hipLaunchKernelGGL(k_relayout_k2, grid1(M * nsb), dim3(256), 0, g.stream, (const uint8_t *)raw_dev, kt, M * nsb,
+                           (uint8_t *)w.qs, (uint32_t *)w.aux, (uint8_t *)w.sc, (__half *)w.d);
     HIP_CHECK(hipGetLastError());
 }
 bool wants_ksoa(const ggml_tensor *t) {
@@ -792,7 +830,7 @@ void destroy_record(DevTensor *e) {
     if (e->dev) HIP_CHECK(hipFree(e->dev));
     if (e->w16) {
         HIP_CHECK(hipFree(e->w16));
-        g.w16_bytes -= (size_t)e->qw.M * e->qw.nb * 64;
+        g.w16_bytes -= e->w16_size;
     }
     e->magic = 0;
     delete e;
@@ -1049,12 +1087,16 @@ KAct quantize_activation_k(const ggml_tensor *src1) {
 }
 template <int KT, int NCOLS>
 void launch_mmvq_k(const MmvqKArgs &a, int nwg, size_t lds) {
-    static size_t opted = 64 * 1024;
-    if (lds > opted) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_mmvq_k<KT, NCOLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        opted = 150 * 1024;
+    static DevOnce opted;  // more than 64 KB of dynamic LDS needs the attribute, once per device and instantiation
+    if constexpr (KT == KT_Q4_K || KT == KT_Q6_K) {
+        if (lds > 64 * 1024 && opted.first())
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmvq_k<KT, NCOLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        hipLaunchKernelGGL((k_mmvq_k<KT, NCOLS>), dim3(nwg), dim3(256), lds, g.stream, a);
+    } else {
+        if (lds > 64 * 1024 && opted.first())
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_mmvq_k2<KT, NCOLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        hipLaunchKernelGGL((k_mmvq_k2<KT, NCOLS>), dim3(nwg), dim3(256), lds, g.stream, a);
     }
-    hipLaunchKernelGGL((k_mmvq_k<KT, NCOLS>), dim3(nwg), dim3(256), lds, g.stream, a);
 }
 template <int KT>
 void launch_mmvq_k_c(const MmvqKArgs &a, int ncols, int nwg, size_t lds) {
@@ -1065,15 +1107,17 @@ void launch_mmvq_k_c(const MmvqKArgs &a, int ncols, int nwg, size_t lds) {
         default: launch_mmvq_k<KT, 8>(a, nwg, lds); break;
     }
 }
+bool mul_mat_k_gemm(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst);
 void mul_mat_k(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
     const int kt = kt_of(src0->type);
     const int64_t K = src1->ne[0], N = src1->ne[1], nsb = K / 256;
     BK_ASSERT(K % 256 == 0 && src0->ne[0] == K && dst->type == GGML_TYPE_F32 && dst->nb[0] == 4);
+    if (g.opt_mmq_min > 0 && N >= g.opt_mmq_min && mul_mat_k_gemm(src0, src1, dst)) return;  // prompt batch: f16 GEMM
     const KWeight w = kweight_of(src0);
     const KAct act = quantize_activation_k(src1);
     const size_t col_lds = (size_t)K + (size_t)nsb * (4 + 64);
     if (col_lds > 150 * 1024) die("mul_mat: K=%lld too large for the LDS-staged K-quant mat-vec", (long long)K);
-    const double sb_bytes = kt == KT_Q4_K ? 148.0 : 210.0;
+    const double sb_bytes = k_block_bytes(kt);
     int64_t c0 = 0;
     while (c0 < N) {
         int ncols = 8;
@@ -1090,13 +1134,28 @@ void mul_mat_k(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *ds
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / std::max<size_t>(lds, 1)));
         const int nwg = (int)std::min<int64_t>((w.M + 3) / 4, (int64_t)g.num_cus * per_cu);
         Timed tm(GGML_HIP_KCLASS_MMVQ, (double)w.M * nsb * sb_bytes + (double)w.M * ncols * 4 + (double)lds);
-        if (kt == KT_Q4_K)
-            launch_mmvq_k_c<KT_Q4_K>(a, ncols, nwg, lds);
-        else
-            launch_mmvq_k_c<KT_Q6_K>(a, ncols, nwg, lds);
+        switch (kt) {
+            case KT_Q4_K: launch_mmvq_k_c<KT_Q4_K>(a, ncols, nwg, lds); break;
+            case KT_Q6_K: launch_mmvq_k_c<KT_Q6_K>(a, ncols, nwg, lds); break;
+            case KT_Q2_K: launch_mmvq_k_c<KT_Q2_K>(a, ncols, nwg, lds); break;
+            case KT_Q3_K: launch_mmvq_k_c<KT_Q3_K>(a, ncols, nwg, lds); break;
+            default: launch_mmvq_k_c<KT_Q5_K>(a, ncols, nwg, lds); break;
+        }
         HIP_CHECK(hipGetLastError());
         c0 += ncols;
     }
+}
+// rows of a planar K weight dequantized to f32 (the decoders of get_rows): dst[r * ldd + k]
+void dequant_k_rows(const KWeight &w, const int *ids, int64_t rows, float *dst, int64_t ldd) {
+    const dim3 grid((unsigned)((w.nsb * (w.kt == KT_Q4_K || w.kt == KT_Q6_K ? 8 : 16) + 255) / 256), (unsigned)rows);
+    switch (w.kt) {
+        case KT_Q4_K:
+        case KT_Q6_K: hipLaunchKernelGGL(k_get_rows_k, grid, dim3(256), 0, g.stream, w, ids, dst, ldd); break;
+        case KT_Q2_K: hipLaunchKernelGGL(k_get_rows_k2<KT_Q2_K>, grid, dim3(256), 0, g.stream, w, ids, dst, ldd); break;
+        case KT_Q3_K: hipLaunchKernelGGL(k_get_rows_k2<KT_Q3_K>, grid, dim3(256), 0, g.stream, w, ids, dst, ldd); break;
+        default: hipLaunchKernelGGL(k_get_rows_k2<KT_Q5_K>, grid, dim3(256), 0, g.stream, w, ids, dst, ldd); break;
+    }
+    HIP_CHECK(hipGetLastError());
 }
 
 // Resident f16 copy of a quantized weight (kernels/mmq_w16.h): created on first use by a prompt batch and kept as a CACHE:
@@ -1116,10 +1175,10 @@ size_t release_w16_copies() {
                 synced = true;
             }
             HIP_CHECK(hipFree(e->w16));
-            const size_t bytes = (size_t)e->qw.M * e->qw.nb * 64;
-            freed += bytes;
-            g.w16_bytes -= bytes;
+            freed += e->w16_size;
+            g.w16_bytes -= e->w16_size;
             e->w16 = nullptr;
+            e->w16_size = 0;
             e->qw.w16 = nullptr;
         }
     if (freed) g.w16_gen++;  // prompt plans re-read their weights' w16 pointers at the next launch (llama_plan.inc)
@@ -1137,6 +1196,7 @@ bool ensure_w16(DevTensor *e) {
         return false;
     }
     g.w16_bytes += bytes;
+    e->w16_size = bytes;
     const unsigned nblk = (unsigned)((e->qw.M * e->qw.nb + 255) / 256);
     switch (e->qw.qt) {
         case QT_Q4_0: hipLaunchKernelGGL(k_dequant_w16<QT_Q4_0>, dim3(nblk), dim3(256), 0, g.stream, e->qw, (_Float16 *)e->w16); break;
@@ -1148,6 +1208,35 @@ bool ensure_w16(DevTensor *e) {
     }
     HIP_CHECK(hipGetLastError());
     e->qw.w16 = e->w16;
+    return true;
+}
+
+// The same for a planar K-quant weight (kernels/kquant2.h): its rows dequantized by the get_rows decoders (f32, 8192 rows
+// at a time through a temporary), rounded to f16 in the GEMM's k order.
+bool ensure_w16_k(DevTensor *e) {
+    if (!e || !e->ksoa || !g.opt_mmq_w16) return false;
+    if (e->w16) return true;
+    const int64_t M = e->kw.M, K = e->kw.nsb * 256, chunk = std::min<int64_t>(M, 8192);
+    const size_t bytes = (size_t)M * K * 2, tmp_bytes = (size_t)chunk * K * 4;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + tmp_bytes + w16_headroom()) return false;
+    float *tmp = nullptr;
+    if (hipMalloc((void **)&e->w16, bytes) != hipSuccess || hipMalloc((void **)&tmp, tmp_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e->w16) HIP_CHECK(hipFree(e->w16));
+        e->w16 = nullptr;
+        return false;
+    }
+    for (int64_t r0 = 0; r0 < M; r0 += chunk) {
+        const int64_t n = std::min(chunk, M - r0);
+        dequant_k_rows(kw_rows(e->kw, r0, n), nullptr, n, tmp, K);
+        hipLaunchKernelGGL(k_f32_to_w16, grid1(n * K), dim3(256), 0, g.stream, tmp, n * K / 32, (_Float16 *)e->w16 + r0 * K);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    HIP_CHECK(hipFree(tmp));
+    g.w16_bytes += bytes;
+    e->w16_size = bytes;
     return true;
 }
 
@@ -1433,6 +1522,37 @@ void mul_mat_q_mfma(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tenso
                    dst->nb[0] == 4 && ggml_is_contiguous(dst));
 }
 
+// K-quant prompt batch on the f16 GEMM: the weight's resident f16 copy x the activations after their Q8_K round trip
+// (f16(d8 * q): what ggml's K-quant dots see of src1).  Same kernels and tile rules as the other formats; the f16 rounding
+// of both operands is the approximation those already make.  false = not applicable here (the caller streams the weight
+// through the mat-vec kernel instead): options off, a view / workspace weight, fewer than 64 tokens without a copy yet, no HBM.
+bool mul_mat_k_gemm(const ggml_tensor *src0, const ggml_tensor *src1, ggml_tensor *dst) {
+    if (!(g.opt_mmq_w16 && g.opt_mmq_persist && g.opt_mmq_dma == 1) || g.opt_mmq_i8) return false;
+    if (dst->type != GGML_TYPE_F32 || dst->nb[0] != 4 || src1->ne[2] != 1 || src1->ne[3] != 1) return false;
+    DevTensor *e = extra_of(src0);
+    if (!e) e = find_tensor((uintptr_t)src0->data);
+    if (!(e && e->ksoa && (uintptr_t)src0->data == e->host)) return false;
+    const int64_t K = src1->ne[0], N = src1->ne[1], nsb = K / 256;
+    if (!e->w16 && N < W16_MIN_TOKENS) return false;
+    if (!ensure_w16_k(e)) return false;
+    _Float16 *x16 = (_Float16 *)ws_alloc((size_t)N * K * 2);
+    {
+        Timed tm(GGML_HIP_KCLASS_OTHER, (double)(K * N * 6));
+        hipLaunchKernelGGL(k_quant_act_f16_k, dim3((unsigned)nsb, (unsigned)N), dim3(256), 0, g.stream, dev_ptr(src1),
+                           (int64_t)src1->nb[1], nsb, x16);
+        HIP_CHECK(hipGetLastError());
+    }
+    QWeight w;
+    memset(&w, 0, sizeof(w));
+    w.M = e->kw.M;
+    w.nb = K / 32;
+    w.qt = QT_Q8_0;  // never read: every kernel that takes a resident copy reads only w16
+    w.w16 = e->w16;
+    mmq_f16_launch(QT_Q8_0, w, x16, nullptr, nullptr, (float *)dev_ptr(dst), (int64_t)dst->nb[1] / 4, N, K / 32,
+                   ggml_is_contiguous(dst));
+    return true;
+}
+
 int pick_rows(int64_t M) {
     if (g.opt_mmvq_rows == 1 || g.opt_mmvq_rows == 2 || g.opt_mmvq_rows == 4) return g.opt_mmvq_rows;
     return M >= 16384 ? 2 : 1;
@@ -1716,9 +1836,7 @@ void op_get_rows(ggml_tensor *dst) {
         hipLaunchKernelGGL(k_get_rows_q, dim3((unsigned)((w.nb + 255) / 256), (unsigned)N), dim3(256), 0, g.stream, w,
                            pid, pd, ne0);
     } else if (kt_of(tab->type) >= 0) {
-        const KWeight w = kweight_of(tab);
-        hipLaunchKernelGGL(k_get_rows_k, dim3((unsigned)((w.nsb * 8 + 255) / 256), (unsigned)N), dim3(256), 0, g.stream, w, pid,
-                           pd, ne0);
+        dequant_k_rows(kweight_of(tab), pid, N, pd, ne0);
     } else if (tab->type == GGML_TYPE_F16) {
         hipLaunchKernelGGL(k_get_rows<__half>, dim3((unsigned)((ne0 + 255) / 256), (unsigned)N), dim3(256), 0, g.stream,
                            (const char *)dev_ptr(tab), (int64_t)tab->nb[1], pid, pd, ne0);

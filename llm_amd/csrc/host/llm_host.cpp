@@ -45,6 +45,7 @@ struct ModelParameters {
     long n_gqa = -1;
     // layer-split extension: this process owns layers [layer_begin, layer_end)
     size_t layer_begin = 0, layer_end = (size_t)-1;
+    int main_device = -1;  // >= 0: a stage of an in-process layer split, bound to this device slot
 
     bool should_offload(size_t layer) const {
         if (!use_gpu) return false;
@@ -97,7 +98,9 @@ class InferenceSession {
             return (size_t)size + (5 + 10 * n_layer) * 256;  // object overhead
         }();
         if (params.use_gpu) {
-            ggml::accelerator::initialize(0);
+            // inference_session.rs: ggml::accelerator::initialize(0).  A stage of an in-process layer split lives on its
+            // own device slot, which llm_start_session made current: it must stay current (and the caller's split stay set)
+            if (params.main_device < 0) ggml::accelerator::initialize(0);
             ggml::accelerator::set_scratch_size(config.n_batch * 1024 * 1024);
         }
         session_ctx_ = std::make_shared<Context>(Context::new_with_allocate(context_byte_size));
@@ -612,6 +615,7 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
             llm::ModelParameters ps = p;
             ps.layer_begin = bounds[i];
             ps.layer_end = bounds[i + 1];
+            ps.main_device = slots[i];
             ggml_hip_set_main_device(slots[i]);
             m->stages.push_back(new llm::Llama(h, ps, llm::TensorLoader(tensors, n_tensors)));
             m->devices.push_back(slots[i]);

@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_mmvq_k(const MmvqKArgs a) {
 __global__ void k_get_rows_k(const KWeight w, const int *__restrict__ ids, float *dst, int64_t ldd) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= w.nsb * 8) return;
-    const int64_t sb = t >> 3, row = ids[blockIdx.y], g = row * w.nsb + sb;
+    const int64_t sb = t >> 3, row = ids ? ids[blockIdx.y] : (int64_t)blockIdx.y, g = row * w.nsb + sb;
     const int c = (int)(t & 7);
     float *y = dst + (int64_t)blockIdx.y * ldd + sb * 256;
     const uint8_t *q = w.qs + g * 128 + c * 16;

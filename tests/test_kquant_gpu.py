@@ -1,7 +1,7 @@
-"""GPU parity of the K-quant path: Q4_K and Q6_K weights — the super-block formats the reference's
-bindings name (crates/ggml/sys/src/lib.rs:3103-3108, 3240-3245; activation side block_q8_K :3303-3307; file types
-crates/llm-base/src/loader.rs:88-143) — through the C ABI against the oracle's restatement of k_quants.c
-(vec_dot_q4_K_q8_K, vec_dot_q6_K_q8_K, quantize_row_q8_K, dequantize_row_q*_K).
+"""GPU parity of the K-quant path: Q2_K, Q3_K, Q4_K, Q5_K and Q6_K weights — the super-block formats
+the reference's bindings name (crates/ggml/sys/src/lib.rs:2977, 3040, 3103-3108, 3166, 3240-3245; activation side
+block_q8_K :3303-3307; file types crates/llm-base/src/loader.rs:80-143) — through the C ABI against the oracle's
+restatement of k_quants.c (vec_dot_q*_K_q8_K, quantize_row_q8_K, dequantize_row_q*_K).
 
 The library has no K-quant ENCODER (files arrive pre-quantized), so the test weights are encoded by the oracle; what is
 under test is everything after that: upload re-layout, the Q8_K activation quantizer, the mat-vec and get_rows.
@@ -14,7 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KTYPES = [12, 14]  # q4_K q6_K
+KTYPES = [10, 11, 12, 13, 14]  # q2_K q3_K q4_K q5_K q6_K
 
 
 def _mul_mat_gpu(G, wtype, W_raw, M, K, X, transform=True):
@@ -127,7 +127,7 @@ TINY_K = dict(n_vocab=256, n_embd=256, n_head=4, n_head_kv=4, n_layer=2, n_rot=6
 
 @pytest.mark.parametrize("wtype", KTYPES)
 def test_llama_with_k_quant_weights_matches_oracle(G, O, wtype):
-    """A two-layer LLaMA whose 2-D weights are all Q4_K (or all Q6_K) through the session API: prompt chunks and decode
+    """A two-layer LLaMA whose 2-D weights are all of one K type through the session API: prompt chunks and decode
     steps against the oracle on the same K/V state.  K-quant graphs take the generic executor (the fused decode plan
     matches the 32-wide block types only): the statistic says so."""
     from llm_amd import llama, synth
@@ -159,3 +159,32 @@ def test_llama_with_k_quant_weights_matches_oracle(G, O, wtype):
     assert int(G.lib().ggml_hip_get_stat(b"generic_graphs")) > g0
     sess.free()
     model.free()
+
+
+@pytest.mark.parametrize("wtype", KTYPES)
+@pytest.mark.parametrize("shape", [(256, 512, 64), (384, 1024, 200), (1000, 2048, 96), (512, 4096, 512)])
+def test_prompt_batch_of_a_k_quant_weight_runs_on_the_f16_gemm(G, O, wtype, shape):
+    """64 tokens and more: the weight's resident f16 copy (its dequantized values in f16) times the activations after
+    their Q8_K round trip, on the MFMA GEMM of the other formats (mul_mat_k_gemm).  Against the oracle's exact dots the
+    difference is the f16 rounding of both operands (2^-11 relative each, random sign) plus f32 accumulation:
+    |got - exact| <= 1e-3 * sum|w||x| and 20x below that in the rms; the launch counters say a GEMM kernel ran."""
+    M, K, N = shape
+    rng = np.random.default_rng([wtype, M, K, N])
+    W_raw = _weights(O, wtype, M, K, rng)
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    X[:, ::7] *= 4.0
+    def gemms():
+        return sum(int(G.lib().ggml_hip_get_stat(k)) for k in (b"mmq_launches_w16_p8", b"mmq_launches_w16_256"))
+    n0, b0 = gemms(), int(G.lib().ggml_hip_get_stat(b"w16_bytes"))
+    got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
+    assert gemms() > n0
+    rows = rng.choice(M, 48, replace=False)  # the oracle is a scalar loop
+    rb = O.row_bytes(wtype, K)
+    sub = np.concatenate([W_raw[m * rb:(m + 1) * rb] for m in rows])
+    exact = O.mul_mat(wtype, sub, len(rows), K, X, mode=0)
+    scale = np.abs(X) @ np.abs(_dequant(O, wtype, sub, len(rows), K)).T
+    err = np.abs(got[:, rows] - exact)
+    assert np.all(err <= 1e-3 * scale + 1e-6), float(np.max(err / (scale + 1e-12)))
+    assert float(np.sqrt(np.mean((err / (scale + 1e-12)) ** 2))) <= 1e-4
+    # the copy is a cache entry like the other formats': accounted, and released with the weight
+    assert int(G.lib().ggml_hip_get_stat(b"w16_bytes")) == b0
