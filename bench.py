@@ -33,14 +33,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=128, help="timed decode tokens (BASELINE.md section 3: 128)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "65b", "tiny"])
-    ap.add_argument("--wtype", default="q4_0", choices=["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_k", "q6_k"])
+    ap.add_argument("--wtype", default="q4_0", choices=["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_k", "q3_k", "q4_k", "q5_k", "q6_k"])
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the token after the timed loop")
     ap.add_argument("--roofline-steps", type=int, default=20)
-    ap.add_argument("--mode", default="decode", choices=["decode", "prefill"],
-                    help="decode = BASELINE configs[1] (the metric); prefill = configs[2], 512-token prompt batch on MFMA")
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "feed"],
+                    help="decode = BASELINE configs[1] (the metric); prefill = configs[2], 512-token prompt batch on MFMA; "
+                         "feed = InferenceSession::feed_prompt in chunks of --n-batch (profiling leg)")
+    ap.add_argument("--n-batch", type=int, default=8, help="--mode feed: tokens per Model::evaluate (the reference's default is 8)")
     ap.add_argument("--prefill-tokens", type=int, default=512)
     ap.add_argument("--prefill-steps", type=int, default=5, help="timed 512-token prefill steps of the default run's configs[2] leg (0 = skip)")
     ap.add_argument("--weights", default="gaussian", choices=["gaussian", "blocks"],
@@ -52,7 +54,8 @@ def build_model(args, layer_range=None):
     from llm_amd import ggml, llama, synth
     hp = {"7b": synth.LLAMA_7B, "13b": synth.LLAMA_13B, "65b": synth.LLAMA_65B, "tiny": synth.TINY}[args.model]
     wtype = {"q4_0": ggml.TYPE_Q4_0, "q4_1": ggml.TYPE_Q4_1, "q5_0": ggml.TYPE_Q5_0, "q5_1": ggml.TYPE_Q5_1,
-             "q8_0": ggml.TYPE_Q8_0, "q4_k": ggml.TYPE_Q4_K, "q6_k": ggml.TYPE_Q6_K}[args.wtype]
+             "q8_0": ggml.TYPE_Q8_0, "q2_k": ggml.TYPE_Q2_K, "q3_k": ggml.TYPE_Q3_K, "q4_k": ggml.TYPE_Q4_K, "q5_k": ggml.TYPE_Q5_K,
+             "q6_k": ggml.TYPE_Q6_K}[args.wtype]
     if wtype in ggml.K_TYPES and args.weights == "gaussian":
         args.weights = "blocks"  # the library has no K-quant encoder
     t0 = time.perf_counter()
@@ -496,6 +499,34 @@ def run_prefill(args):
     model.free()
 
 
+def run_feed(args):
+    """feed_prompt of --prompt tokens in chunks of --n-batch (inference_session.rs:315-316), --steps times over (rewind in
+    between): the steady rate of the multi-token plan, and a workload rocprofv3 can be pointed at."""
+    from llm_amd import ggml
+    L = ggml.lib()
+    hp, w, model, prep = build_model(args)
+    nb = args.n_batch
+    sess = model.start_session(n_batch=nb)
+    prompt = np.random.default_rng(42).integers(0, hp["n_vocab"], args.prompt).astype(np.int32)
+    sess.feed_prompt(prompt)
+    n_again = (args.prompt - nb) // nb * nb
+    times = []
+    for _ in range(max(1, args.steps)):
+        assert sess.rewind(n_again) == 0
+        L.ggml_hip_synchronize()
+        t0 = time.perf_counter()
+        sess.feed_prompt(prompt[args.prompt - n_again:])
+        L.ggml_hip_synchronize()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    print(json.dumps({"metric": f"prompt feed tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()} n_batch={nb}",
+                      "value": round(n_again / t, 1), "unit": "tokens/s", "n_gpus": 1, "steps": len(times),
+                      "ms_per_chunk": round(t * 1e3 / (n_again // nb), 4), "tokens_per_pass": n_again, "n_batch": nb,
+                      "n_past_range": [args.prompt - n_again, args.prompt], "data": "synthetic"}), flush=True)
+    sess.free()
+    model.free()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -505,6 +536,9 @@ def main():
         return
     if args.mode == "prefill":
         run_prefill(args)
+        return
+    if args.mode == "feed":
+        run_feed(args)
         return
     run_single(args)
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GGML_HIP_LIB") or os.path.join(_HERE, "libggml_hip.so
 
 # enums (include/ggml_hip.h)
 TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q4_1, TYPE_Q5_0, TYPE_Q5_1, TYPE_Q8_0, TYPE_Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9
-TYPE_Q4_K, TYPE_Q6_K, TYPE_Q8_K = 12, 14, 15  # K-quants that run on the device (kernels/kquant.h); Q8_K is their activation type
+TYPE_Q2_K, TYPE_Q3_K, TYPE_Q4_K, TYPE_Q5_K, TYPE_Q6_K, TYPE_Q8_K = 10, 11, 12, 13, 14, 15  # K-quants (kernels/kquant.h, kquant2.h); Q8_K is their activation type
 TYPE_I8, TYPE_I16, TYPE_I32 = 16, 17, 18
 BACKEND_CPU, BACKEND_GPU, BACKEND_GPU_SPLIT = 0, 10, 20
 OP_NONE, OP_MUL_MAT = 0, 21
@@ -25,16 +25,21 @@ COMM_ID_BYTES = 128  # GGML_HIP_COMM_ID_BYTES
 KKIND_BASE = 16  # + {0 wq|wk|wv, 1 wo, 2 w1|w3, 3 w2, 4 lm_head}: one kind of decode mat-vec (bench_plan_class)
 
 TYPE_NAMES = {TYPE_F32: "f32", TYPE_F16: "f16", TYPE_Q4_0: "q4_0", TYPE_Q4_1: "q4_1", TYPE_Q5_0: "q5_0",
-              TYPE_Q5_1: "q5_1", TYPE_Q8_0: "q8_0", TYPE_Q4_K: "q4_K", TYPE_Q6_K: "q6_K", TYPE_I32: "i32"}
+              TYPE_Q5_1: "q5_1", TYPE_Q8_0: "q8_0", TYPE_Q2_K: "q2_K", TYPE_Q3_K: "q3_K", TYPE_Q4_K: "q4_K", TYPE_Q5_K: "q5_K",
+              TYPE_Q6_K: "q6_K", TYPE_I32: "i32"}
 BLOCK_BYTES = {TYPE_F32: 4, TYPE_F16: 2, TYPE_Q4_0: 18, TYPE_Q4_1: 20, TYPE_Q5_0: 22, TYPE_Q5_1: 24, TYPE_Q8_0: 34,
-               TYPE_Q8_1: 40, TYPE_Q4_K: 144, TYPE_Q6_K: 210, TYPE_Q8_K: 292, TYPE_I8: 1, TYPE_I16: 2, TYPE_I32: 4}
+               TYPE_Q8_1: 40, TYPE_Q2_K: 84, TYPE_Q3_K: 110, TYPE_Q4_K: 144, TYPE_Q5_K: 176, TYPE_Q6_K: 210, TYPE_Q8_K: 292,
+               TYPE_I8: 1, TYPE_I16: 2, TYPE_I32: 4}
 BLOCK_ELEMS = {TYPE_F32: 1, TYPE_F16: 1, TYPE_Q4_0: 32, TYPE_Q4_1: 32, TYPE_Q5_0: 32, TYPE_Q5_1: 32, TYPE_Q8_0: 32,
-               TYPE_Q8_1: 32, TYPE_Q4_K: 256, TYPE_Q6_K: 256, TYPE_Q8_K: 256, TYPE_I8: 1, TYPE_I16: 1, TYPE_I32: 1}
+               TYPE_Q8_1: 32, TYPE_Q2_K: 256, TYPE_Q3_K: 256, TYPE_Q4_K: 256, TYPE_Q5_K: 256, TYPE_Q6_K: 256, TYPE_Q8_K: 256,
+               TYPE_I8: 1, TYPE_I16: 1, TYPE_I32: 1}
 QUANT_TYPES = (TYPE_Q4_0, TYPE_Q4_1, TYPE_Q5_0, TYPE_Q5_1, TYPE_Q8_0)
-K_TYPES = (TYPE_Q4_K, TYPE_Q6_K)  # files arrive pre-quantized: the library has no K-quant encoder (ggml_quantize_q4_K ...)
+K_TYPES = (TYPE_Q2_K, TYPE_Q3_K, TYPE_Q4_K, TYPE_Q5_K, TYPE_Q6_K)  # files arrive pre-quantized: the library has no K-quant encoder (ggml_quantize_q4_K ...)
 # llama.cpp ftype codes for GGJT files (crates/ggml/sys/src/llama.rs:16-32)
 FTYPE_OF = {TYPE_F32: 0, TYPE_F16: 1, TYPE_Q4_0: 2, TYPE_Q4_1: 3, TYPE_Q8_0: 7, TYPE_Q5_0: 8, TYPE_Q5_1: 9,
-            TYPE_Q4_K: 14, TYPE_Q6_K: 18}  # ... MOSTLY_Q4_K_S = 14, MOSTLY_Q6_K = 18
+            # synthetic files whose 2-D tensors are ALL of one K type carry the nearest llama.cpp code (real Q*_K_S / _M files
+            # mix types per tensor; the loader reads each tensor's own type, the code is informational: loader.rs:32-36)
+            TYPE_Q2_K: 10, TYPE_Q3_K: 11, TYPE_Q4_K: 14, TYPE_Q5_K: 16, TYPE_Q6_K: 18}
 
 
 class ggml_tensor(C.Structure):

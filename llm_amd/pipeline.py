@@ -283,6 +283,8 @@ def run_bench(args):
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device) if device is not None else torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    ranges = [None] * world  # what every rank holds: [layer_begin, layer_end, local device]
+    dist.all_gather_object(ranges, [lb, le, int(os.environ["GGML_HIP_DEVICE"])])
     if rank == 0:
         total_tokens = n_seq * args.steps
         out = {"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}",
@@ -294,6 +296,7 @@ def run_bench(args):
                                       f"{world} GPUs ({le - lb} layers/GPU), {n_seq} sequences in flight (one per stage), "
                                       f"{args.prompt}-token prompts, ctx {ctx}, f16 KV",
                           "parallelism": f"pp{world} layer split, residual hop: " + ("RCCL send/recv inside the library" if use_rccl else "host copies over gloo (fewer GPUs than ranks)"),
+                          "layer_ranges_by_rank": ranges,
                           "sequences_in_flight": n_seq,
                           "single_stream_tokens_per_s": round(args.steps / elapsed, 2),
                           "comm_backend": backend, "comm_ranks_seen_by_rccl": comm_ranks},
