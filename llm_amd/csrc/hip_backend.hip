@@ -2996,6 +2996,58 @@ int ggml_hip_debug_prompt_attention(const float *q, const uint16_t *mem_k, const
     return 0;
 }
 
+// Test hook: one weight matrix times N (2..8) activation rows through k_mmq_cols exactly as the multi-token plan launches it
+// (k_quant_row with its [block][8] tables, then the EPI_STORE launch).  w: a quantized 2-D weight with a device copy;
+// x: host [N][K] f32; out: host [N][M] f32.  Returns 0, or -1 when the plan would not take this shape on k_mmq_cols.
+int ggml_hip_debug_mul_mat_cols(const struct ggml_tensor *w, const float *x, float *out, int N) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    ensure_init();
+    finish_pending();
+    const int qt = qt_of(w->type);
+    if (qt < 0 || N < 2 || N > 8) return -1;
+    const QWeight qw = qweight_of(w);
+    const int64_t K = w->ne[0], M = w->ne[1], nb = K / 32;
+    if (!cols_ok((int)M, 1, nb, {M})) return -1;
+    const bool f16d = qt == QT_Q4_0 || qt == QT_Q5_0 || qt == QT_Q8_0;
+    char *dx, *dlo, *dhi, *dd, *ds, *ddT, *dsT, *dout;
+    dev_malloc((void **)&dx, (size_t)N * K * 4, "debug x");
+    dev_malloc((void **)&dlo, (size_t)N * K / 2, "debug lo");
+    dev_malloc((void **)&dhi, (size_t)N * K / 2, "debug hi");
+    dev_malloc((void **)&dd, (size_t)N * nb * 4, "debug d");
+    dev_malloc((void **)&ds, (size_t)N * nb * 4, "debug s");
+    dev_malloc((void **)&ddT, (size_t)nb * 32, "debug dT");
+    dev_malloc((void **)&dsT, (size_t)nb * 32, "debug sT");
+    dev_malloc((void **)&dout, (size_t)N * M * 4, "debug out");
+    h2d_bulk(dx, x, (size_t)N * K * 4);
+    HIP_CHECK(hipMemsetAsync(ddT, 0, (size_t)nb * 32, g.stream));
+    HIP_CHECK(hipMemsetAsync(dsT, 0, (size_t)nb * 32, g.stream));
+    HIP_CHECK(hipMemsetAsync(dout, 0xFF, (size_t)N * M * 4, g.stream));
+    const dim3 grid((unsigned)((nb * 32 + 255) / 256), (unsigned)N);
+    if (f16d)
+        hipLaunchKernelGGL(k_quant_row<true>, grid, dim3(256), 0, g.stream, (const float *)dx, (int)nb, (int8_t *)dlo, (int8_t *)dhi,
+                           (float *)dd, (int *)ds, (float *)ddT, (int *)dsT);
+    else
+        hipLaunchKernelGGL(k_quant_row<false>, grid, dim3(256), 0, g.stream, (const float *)dx, (int)nb, (int8_t *)dlo, (int8_t *)dhi,
+                           (float *)dd, (int *)ds, (float *)ddT, (int *)dsT);
+    HIP_CHECK(hipGetLastError());
+    ColsArgs c;
+    memset(&c, 0, sizeof(c));
+    c.d.w[0] = qw;
+    c.d.x = QAct{(const i32x4 *)dlo, (const i32x4 *)dhi, (const float *)dd, (const int *)ds};
+    c.d.nb = nb;
+    c.d.dst = (float *)dout;
+    c.ncols = N;
+    c.ldd = M;
+    c.ldr = M;
+    c.dxT = (const float *)ddT;
+    c.sxT = (const int *)dsT;
+    launch_cols_t<EPI_STORE>(qt, c, (int)M);
+    d2h_queue(out, dout, (size_t)N * M * 4);
+    d2h_finish();
+    for (char *b : {dx, dlo, dhi, dd, ds, ddT, dsT, dout}) HIP_CHECK(hipFree(b));
+    return 0;
+}
+
 int ggml_hip_decode_greedy_chain(struct ggml_cgraph *last, int n, int32_t *out_tokens, float *last_logits) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     return decode_greedy_chain(last, n, out_tokens, last_logits);

@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(128) k_rope_table(const DecParams *__restrict_
 template <bool F16_D>
 __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict__ x, const float *__restrict__ w,
                                                         float eps, int E, float *y_f32 /*nullable*/, int8_t *lo,
-                                                        int8_t *hi, float *dq, int *sumq) {
+                                                        int8_t *hi, float *dq, int *sumq,
+                                                        float *dT = nullptr /* [E/32][8] copy of the scales, row r in column r */,
+                                                        int *sT = nullptr /* ... of the sums (k_mmq_cols stages them by DMA) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_y = (float *)smem;                 // E floats
     __shared__ double s_part[16];
@@ -104,10 +106,29 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
         dq += r * (E / 32);
         sumq += r * (E / 32);
     }
+    // the row and the norm weight are fetched once, all loads in flight together (E <= 8192: 8 elements per thread; the
+    // sums run in the order of the plain loops they replace)
+    constexpr int PT = 8;
+    const bool in_regs = E <= PT * 1024;
+    float xv[PT], wv[PT];
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const int i = tid + k * 1024;
+            xv[k] = i < E ? x[i] : 0.0f;
+            wv[k] = i < E ? w[i] : 0.0f;
+        }
+    }
     double s = 0.0;
-    for (int i = tid; i < E; i += 1024) {
-        const float v = x[i];
-        s += (double)(v * v);
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < PT; k++)
+            if (tid + k * 1024 < E) s += (double)(xv[k] * xv[k]);
+    } else {
+        for (int i = tid; i < E; i += 1024) {
+            const float v = x[i];
+            s += (double)(v * v);
+        }
     }
     s = wave_sum_f64(s);
     if ((tid & 63) == 0) s_part[tid >> 6] = s;
@@ -117,10 +138,22 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
     for (int i = 0; i < 16; i++) tot += s_part[i];
     const float mean = (float)(tot / (double)E);
     const float scale = 1.0f / sqrtf(mean + eps);
-    for (int i = tid; i < E; i += 1024) {
-        const float v = (x[i] * scale) * w[i];
-        s_y[i] = v;
-        if (y_f32) y_f32[i] = v;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const int i = tid + k * 1024;
+            if (i < E) {
+                const float v = (xv[k] * scale) * wv[k];
+                s_y[i] = v;
+                if (y_f32) y_f32[i] = v;
+            }
+        }
+    } else {
+        for (int i = tid; i < E; i += 1024) {
+            const float v = (x[i] * scale) * w[i];
+            s_y[i] = v;
+            if (y_f32) y_f32[i] = v;
+        }
     }
     __syncthreads();
     const int nblk = E / 32, l = tid & 31;
@@ -137,6 +170,10 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
         if (l == 0) {
             dq[b] = F16_D ? round_f16(d) : d;
             sumq[b] = sq;
+            if (dT) {
+                dT[b * 8 + blockIdx.x] = F16_D ? round_f16(d) : d;
+                sT[b * 8 + blockIdx.x] = sq;
+            }
         }
     }
 }
@@ -144,7 +181,7 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
 // re-quantize a plain f32 row (the FFN gate before w2): 32 lanes per block
 template <bool F16_D>
 __global__ void __launch_bounds__(256) k_quant_row(const float *__restrict__ x, int nblk, int8_t *lo, int8_t *hi,
-                                                   float *dq, int *sumq) {
+                                                   float *dq, int *sumq, float *dT = nullptr, int *sT = nullptr) {
     const int b = (blockIdx.x * 256 + threadIdx.x) >> 5, l = threadIdx.x & 31;
     if (b >= nblk) return;
     {  // blockIdx.y = activation row
@@ -167,6 +204,10 @@ __global__ void __launch_bounds__(256) k_quant_row(const float *__restrict__ x, 
     if (l == 0) {
         dq[b] = F16_D ? round_f16(d) : d;
         sumq[b] = sq;
+        if (dT) {
+            dT[b * 8 + blockIdx.y] = F16_D ? round_f16(d) : d;
+            sT[b * 8 + blockIdx.y] = sq;
+        }
     }
 }
 
@@ -509,7 +550,8 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
                                                       float scale, int D, int n_rep /* H / Hkv */, int64_t Egqa,
                                                       int64_t C, float *out_f32, int8_t *lo, int8_t *hi, float *dq,
                                                       int *sumq, long long *ts, int n_head, const PrefetchArgs pf,
-                                                      int64_t Clds /* positions the LDS arrays hold (<= C, % 8 == 0) */) {
+                                                      int64_t Clds /* positions the LDS arrays hold (<= C, % 8 == 0) */,
+                                                      float *dT = nullptr, int *sT = nullptr /* as k_rmsnorm_quant */) {
     // Workgroups past the heads (decode only; the plan launches one per otherwise idle CU) pull weights of the next two
     // mat-vecs into the L2 of the XCD that will read them (see prefetch_slice).
     if ((int)blockIdx.x >= n_head) {
@@ -661,6 +703,10 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
         if (l == 0) {
             dq[gb] = F16_D ? round_f16(d) : d;
             sumq[gb] = sq;
+            if (dT) {
+                dT[((int64_t)h * nblk + b) * 8 + qn] = F16_D ? round_f16(d) : d;
+                sT[((int64_t)h * nblk + b) * 8 + qn] = sq;
+            }
         }
     }
     if (ts && tid == 0) {

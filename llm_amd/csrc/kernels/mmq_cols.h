@@ -15,26 +15,36 @@
 // ggml's contract is kept: activations re-quantized to Q8_0 / Q8_1, exact int32 block dots, f32 accumulation across
 // blocks (only the order of that f32 sum differs: 2e-5 * scale, the mat-vec bound of tests/test_ops_gpu.py).
 //
-// Work split: the workgroup (8 waves) owns a contiguous range of 16-row groups; a unit = (group, chunk of `kc` blocks of
-// K) goes to wave (unit % 8); partial sums of a row's chunks meet in LDS in chunk order (deterministic), then the
-// epilogues of decode_big8.h run (store / +residual / silu(w1 x) * w3 x / RoPE + K,V store per token).
+// Work split (round 3, after the in-kernel timeline of tests/tools/cols_timeline.py): the workgroup (8 waves) owns a
+// contiguous range of 16-row groups; wave w owns the K range [K w / 8, K (w + 1) / 8) (in steps of 4 blocks) of EVERY group
+// of the workgroup: a unit = (group, matrix) costs every wave the same number of steps, nothing is divided at run time, and
+// the eight partial sums of a row meet in LDS in wave order (deterministic).  Then the epilogues of decode_big8.h run
+// (store / +residual / silu(w1 x) * w3 x / RoPE + K,V store per token).
+// Staging: the activation planes and the [block][8] scale / sum tables (written in that layout by the producing kernels:
+// ColsArgs::dxT, sxT) go to LDS by LDS-DMA in front of the weight ring; the first barrier waits for them only
+// (s_waitcnt vmcnt(ring loads)), not for the ring (12.5 MB chip-wide: 2.7 us at HBM speed).
 #pragma once
 #include "decode_big8.h"
+#include "mmq_dma.h"
 
 struct ColsArgs {
     DecMmvqArgs d;     // d.x: Q8 rows [ncols][nb] (planar), d.dst / d.res: row 0
     int ncols;         // 2..8
     int64_t ldd, ldr;  // floats between consecutive rows of dst / res
     const float *rope; // EPI_QKV: (cos, sin) tables of the chunk's positions, 128 floats per token (k_rope_table)
-    int kc;            // blocks per K chunk (multiple of 4)
+    const float *dxT;  // activation scales transposed: [nb][8] (column c of block b at b * 8 + c; zeros for c >= ncols)
+    const int *sxT;    // activation quant sums, same layout
     int ngroups;       // 16-row groups (EPI_GATE: pairs of a w1 and a w3 group) in the launch
+    int gq, gr;        // ngroups / gridDim.x and ngroups % gridDim.x: workgroup b owns gq (+1 if b < gr) groups from b * gq + min(b, gr)
+    long long *ts;     // INSTR build only (option "timeline"): 8 x int64 per sampled workgroup, as BigArgs::ts
+    int ts_wgs;
 };
 
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 #define COLS_T 512
 #define COLS_W 8
-#define COLS_MAX_UNITS 96  /* (sub-group, chunk) units of a workgroup: 48 KB of partial sums */
+#define COLS_MAX_UNITS 12  /* (group, matrix) units of a workgroup: 8 x 512 B of partial sums each */
 
 template <int QT>
 struct ColsStep {
@@ -56,28 +66,43 @@ __device__ __forceinline__ float cols_scale(int sumi, float dw, float mw, float 
     }
 }
 
-template <int QT, int EPI>
+// INSTR: the measurement build (timeline stamps of wave 0 in sampled workgroups: tests/tools/cols_timeline.py), launched only
+// while option "timeline" is set; the production instantiation carries none of it.
+template <int QT, int EPI, bool INSTR = false>
 __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
     const DecMmvqArgs &a = ca.d;
+    long long t_in = 0, t_pre = 0, t_dma = 0, t_issued = 0, t_staged = 0, t_loop = 0, t_sync2 = 0;
+    if constexpr (INSTR) t_in = big_now();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NSUB = EPI == EPI_GATE ? 2 : 1;  // weight matrices a group draws rows from (w1 and w3)
+    constexpr int LPS = QT == QT_Q4_0 ? 2 : QT == QT_Q5_1 ? 4 : 3;  // VMEM loads of one ring step (issue below)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ncols = ca.ncols, nb = (int)a.nb, kc = ca.kc;
-    const int nk = (nb + kc - 1) / kc;
+    const int ncols = ca.ncols, nb = (int)a.nb;
     // LDS: activation planes [8][nb] x 16 B (low / high halves), per-block scales and quant sums [nb][8],
-    // the partial sums [unit][16 rows][8 columns]
+    // the partial sums [unit][wave][16 rows][8 columns]
     i32x4 *s_lo = (i32x4 *)smem;
     i32x4 *s_hi = s_lo + 8 * nb;
     float *s_dx = (float *)(s_hi + 8 * nb);
     int *s_sx = (int *)(s_dx + 8 * nb);
     float *s_part = (float *)(s_sx + 8 * nb);
 
-    // ---- this workgroup's groups
-    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
-    const int g_begin = (int)(((int64_t)ca.ngroups * bid) / G), g_end = (int)(((int64_t)ca.ngroups * (bid + 1)) / G);
-    const int nlg = g_end - g_begin;             // groups here
-    const int nunits = nlg * NSUB * nk;          // <= COLS_MAX_UNITS (launcher)
+    // ---- this workgroup's groups, this wave's K range
+    const int bid = (int)blockIdx.x;
+    const int g_begin = bid * ca.gq + min(bid, ca.gr);
+    const int nlg = ca.gq + (bid < ca.gr ? 1 : 0);  // groups here (no run-time division: the prologue is a serial scalar chain)
+    const int nu = nlg * NSUB;         // units: <= COLS_MAX_UNITS (launcher)
+    const int nst_all = nb >> 2;       // steps of 4 blocks in a row
+    const int st0 = (nst_all * wave) >> 3, st1 = (nst_all * (wave + 1)) >> 3;
+    const int nst = st1 - st0;         // >= 1 (launcher: nb >= 32)
+    // the weight records in registers up front (one batch of kernarg loads instead of a load + wait inside every unit switch)
+    // (plain scalars: a copy of the QWeight structs lands in scratch)
+    constexpr int I1 = EPI == EPI_GATE ? 1 : 0;
+    const uint8_t *const qsA = a.w[0].qs, *const qsB = a.w[I1].qs;
+    const uint8_t *const qs2A = a.w[0].qs2, *const qs2B = a.w[I1].qs2;
+    const uint32_t *const qhA = a.w[0].qh, *const qhB = a.w[I1].qh;
+    const __half *const wdA = a.w[0].d, *const wdB = a.w[I1].d;
+    const __half *const wmA = a.w[0].m, *const wmB = a.w[I1].m;
     // group -> (matrix, first row)
     const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0;
     auto group_rows = [&](int g, int sub, int &sg, int &m0) {
@@ -97,63 +122,76 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
         m0 = r;
     };
 
-    // ---- activations -> LDS
+    // every kernel argument the prologue needs, fetched as ONE batch of scalar loads: left to itself the compiler loads each
+    // next to its first use, and the prologue becomes a chain of four ~0.35 us kernarg round trips (in-kernel timeline)
     {
-        const int nx = ncols * nb;
-        for (int i = tid; i < 8 * nb; i += COLS_T) {
-            const int c = i / nb, b = i - c * nb;
-            i32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-            float d = 0.0f;
-            int s = 0;
-            if (i < nx) {
-                lo = a.x.lo[i];
-                hi = a.x.hi[i];
-                d = a.x.d[i];
-                s = a.x.sum[i];
-            }
-            s_lo[i] = lo;
-            s_hi[i] = hi;
-            s_dx[b * 8 + c] = d;
-            s_sx[b * 8 + c] = s;
+        const void *p0 = a.x.lo, *p1 = a.x.hi, *p2 = ca.dxT, *p3 = ca.sxT;
+        asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(nb), "s"(ncols), "s"(ca.gq), "s"(ca.gr), "s"(M0), "s"(M1));
+        if constexpr (EPI != EPI_QKV) {
+            const void *p4 = qsA, *p5 = qsB, *p6 = wdA, *p7 = wdB, *p8 = a.dst, *p9 = a.res;
+            asm volatile("" ::"s"(p4), "s"(p5), "s"(p6), "s"(p7), "s"(p8), "s"(p9), "s"(ca.ldd), "s"(ca.ldr));
+            if constexpr (QT == QT_Q8_0) asm volatile("" ::"s"(qs2A), "s"(qs2B));
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) asm volatile("" ::"s"(qhA), "s"(qhB));
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) asm volatile("" ::"s"(wmA), "s"(wmB));
         }
     }
+    if constexpr (INSTR) t_pre = big_now();
+    // ---- activations -> LDS by DMA: every plane has its LDS layout in global memory, one instruction per 1 KB
+    {
+        const int nq = ncols * nb;  // 16-byte items of a quant plane (columns >= ncols stay as they are: never stored)
+        for (int i0 = wave * 64; i0 < nq; i0 += COLS_T) {  // wave-uniform
+            if (i0 + lane < nq) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.x.lo + i0 + lane), (lptr_t)(s_lo + i0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.x.hi + i0 + lane), (lptr_t)(s_hi + i0), 16, 0, 0);
+            }
+        }
+        const int nt = 2 * nb;  // 16-byte items of a [nb][8] table
+        for (int i0 = wave * 64; i0 < nt; i0 += COLS_T) {
+            if (i0 + lane < nt) {
+                __builtin_amdgcn_global_load_lds((gptr_t)((const f32x4 *)ca.dxT + i0 + lane), (lptr_t)((f32x4 *)s_dx + i0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)((const f32x4 *)ca.sxT + i0 + lane), (lptr_t)((f32x4 *)s_sx + i0), 16, 0, 0);
+            }
+        }
+    }
+    asm volatile("" ::: "memory");  // the ring's loads stay behind the DMA (the wait below counts on it)
+    if constexpr (INSTR) t_dma = big_now();
 
-    // ---- the wave's units, a weight ring across them
+    // ---- the wave's steps: unit q = 0 .. nu-1, within a unit the steps st0 .. st1-1; a weight ring across them
     const int jrow = lane & 15, bg = lane >> 4;
     const bool act = ((lane & 15) >> 2) == bg;  // A operand: this lane's row carries a column of its own k group
     const int acol = lane & 3;
     struct Cursor {
-        int u;     // unit index (local): u = (lg * NSUB + sub) * nk + chunk
-        int st;    // super-tile (4 blocks) within the chunk
-        int nst;   // super-tiles of this chunk
+        int q, st;
         const uint8_t *qs, *qs2;
         const uint32_t *qh;
         const __half *wd, *wm;
         uint32_t row_blk;  // (row of this lane) * nb
-        int b0;            // first block of the chunk
     };
-    auto open_unit = [&](Cursor &c, int u) {
-        c.u = u;
-        c.st = 0;
-        if (u >= nunits) {
-            c.nst = 0;
-            return;
-        }
-        const int chunk = u % nk, gs = u / nk, sub = gs % NSUB, lg = gs / NSUB;
+    auto open_unit = [&](Cursor &c, int q) {
+        c.q = q;
+        c.st = st0;
+        if (q >= nu) return;
+        const int sub = q & (NSUB - 1), lg = NSUB == 2 ? q >> 1 : q;
         int sg, m0;
         group_rows(g_begin + lg, sub, sg, m0);
         // scalar selects (sg is wave-uniform): a kernarg array indexed by a "divergent" id is fetched with vector loads
-        c.qs = sg == 0 ? a.w[0].qs : sg == 1 ? a.w[1].qs : a.w[2].qs;
-        c.qs2 = sg == 0 ? a.w[0].qs2 : sg == 1 ? a.w[1].qs2 : a.w[2].qs2;
-        c.qh = sg == 0 ? a.w[0].qh : sg == 1 ? a.w[1].qh : a.w[2].qh;
-        c.wd = sg == 0 ? a.w[0].d : sg == 1 ? a.w[1].d : a.w[2].d;
-        c.wm = sg == 0 ? a.w[0].m : sg == 1 ? a.w[1].m : a.w[2].m;
+        if constexpr (EPI == EPI_QKV) {  // three matrices and the longest epilogue: hoisted copies overflow the SGPRs into scratch
+            c.qs = sg == 0 ? a.w[0].qs : sg == 1 ? a.w[1].qs : a.w[2].qs;
+            if constexpr (QT == QT_Q8_0) c.qs2 = sg == 0 ? a.w[0].qs2 : sg == 1 ? a.w[1].qs2 : a.w[2].qs2;
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) c.qh = sg == 0 ? a.w[0].qh : sg == 1 ? a.w[1].qh : a.w[2].qh;
+            c.wd = sg == 0 ? a.w[0].d : sg == 1 ? a.w[1].d : a.w[2].d;
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) c.wm = sg == 0 ? a.w[0].m : sg == 1 ? a.w[1].m : a.w[2].m;
+        } else {
+            c.qs = sg == 0 ? qsA : qsB;
+            if constexpr (QT == QT_Q8_0) c.qs2 = sg == 0 ? qs2A : qs2B;
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) c.qh = sg == 0 ? qhA : qhB;
+            c.wd = sg == 0 ? wdA : wdB;
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) c.wm = sg == 0 ? wmA : wmB;
+        }
         c.row_blk = (uint32_t)(m0 + jrow) * (uint32_t)nb;
-        c.b0 = chunk * kc;
-        c.nst = (min(nb, c.b0 + kc) - c.b0) >> 2;
     };
     auto issue = [&](ColsStep<QT> &s, const Cursor &c) {
-        const uint32_t o = c.row_blk + (uint32_t)(c.b0 + 4 * c.st + bg);
+        const uint32_t o = c.row_blk + (uint32_t)(4 * c.st + bg);
         s.q = __builtin_nontemporal_load((const u32x4 *)(c.qs + (size_t)o * 16));
         if constexpr (QT == QT_Q8_0) s.p = __builtin_nontemporal_load((const u32x4 *)(c.qs2 + (size_t)o * 16));
         if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) s.h = __builtin_nontemporal_load(c.qh + o);
@@ -161,36 +199,42 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
         if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) s.mw = c.wm[o];
     };
     auto advance = [&](Cursor &c) {
-        if (++c.st >= c.nst) open_unit(c, c.u + COLS_W);
+        if (++c.st >= st1) open_unit(c, c.q + 1);
     };
     constexpr int PF = QT == QT_Q8_0 ? 4 : 6;
     ColsStep<QT> ring[PF];
     Cursor pc;  // producer
-    open_unit(pc, wave);
+    open_unit(pc, 0);
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        if (pc.nst > 0) {
+        if (pc.q < nu) {
             issue(ring[k], pc);
             advance(pc);
         }
     }
+    if constexpr (INSTR) t_issued = big_now();
+    // the DMA is older than the ring's loads: with a full ring in flight, "at most PF * LPS outstanding" means it has landed
+    if (nu * nst >= PF)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * LPS) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // activations staged
+    if constexpr (INSTR) t_staged = big_now();
 
-    Cursor cc;  // consumer
-    open_unit(cc, wave);
+    int cq = 0, cst = st0;  // consumer
     float f[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) f[c] = 0.0f;
-    while (cc.nst > 0) {
+    while (cq < nu) {
 #pragma unroll
         for (int k = 0; k < PF; k++) {
-            if (cc.nst > 0) {  // wave-uniform
+            if (cq < nu) {  // wave-uniform
                 const ColsStep<QT> st = ring[k];
-                if (pc.nst > 0) {
+                if (pc.q < nu) {
                     issue(ring[k], pc);
                     advance(pc);
                 }
-                const int bl = cc.b0 + 4 * cc.st + bg;  // this lane's block (weights, scales, outputs)
+                const int bl = 4 * cst + bg;  // this lane's block (weights, scales, outputs)
                 uint32_t wl[4], wh[4];
                 block_unpack<QT>(st.q, st.p, st.h, wl, wh);
                 const i32x4v bwl = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]}, bwh = {(int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]};
@@ -218,7 +262,7 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) f[4 + c] += cols_scale<QT>(acc[c], dw, mw, xd[c], xs[c]);
                 }
-                if (cc.st + 1 >= cc.nst) {  // the unit is complete: add the four block groups, park the 16 x 8 sums
+                if (++cst >= st1) {  // the wave's part of the unit is complete: add the four block groups, park the 16 x 8 sums
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
                         float v = f[c];
@@ -227,24 +271,28 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
                         f[c] = v;
                     }
                     if (lane < 16) {
-                        float *o = s_part + ((size_t)cc.u * 16 + lane) * 8;
+                        float *o = s_part + ((size_t)(cq * COLS_W + wave) * 16 + lane) * 8;
                         *(f32x4 *)o = f32x4{f[0], f[1], f[2], f[3]};
                         *(f32x4 *)(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
                     }
 #pragma unroll
                     for (int c = 0; c < 8; c++) f[c] = 0.0f;
+                    cst = st0;
+                    cq++;
                 }
-                advance(cc);
             }
         }
     }
+    if constexpr (INSTR) t_loop = big_now();
     __syncthreads();
+    if constexpr (INSTR) t_sync2 = big_now();
 
-    // ---- epilogues: thread per (group, row or row pair, column); chunk partials added in chunk order
+    // ---- epilogues: thread per (group, row or row pair, column); the eight waves' partials added in wave order
     auto total = [&](int lg, int sub, int row, int c) {
-        const float *p = s_part + ((size_t)((lg * NSUB + sub) * nk) * 16 + row) * 8 + c;
+        const float *p = s_part + ((size_t)((lg * NSUB + sub) * COLS_W) * 16 + row) * 8 + c;
         float v = 0.0f;
-        for (int k = 0; k < nk; k++) v += p[(size_t)k * 128];
+#pragma unroll
+        for (int k = 0; k < COLS_W; k++) v += p[(size_t)k * 128];
         return v;
     };
     if constexpr (EPI == EPI_QKV) {
@@ -286,6 +334,13 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
             } else {
                 a.dst[(int64_t)c * ca.ldd + m] = silu_table(v) * total(lg, 1, row, c);
             }
+        }
+    }
+    if constexpr (INSTR) {
+        const int every = ca.ts_wgs > 0 ? max(1, (int)gridDim.x / ca.ts_wgs) : 0;
+        if (ca.ts && every && tid == 0 && (int)blockIdx.x % every == 0 && (int)blockIdx.x / every < ca.ts_wgs) {
+            long long *o = ca.ts + (size_t)((int)blockIdx.x / every) * 8;
+            o[0] = t_in; o[1] = t_pre; o[2] = t_dma; o[3] = t_issued; o[4] = t_staged; o[5] = t_loop; o[6] = t_sync2; o[7] = big_now();
         }
     }
 }
