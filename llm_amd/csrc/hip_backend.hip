@@ -52,12 +52,28 @@
 #include "kernels/prompt.h"
 #include "kernels/prompt_attn.h"
 
+// Last words of the library: stderr, and (GGML_HIP_FATAL_LOG=path) a file — a test runner that captures file descriptor 2
+// swallows the message of an abort together with the process.
+static void fatal_note(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "libggml_hip: %s\n", buf);
+    if (const char *path = getenv("GGML_HIP_FATAL_LOG"))
+        if (FILE *f = fopen(path, "a")) {
+            fprintf(f, "libggml_hip: %s\n", buf);
+            fclose(f);
+        }
+}
+
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
         hipError_t err__ = (expr);                                                                   \
         if (err__ != hipSuccess) {                                                                   \
-            fprintf(stderr, "libggml_hip: HIP error %d (%s) at %s:%d: %s\n", (int)err__,             \
-                    hipGetErrorString(err__), __FILE__, __LINE__, #expr);                            \
+            fatal_note("HIP error %d (%s) at %s:%d: %s", (int)err__, hipGetErrorString(err__), __FILE__,  \
+                       __LINE__, #expr);                                                             \
             abort();                                                                                 \
         }                                                                                            \
     } while (0)
@@ -65,7 +81,7 @@
 #define BK_ASSERT(x)                                                                                 \
     do {                                                                                             \
         if (!(x)) {                                                                                  \
-            fprintf(stderr, "libggml_hip: assertion failed at %s:%d: %s\n", __FILE__, __LINE__, #x); \
+            fatal_note("assertion failed at %s:%d: %s", __FILE__, __LINE__, #x);                     \
             abort();                                                                                 \
         }                                                                                            \
     } while (0)
@@ -73,12 +89,12 @@
 namespace {
 
 [[noreturn]] void die(const char *fmt, ...) {
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
-    fprintf(stderr, "libggml_hip: ");
-    vfprintf(stderr, fmt, ap);
-    fprintf(stderr, "\n");
+    vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
+    fatal_note("%s", buf);
     abort();
 }
 

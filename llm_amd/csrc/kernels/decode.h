@@ -20,7 +20,7 @@ struct DecParams {
     int n_past;   // tokens already in the KV cache = position of the (first) token being evaluated
     int token;    // its id (row of tok_embeddings)
     int pad[2];
-    int tokens[8];  // multi-token plan (2..8 tokens of a prompt chunk): ids of all tokens, tokens[0] == token
+    int tokens[32];  // multi-token plan (2..31 tokens of a prompt chunk): ids of all tokens, tokens[0] == token
 };
 
 // Greedy sampling on the device: token = first index of the maximum logit — what a host loop
@@ -170,9 +170,10 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
         if (l == 0) {
             dq[b] = F16_D ? round_f16(d) : d;
             sumq[b] = sq;
-            if (dT) {
-                dT[b * 8 + blockIdx.x] = F16_D ? round_f16(d) : d;
-                sT[b * 8 + blockIdx.x] = sq;
+            if (dT) {  // rows 8p .. 8p+7 form table p
+                const int64_t o = (int64_t)(blockIdx.x >> 3) * nblk * 8 + b * 8 + (blockIdx.x & 7);
+                dT[o] = F16_D ? round_f16(d) : d;
+                sT[o] = sq;
             }
         }
     }
@@ -205,8 +206,9 @@ __global__ void __launch_bounds__(256) k_quant_row(const float *__restrict__ x, 
         dq[b] = F16_D ? round_f16(d) : d;
         sumq[b] = sq;
         if (dT) {
-            dT[b * 8 + blockIdx.y] = F16_D ? round_f16(d) : d;
-            sT[b * 8 + blockIdx.y] = sq;
+            const int64_t o = (int64_t)(blockIdx.y >> 3) * nblk * 8 + b * 8 + (blockIdx.y & 7);
+            dT[o] = F16_D ? round_f16(d) : d;
+            sT[o] = sq;
         }
     }
 }
@@ -704,8 +706,9 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
             dq[gb] = F16_D ? round_f16(d) : d;
             sumq[gb] = sq;
             if (dT) {
-                dT[((int64_t)h * nblk + b) * 8 + qn] = F16_D ? round_f16(d) : d;
-                sT[((int64_t)h * nblk + b) * 8 + qn] = sq;
+                const int64_t o = (int64_t)(qn >> 3) * (Eq / 32) * 8 + ((int64_t)h * nblk + b) * 8 + (qn & 7);
+                dT[o] = F16_D ? round_f16(d) : d;
+                sT[o] = sq;
             }
         }
     }

@@ -29,7 +29,8 @@
 
 struct ColsArgs {
     DecMmvqArgs d;     // d.x: Q8 rows [ncols][nb] (planar), d.dst / d.res: row 0
-    int ncols;         // 2..8
+    int ncols;         // 1..8 columns of this pass
+    int col0;          // first column of the pass within the chunk (EPI_QKV: K / V positions are n_past + col0 + c)
     int64_t ldd, ldr;  // floats between consecutive rows of dst / res
     const float *rope; // EPI_QKV: (cos, sin) tables of the chunk's positions, 128 floats per token (k_rope_table)
     const float *dxT;  // activation scales transposed: [nb][8] (column c of block b at b * 8 + c; zeros for c >= ncols)
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
             group_rows(g_begin + lg, 0, sg, m0);
             const int m = m0 + 2 * pr;
             const float v0 = total(lg, 0, 2 * pr, c), v1 = total(lg, 0, 2 * pr + 1, c);
-            const int p = n_past + c;
+            const int p = n_past + ca.col0 + c;
             if (sg == 2) {
                 a.mem_v[(int64_t)m * a.C + p] = __float2half_rn(v0);
                 a.mem_v[(int64_t)(m + 1) * a.C + p] = __float2half_rn(v1);

@@ -100,3 +100,35 @@ def test_cols_kernel_matches_big8_and_the_oracle(G, O, wtype, cfg):
     # how often a chunk stays within f32 summation noise of the oracle is reported, not asserted: with 1024-wide rows nearly
     # every chunk moves some activation across an int8 rounding edge; the kernel's own arithmetic is pinned at op level above
     print(f"{cfg} type {wtype}: {n_strict} of {n_all} chunks within {STRICT} of the oracle, {n_same} equal to big8 within 1e-5")
+
+
+@pytest.mark.parametrize("wtype", [2, 7])
+def test_chunks_of_9_to_31_tokens_run_in_passes_and_equal_the_8_token_chunks(G, wtype):
+    """A chunk of 9..31 tokens (below the prompt plan's threshold of 32) is the multi-token plan in passes of 8 columns: every
+    weight matrix streamed once per pass.  A token's arithmetic does not depend on which other tokens share its chunk (same
+    kernels, columns independent), so feeding [31, 9, 16] must reproduce [8, 8, 8, ...] BIT FOR BIT: logits of every token
+    and the K/V cache; the counters say the fused plan ran every token."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(GQA2, wtype, seed=11)
+    model = llama.Llama(hp, w, context_size=96)
+    toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 56).astype(np.int32)
+
+    def run(n_batch, sizes):
+        sess = model.start_session(n_batch=n_batch)
+        p0, g0 = _stat(G, "plan_tokens"), _stat(G, "generic_graphs")
+        outs, at = [], 0
+        for n in sizes:
+            outs.append(sess.evaluate(toks[at:at + n]))
+            at += n
+        assert at == len(toks)
+        assert _stat(G, "plan_tokens") - p0 == len(toks) and _stat(G, "generic_graphs") == g0
+        k, v = sess.get_kv()
+        sess.free()
+        return np.concatenate(outs), k, v
+
+    a, ka, va = run(31, [31, 9, 16])
+    b, kb, vb = run(8, [8] * 7)  # (a last chunk of ONE token would be the decode plan: another kernel, another sum order)
+    assert a.shape == b.shape == (56, hp["n_vocab"])
+    assert np.array_equal(a, b)
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    model.free()
