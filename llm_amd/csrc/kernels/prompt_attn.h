@@ -27,12 +27,15 @@ struct PAttnArgs {
     int64_t C;
     float scale;
     int row_bytes;       // LDS bytes per score row
+    long long *ts;       // INSTR build (option "timeline"): 8 x int64 per workgroup, see tests/tools/pattn_timeline.py
 };
 
 #define PATTN_Q 32
 
-template <int D>
+template <int D, bool INSTR = false>
 __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if constexpr (INSTR) t0 = (long long)wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int KS = D / 16;      // MFMA k steps of a K.Q tile
     constexpr int NWV = D / 32;     // waves that take part in V.P
@@ -63,6 +66,7 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
             }
         }
     }
+    if constexpr (INSTR) t1 = (long long)wall_clock64();
     // ---- S phase
     auto load_k = [&](int kt, f16x8 (&kb)[KS]) {
         const int64_t t = min((int64_t)kt * 32 + fr, a.C - 1);
@@ -71,55 +75,88 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         for (int ks = 0; ks < KS; ks++) kb[ks] = *(const f16x8 *)(kp + ks * 16);
     };
     {
-        f16x8 kb[2][KS];
-        if (wave < nkt) load_k(wave, kb[0]);
-        int cur = 0;
-        for (int kt = wave; kt < nkt; kt += 4) {
-            // two named buffers: the index is made static by unrolling the pair
+        // K fragments of up to three of the wave's key tiles in flight (96 VGPRs for D = 128; 2 waves per SIMD leave 256):
+        // with one tile ahead the phase ran at one L2 / HBM round trip per tile (in-kernel timeline, 2.1 us per tile)
+        constexpr int KR = 3;
+        f16x8 kb[KR][KS];
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                if (half == cur) {
-                    if (kt + 4 < nkt) load_k(kt + 4, kb[half ^ 1]);
+        for (int j = 0; j < KR - 1; j++)
+            if (wave + 4 * j < nkt) load_k(wave + 4 * j, kb[j]);
+        for (int kt0 = wave; kt0 < nkt; kt0 += 4 * KR) {
+#pragma unroll
+            for (int j = 0; j < KR; j++) {
+                const int kt = kt0 + 4 * j;
+                if (kt < nkt) {  // wave-uniform
+                    if (kt + 4 * (KR - 1) < nkt) load_k(kt + 4 * (KR - 1), kb[(j + KR - 1) % KR]);
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kb[half][ks], acc, 0, 0, 0);
+                    for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kb[j][ks], acc, 0, 0, 0);
                     float *sp = (float *)(lds + 4 * fh * rb) + kt * 32 + fr;
 #pragma unroll
                     for (int r = 0; r < 16; r++) *(float *)((char *)sp + ((r & 3) + 8 * (r >> 2)) * rb) = acc[r];
                 }
             }
-            cur ^= 1;
         }
     }
     __syncthreads();
+    if constexpr (INSTR) t2 = (long long)wall_clock64();
     // ---- softmax: the operations of k_p_soft_max, row by row; the row is then overwritten with its f16 probabilities
     const int npad = ((T_hi + 15) >> 4) << 4;  // V.P reads whole 16-key chunks: zeros behind the last visible key
-    for (int rr = 0; rr < 8; rr++) {
-        const int row = wave * 8 + rr;
-        if (q0 + row >= a.N) break;  // ragged last tile (wave-uniform)
-        float *p = (float *)(lds + row * rb);
-        const int lim = a.n_past + q0 + row;  // keys > lim are masked
-        float mx = -INFINITY;
-        for (int i = lane; i <= lim; i += 64) mx = fmaxf(mx, p[i] * a.scale);
-        mx = wave_max_f32(mx);
-        double sum = 0.0;
-        for (int i = lane; i <= lim; i += 64) {
-            const float e = round_f16(expf(round_f16(p[i] * a.scale - mx)));
-            sum += (double)e;
-            p[i] = e;
+    {
+        // The wave's 8 rows side by side: each row's three passes are chains of LDS read -> exp -> LDS write that ran at one
+        // latency per step when the rows went one after the other (20 of the kernel's 35 us); per element and per row the
+        // operations and their order are unchanged.
+        constexpr int RW = 8;
+        const int row0 = wave * RW;
+        const int nrow = min(RW, a.N - q0 - row0);  // rows of this wave that exist (ragged last tile), wave-uniform, may be <= 0
+        const int lim0 = a.n_past + q0 + row0;      // row rr sees keys 0 .. lim0 + rr
+        const int lim_hi = lim0 + nrow - 1;
+        float mx[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) mx[rr] = -INFINITY;
+        for (int i = lane; i <= lim_hi; i += 64) {
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++)
+                if (rr < nrow && i <= lim0 + rr) mx[rr] = fmaxf(mx[rr], ((const float *)(lds + (row0 + rr) * rb))[i] * a.scale);
         }
-        sum = wave_sum_f64(sum);
-        const float inv = (float)(1.0 / sum);
-        _Float16 *p16 = (_Float16 *)p;
-        for (int i0 = 0; i0 < npad; i0 += 64) {  // f16 element i lands on f32 element i / 2, which this wave read in an earlier
-            const int i = i0 + lane;             // (or this) iteration: LDS operations of a wave execute in order
-            const float e = i <= lim ? p[i] : 0.0f;
-            if (i < npad) p16[i] = (_Float16)(e * inv);
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) mx[rr] = wave_max_f32(mx[rr]);
+        double sum[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) sum[rr] = 0.0;
+        for (int i = lane; i <= lim_hi; i += 64) {
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++)
+                if (rr < nrow && i <= lim0 + rr) {
+                    float *p = (float *)(lds + (row0 + rr) * rb);
+                    const float e = round_f16(expf(round_f16(p[i] * a.scale - mx[rr])));
+                    sum[rr] += (double)e;
+                    p[i] = e;
+                }
+        }
+        float inv[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) {
+            sum[rr] = wave_sum_f64(sum[rr]);
+            inv[rr] = (float)(1.0 / sum[rr]);
+        }
+        // each row overwritten in place with its f16 probabilities: f16 element i lands on f32 element i / 2, which this wave
+        // read in an earlier (or this) iteration — LDS operations of a wave execute in order
+        for (int i0 = 0; i0 < npad; i0 += 64) {
+            const int i = i0 + lane;
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++)
+                if (rr < nrow) {
+                    float *p = (float *)(lds + (row0 + rr) * rb);
+                    const float e = i <= lim0 + rr ? p[i] : 0.0f;
+                    if (i < npad) ((_Float16 *)p)[i] = (_Float16)(e * inv[rr]);
+                }
         }
     }
     __syncthreads();
+    if constexpr (INSTR) t3 = (long long)wall_clock64();
     // ---- V.P
     if (wave < NWV) {
         const int nch = npad >> 4;
@@ -136,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-        constexpr int PF = 4;  // chunks in flight
+        constexpr int PF = 8;  // chunks in flight
         f16x8 vb[PF];
 #pragma unroll
         for (int k = 0; k < PF; k++)
@@ -157,6 +194,13 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2);
             if (q0 + 4 * fh + row < a.N) op[(int64_t)row * a.E] = acc[r];
+        }
+    }
+    if constexpr (INSTR) {
+        t4 = (long long)wall_clock64();
+        if (a.ts && tid == 0) {
+            long long *o = a.ts + (size_t)blockIdx.x * 8;
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = T_hi; o[6] = qt; o[7] = h;
         }
     }
 }
