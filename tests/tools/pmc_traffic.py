@@ -8,8 +8,8 @@ import os
 import sqlite3
 import sys
 
-KINDS = {"qkv": "%k_mmvq_big<0, 3, 1>%", "wo": "%k_mmvq_big<0, 1, 0>%", "gate_up": "%k_mmvq_big<0, 2, 1>%",
-         "down": "%k_mmvq_big<0, 1, 2>%", "lm_head": "%k_mmvq_big<0, 0, 1>%"}
+KINDS = {"qkv": "%k_mmvq_big<0, 3, 1%", "wo": "%k_mmvq_big<0, 1, 0%", "gate_up": "%k_mmvq_big<0, 2, 1%",
+         "down": "%k_mmvq_big<0, 1, 2%", "lm_head": "%k_mmvq_big<0, 0, 1%"}
 
 
 def avg(d, like, counter):
