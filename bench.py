@@ -315,6 +315,20 @@ def run_single(args):
     sess.infer_tokens_device(args.steps)
     L.ggml_hip_synchronize()
     dev_s = time.perf_counter() - td
+    # ... and with 8 tokens per hipGraph launch (option chain_k): what the graph-launch gap between tokens costs
+    dev8_s = None
+    if hasattr(ggml, "set_option"):
+        ggml.set_option("chain_k", 8)
+        try:
+            sess.infer_next_token()
+            sess.infer_tokens_device(8)  # captures the 8-token graph
+            L.ggml_hip_synchronize()
+            td = time.perf_counter()
+            sess.infer_tokens_device(args.steps)
+            L.ggml_hip_synchronize()
+            dev8_s = time.perf_counter() - td
+        finally:
+            ggml.set_option("chain_k", 0)
     # the same decode deep into the context (n_past ~1800 of 2048): attention split over positions (decode_attn_split.h)
     long_ctx = None
     if args.model != "tiny":
@@ -410,7 +424,9 @@ def run_single(args):
                       "long_context": long_ctx,
                       "device_sampling": {"tokens_per_s": round(args.steps / dev_s, 2), "ms_per_token": round(dev_s / args.steps * 1e3, 4),
                                           "note": "same greedy tokens via llm_infer_tokens_greedy_device (argmax kernel feeds the next "
-                                                  "replay; logits stay in HBM until the last token)"},
+                                                  "replay; logits stay in HBM until the last token)",
+                                          "eight_tokens_per_graph_launch": None if not dev8_s else
+                                          {"tokens_per_s": round(args.steps / dev8_s, 2), "ms_per_token": round(dev8_s / args.steps * 1e3, 4)}},
                       "prefill": prefill,
                       "weights": ("BASELINE.md section 4: N(0, 0.02^2) rows quantized by ggml_quantize_q* (gaussians from the "
                                   "library's counter-based generator)") if args.weights == "gaussian" else "random valid GGML blocks",

@@ -311,6 +311,34 @@ def test_device_sampled_chain_equals_token_by_token_greedy(G, O, wtype):
     model.free()
 
 
+@pytest.mark.parametrize("wtype", [2, 8])
+def test_chain_of_several_tokens_per_graph_launch_equals_the_plain_chain(G, O, wtype):
+    """Option chain_k = K: k_argmax_next + one token, K times over, captured as ONE hipGraph (the kernels read token and
+    position from the DecParams the argmax advances on the device).  Same ids, final logits and K/V as token-by-token
+    decode, for chain lengths that are and are not multiples of K."""
+    hp, w, model = _mk(G, wtype, seed=9)
+    prompt = np.random.default_rng(6).integers(0, hp["n_vocab"], 9).astype(np.int32)
+    a = model.start_session(n_batch=8)
+    a.feed_prompt(prompt)
+    ref = [a.infer_next_token() for _ in range(27)]
+    G.set_option("chain_k", 4)
+    try:
+        b = model.start_session(n_batch=8)
+        b.feed_prompt(prompt)
+        got = list(b.infer_tokens_device(14))   # 1 normal step, then 3 graphs of 4 and a single token
+        got += list(b.infer_tokens_device(13))  # the same graph again at another offset
+    finally:
+        G.set_option("chain_k", 0)
+    assert got == ref
+    assert np.array_equal(b.last_logits(), a.last_logits())
+    ka, va = a.get_kv()
+    kb, vb = b.get_kv()
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    a.free()
+    b.free()
+    model.free()
+
+
 def test_device_argmax_takes_the_first_maximum(G, O):
     """k_argmax_next = the host loop `if (l[i] > l[best]) best = i`: ties go to the lowest index.  Checked through the
     chain on a model whose lm_head has duplicated rows (equal logits by construction)."""
