@@ -17,6 +17,7 @@
 //   V.P    : wave w takes value channels 32w .. 32w+31 (D / 32 waves), V^T fragments from global, P fragments from LDS.
 #pragma once
 #include "gemm_f16.h"
+#include "mmq.h"
 
 struct PAttnArgs {
     const float *q;      // [N][E] f32, RoPE applied
@@ -27,6 +28,9 @@ struct PAttnArgs {
     int64_t C;
     float scale;
     int row_bytes;       // LDS bytes per score row
+    _Float16 *x16;       // != nullptr: the output goes out as wo's GEMM operand instead — every 32-channel block re-quantized to Q8
+                         // and written as f16(d * q) in the GEMM's k order (what k_p_quant4 makes of `out`); `out` is not written
+    int f16d;            // ... with the block scale rounded to f16 first (weight types whose vec_dot_type is Q8_0)
     long long *ts;       // INSTR build (option "timeline"): 8 x int64 per workgroup, see tests/tools/pattn_timeline.py
 };
 
@@ -189,11 +193,31 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
                 }
             }
         }
-        float *op = a.out + (int64_t)(q0 + 4 * fh) * a.E + h * D + d0 + fr;
+        if (a.x16) {
+            // the wave's 32 channels are one Q8 block of the merged row: amax over the 32 lanes of a half, k_p_quant4's formula
+            _Float16 *xp = a.x16 + (int64_t)(q0 + 4 * fh) * a.E + h * D + d0 + mmq_kperm_inv(fr);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2);
-            if (q0 + 4 * fh + row < a.N) op[(int64_t)row * a.E] = acc[r];
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                const float v = acc[r];
+                float amax = fabsf(v);
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+                const float d = amax / 127.0f;
+                const float id = d != 0.0f ? 1.0f / d : 0.0f;
+                const float dq = a.f16d ? round_f16(d) : d;
+                const int qv = (int)roundf(v * id);
+                float rq = dq * (float)qv;
+                rq = fminf(fmaxf(rq, -65504.0f), 65504.0f);
+                if (q0 + 4 * fh + row < a.N) xp[(int64_t)row * a.E] = (_Float16)rq;
+            }
+        } else {
+            float *op = a.out + (int64_t)(q0 + 4 * fh) * a.E + h * D + d0 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                if (q0 + 4 * fh + row < a.N) op[(int64_t)row * a.E] = acc[r];
+            }
         }
     }
     if constexpr (INSTR) {

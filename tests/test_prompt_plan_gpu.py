@@ -293,3 +293,36 @@ def test_fused_prompt_attention_kernel_matches_the_three_launch_path(G):
                 pr = (e / e.sum()).astype(np.float16).astype(np.float64)
                 ref = vf[hk * D:(hk + 1) * D, :n_past + n + 1] @ pr
                 assert np.allclose(outs[0][n, h * D:(h + 1) * D], ref, rtol=0, atol=4e-3 * max(1.0, float(np.abs(ref).max()))), (N, D, n_past, h, n)
+
+
+@pytest.mark.parametrize("wtype", [2, 3, 8])
+@pytest.mark.parametrize("cfg", ["tiny", "gqa", "wide"])
+def test_fused_prompt_attention_with_its_quantizing_epilogue_in_the_plan(G, wtype, cfg):
+    """In the prompt plan the fused attention kernel writes wo's GEMM operand itself (every 32-channel block of the merged
+    row re-quantized to Q8 and stored as f16(d * q): k_p_quant4's arithmetic in the V.P epilogue; both block-scale kinds:
+    f16-rounded for Q4_0 / Q8_0, f32 for Q4_1).  Against the plan with the three-launch attention + k_p_quant4: identical
+    except where the attention outputs differ by their one-f16-rounding noise, which moves an int8 code now and then:
+    every chunk within 4e-2 * std (the EDGE bound of the other tests), and chunks without such a flip agree to 1e-4 or
+    exactly (seen: 0.0 beside 2e-2 in the same session)."""
+    from llm_amd import llama, synth
+    hp0 = {"tiny": synth.TINY, "gqa": GQA, "wide": WIDE}[cfg]
+    hp, w = synth.make_llama(hp0, wtype, seed=13)
+    model = llama.Llama(hp, w, context_size=512)
+    toks = np.random.default_rng([wtype, 3]).integers(0, hp["n_vocab"], 330).astype(np.int32)
+    chunks = [toks[0:64], toks[64:97], toks[97:225], toks[225:330]]
+    outs = {}
+    for fused in (1, 0):
+        G.set_option("attn_fused", fused)
+        sess = model.start_session(n_batch=192)
+        p0 = _stat(G, "prompt_plan_tokens")
+        outs[fused] = [sess.evaluate(c) for c in chunks]
+        assert _stat(G, "prompt_plan_tokens") - p0 == sum(len(c) for c in chunks)
+        sess.free()
+    G.set_option("attn_fused", 1)
+    ds = []
+    for a, b in zip(outs[1], outs[0]):
+        assert np.isfinite(a).all()
+        ds.append(float(np.max(np.abs(a - b))) / float(b.std()))
+    print(cfg, wtype, ["%.1e" % d for d in ds])
+    assert max(ds) <= 4e-2 and min(ds) <= 1e-4, ds
+    model.free()
