@@ -185,17 +185,19 @@ struct PQkvPost {
     int64_t C;
     int nb_rope, vt_n, vt_m;  // rope blocks (two pairs per thread); V tiles along tokens / channels
     int64_t part;             // != 0: q / kf / vf are the first partials of a K-split GEMM, the second ones lie `part` floats on
+    int skip_q;               // != 0: Q is left as the GEMM wrote it — the fused attention kernel applies RoPE while loading it
 };
 __global__ void __launch_bounds__(256) k_p_qkv_post(const PQkvPost a) {
     __shared__ float s_t[64][65];
     const int b = blockIdx.x;
     if (b < a.nb_rope) {
-        const int per_tok = (a.E + a.Egqa) >> 2;  // 4-vectors (two pairs) per token: Q then K; D/2 is even, so are E/2, Egqa/2
+        const int q4 = a.skip_q ? 0 : (a.E >> 2);
+        const int per_tok = q4 + (a.Egqa >> 2);  // 4-vectors (two pairs) per token: Q then K; D/2 is even, so are E/2, Egqa/2
         const int64_t idx = (int64_t)b * 256 + threadIdx.x;
         if (idx >= (int64_t)a.N * per_tok) return;
         const int n = (int)(idx / per_tok), pr = (int)(idx - (int64_t)n * per_tok);
-        const bool is_k = pr >= (a.E >> 2);
-        const int pi = 2 * (is_k ? pr - (a.E >> 2) : pr);  // first of the two pairs, index inside the row
+        const bool is_k = pr >= q4;
+        const int pi = 2 * (is_k ? pr - q4 : pr);  // first of the two pairs, index inside the row
         const int kk = pi % (a.D >> 1);
         const f32x4 cs = *(const f32x4 *)(a.tab + (int64_t)n * 128 + 2 * kk);  // cos, sin of pairs kk, kk + 1
         if (!is_k) {

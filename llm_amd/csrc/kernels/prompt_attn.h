@@ -28,6 +28,9 @@ struct PAttnArgs {
     int64_t C;
     float scale;
     int row_bytes;       // LDS bytes per score row
+    const float *rope;   // != nullptr: q is the raw wq product; RoPE (cos, sin per pair: 128 floats per token, k_rope_table) is
+                         // applied while its fragments are loaded — k_p_qkv_post's operations on the same values
+    int64_t q_part;      // != 0: ... and q is the first partial of a K-split GEMM, the second lies q_part floats on
     _Float16 *x16;       // != nullptr: the output goes out as wo's GEMM operand instead — every 32-channel block re-quantized to Q8
                          // and written as f16(d * q) in the GEMM's k order (what k_p_quant4 makes of `out`); `out` is not written
     int f16d;            // ... with the block scale rounded to f16 first (weight types whose vec_dot_type is Q8_0)
@@ -62,7 +65,28 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         const float *qp = a.q + (int64_t)qn * a.E + h * D + fh * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const f32x4_u x0 = *(const f32x4_u *)(qp + ks * 16), x1 = *(const f32x4_u *)(qp + ks * 16 + 4);
+            f32x4_u x0 = *(const f32x4_u *)(qp + ks * 16), x1 = *(const f32x4_u *)(qp + ks * 16 + 4);
+            if (a.rope) {  // uniform
+                if (a.q_part) {
+                    const f32x4_u y0 = *(const f32x4_u *)(qp + a.q_part + ks * 16), y1 = *(const f32x4_u *)(qp + a.q_part + ks * 16 + 4);
+                    x0 = x0 + y0;
+                    x1 = x1 + y1;
+                }
+                // dims fh*8 + ks*16 + 0..7 of the head = pairs fh*4 + ks*8 + 0..3: the table offset equals the dim offset
+                const float *tp = a.rope + (int64_t)qn * 128 + fh * 8 + ks * 16;
+                const f32x4_u c0 = *(const f32x4_u *)tp, c1 = *(const f32x4_u *)(tp + 4);
+                f32x4_u o0, o1;
+                o0[0] = x0[0] * c0[0] - x0[1] * c0[1];
+                o0[1] = x0[0] * c0[1] + x0[1] * c0[0];
+                o0[2] = x0[2] * c0[2] - x0[3] * c0[3];
+                o0[3] = x0[2] * c0[3] + x0[3] * c0[2];
+                o1[0] = x1[0] * c1[0] - x1[1] * c1[1];
+                o1[1] = x1[0] * c1[1] + x1[1] * c1[0];
+                o1[2] = x1[2] * c1[2] - x1[3] * c1[3];
+                o1[3] = x1[2] * c1[3] + x1[3] * c1[2];
+                x0 = o0;
+                x1 = o1;
+            }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 qa[ks][e] = (_Float16)x0[e];
