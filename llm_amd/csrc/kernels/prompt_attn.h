@@ -28,6 +28,8 @@ struct PAttnArgs {
     int64_t C;
     float scale;
     int row_bytes;       // LDS bytes per score row
+    const uint16_t *exp_tab;  // != nullptr: ggml's table_exp_f16 (65536 halves: f16(expf(f32(h))) for every f16 bit pattern h,
+                         // filled by the host's expf): the softmax looks its exponentials up exactly as ggml does
     const float *rope;   // != nullptr: q is the raw wq product; RoPE (cos, sin per pair: 128 floats per token, k_rope_table) is
                          // applied while its fragments are loaded — k_p_qkv_post's operations on the same values
     int64_t q_part;      // != 0: ... and q is the first partial of a K-split GEMM, the second lies q_part floats on
@@ -159,7 +161,12 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
             for (int rr = 0; rr < RW; rr++)
                 if (rr < nrow && i <= lim0 + rr) {
                     float *p = (float *)(lds + (row0 + rr) * rb);
-                    const float e = round_f16(expf(round_f16(p[i] * a.scale - mx[rr])));
+                    const float t = p[i] * a.scale - mx[rr];
+                    float e;
+                    if (a.exp_tab)  // uniform: a 2-byte gather from a 128 KB table that lives in L1 / L2 instead of ~20 VALU operations
+                        e = __half2float(__ushort_as_half(a.exp_tab[__half_as_ushort(__float2half_rn(t))]));
+                    else
+                        e = round_f16(expf(round_f16(t)));
                     sum[rr] += (double)e;
                     p[i] = e;
                 }
