@@ -10,7 +10,8 @@
 // operand roles and k order of k_gemm_f16 (A = queries, B = keys / value channels, 16 k per instruction, ascending), so
 // the result is bit-identical to the three-launch path (tests/test_prompt_plan_gpu.py).
 //
-//   grid = (ceil(N / 32) * H), 256 threads.  Dynamic LDS = 32 x (Tp * 4 + 16) bytes, Tp = (n_past + N) rounded up to 64.
+//   grid = (ceil(N / 32) * H), 256 threads.  Dynamic LDS = 32 x (Tp * 4 + 16) bytes, Tp = (n_past + N) rounded up to 64,
+//   (the staged Q tile, 32 x (2 D + 16) bytes, borrows the score rows before the S phase).
 //   S phase: wave w takes key tiles w, w+4, ... of 32 keys (8 MFMAs for D = 128), K fragments straight from global / L2,
 //            the next tile's fragments requested before the current tile's MFMAs.
 //   softmax: wave w takes rows 8w .. 8w+7.
@@ -60,42 +61,52 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     const int nkt = (T_hi + 31) >> 5;
     const int rb = a.row_bytes;
 
-    // ---- Q fragments (A operand): row fr of the tile, 8 channels per k step and lane half
-    f16x8 qa[KS];
-    {
-        const int qn = min(q0 + fr, a.N - 1);
-        const float *qp = a.q + (int64_t)qn * a.E + h * D + fh * 8;
+    // ---- Q tile -> LDS once per workgroup (f16, rotated if a.rope), then every wave's A fragments from there.  All four
+    // waves need the whole tile: fetched per wave it is 64 KB of f32 (128 KB with the RoPE table) through an L1 that delivers
+    // ~17 B per clock — the in-kernel timeline showed 10.8 us of Q load for every workgroup of the prompt plan.
+    constexpr int QROW = D * 2 + 16;  // bytes per staged row (+16: fragment reads of consecutive rows spread over the banks)
+    char *s_q = lds;  // the score rows are not in use yet (32 x QROW <= 32 x row_bytes for every T the launcher accepts)
+    for (int idx = tid; idx < PATTN_Q * (D / 16); idx += 256) {
+        const int row = idx / (D / 16), c = idx % (D / 16);
+        const int qn = min(q0 + row, a.N - 1);
+        const float *qp = a.q + (int64_t)qn * a.E + h * D + c * 16;
+        f32x4_u x[4];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            f32x4_u x0 = *(const f32x4_u *)(qp + ks * 16), x1 = *(const f32x4_u *)(qp + ks * 16 + 4);
-            if (a.rope) {  // uniform
-                if (a.q_part) {
-                    const f32x4_u y0 = *(const f32x4_u *)(qp + a.q_part + ks * 16), y1 = *(const f32x4_u *)(qp + a.q_part + ks * 16 + 4);
-                    x0 = x0 + y0;
-                    x1 = x1 + y1;
-                }
-                // dims fh*8 + ks*16 + 0..7 of the head = pairs fh*4 + ks*8 + 0..3: the table offset equals the dim offset
-                const float *tp = a.rope + (int64_t)qn * 128 + fh * 8 + ks * 16;
-                const f32x4_u c0 = *(const f32x4_u *)tp, c1 = *(const f32x4_u *)(tp + 4);
-                f32x4_u o0, o1;
-                o0[0] = x0[0] * c0[0] - x0[1] * c0[1];
-                o0[1] = x0[0] * c0[1] + x0[1] * c0[0];
-                o0[2] = x0[2] * c0[2] - x0[3] * c0[3];
-                o0[3] = x0[2] * c0[3] + x0[3] * c0[2];
-                o1[0] = x1[0] * c1[0] - x1[1] * c1[1];
-                o1[1] = x1[0] * c1[1] + x1[1] * c1[0];
-                o1[2] = x1[2] * c1[2] - x1[3] * c1[3];
-                o1[3] = x1[2] * c1[3] + x1[3] * c1[2];
-                x0 = o0;
-                x1 = o1;
+        for (int k = 0; k < 4; k++) x[k] = *(const f32x4_u *)(qp + 4 * k);
+        if (a.rope) {  // uniform
+            if (a.q_part) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) x[k] = x[k] + *(const f32x4_u *)(qp + a.q_part + 4 * k);
             }
+            // dims c*16 + 0..15 of the head = pairs c*8 + 0..7: the table offset (2 floats per pair) equals the dim offset
+            const float *tp = a.rope + (int64_t)qn * 128 + c * 16;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                qa[ks][e] = (_Float16)x0[e];
-                qa[ks][4 + e] = (_Float16)x1[e];
+            for (int k = 0; k < 4; k++) {
+                const f32x4_u cs = *(const f32x4_u *)(tp + 4 * k);
+                f32x4_u o;
+                o[0] = x[k][0] * cs[0] - x[k][1] * cs[1];
+                o[1] = x[k][0] * cs[1] + x[k][1] * cs[0];
+                o[2] = x[k][2] * cs[2] - x[k][3] * cs[3];
+                o[3] = x[k][2] * cs[3] + x[k][3] * cs[2];
+                x[k] = o;
             }
         }
+        f16x8 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            h0[e] = (_Float16)x[0][e];
+            h0[4 + e] = (_Float16)x[1][e];
+            h1[e] = (_Float16)x[2][e];
+            h1[4 + e] = (_Float16)x[3][e];
+        }
+        *(f16x8 *)(s_q + row * QROW + c * 32) = h0;
+        *(f16x8 *)(s_q + row * QROW + c * 32 + 16) = h1;
     }
+    __syncthreads();
+    f16x8 qa[KS];  // A operand: row fr of the tile, 8 channels per k step and lane half
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) qa[ks] = *(const f16x8 *)(s_q + fr * QROW + (fh * 8 + ks * 16) * 2);
+    __syncthreads();  // the fragments are in registers: the S phase may overwrite the staging area
     if constexpr (INSTR) t1 = (long long)wall_clock64();
     // ---- S phase
     auto load_k = [&](int kt, f16x8 (&kb)[KS]) {
@@ -231,9 +242,17 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
             for (int r = 0; r < 16; r++) {
                 const int row = (r & 3) + 8 * (r >> 2);
                 const float v = acc[r];
-                float amax = fabsf(v);
-#pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+                // max over the 32 lanes of this half: DPP inside each row of 16, then the two rows' results through scalar
+                // registers (a __shfl_xor is an LDS round trip: five of them per row made this epilogue cost 15 us per launch)
+                float amax = g16_max_f32(fabsf(v));
+                {
+                    const int ai = __builtin_bit_cast(int, amax);
+                    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ai, 0));
+                    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ai, 16));
+                    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ai, 32));
+                    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ai, 48));
+                    amax = fh ? fmaxf(r2, r3) : fmaxf(r0, r1);
+                }
                 const float d = amax / 127.0f;
                 const float id = d != 0.0f ? 1.0f / d : 0.0f;
                 const float dq = a.f16d ? round_f16(d) : d;

@@ -11,7 +11,40 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from llm_amd import ggml  # noqa: E402
 
 
+def report(t, ntile, N, n_past, H):
+    e0 = t[:, 0].min()
+    print(f"N {N} n_past {n_past}: {ntile * H} workgroups; launch span {(t[:, 4].max() - e0) / 100:.2f} us")
+    print("tile  T_hi | entry   qload  scores softmax     vp | dur   (means over heads, us; entry relative to the first workgroup)")
+    for qt in range(ntile):
+        r = t[t[:, 6] == qt]
+        rel = lambda j: float(((r[:, j] - r[:, 0]) / 100).mean())
+        print(f"{qt:4d} {int(r[0, 5]):5d} | {float(((r[:, 0] - e0) / 100).mean()):6.2f} {rel(1):6.2f} {rel(2):6.2f} {rel(3):6.2f} {rel(4):6.2f} | "
+              f"{rel(4):6.2f}")
+
+
+def plan_mode(N):
+    """the kernel as the prompt plan launches it (Q rotated on load, wo's operand written by the epilogue): LLaMA-7B Q4_0"""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama_fast(synth.LLAMA_7B, ggml.TYPE_Q4_0)
+    model = llama.Llama(hp, w, context_size=2048)
+    s = model.start_session(n_batch=N)
+    toks = (np.arange(N + 1, dtype=np.int32) * 7 + 5) % hp["n_vocab"]
+    s.feed_prompt(toks[:1])
+    for _ in range(2):
+        s.feed_prompt(toks[1:])
+        assert s.rewind(N) == 0
+    H, ntile = hp["n_head"], (N + 31) // 32
+    ggml.set_option("timeline", ntile * H)
+    s.feed_prompt(toks[1:])
+    ggml.lib().ggml_hip_synchronize()
+    t = ggml.read_timeline(ntile * H).astype(np.float64)
+    ggml.set_option("timeline", 0)
+    report(t, ntile, N, 1, H)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "plan":
+        return plan_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 512)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     n_past = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     H, D, C = 32, 128, 2048
@@ -30,14 +63,7 @@ def main():
         assert rc == 0
     t = ggml.read_timeline(ntile * H).astype(np.float64)
     ggml.set_option("timeline", 0)
-    e0 = t[:, 0].min()
-    print(f"N {N} n_past {n_past}: {ntile * H} workgroups; launch span {(t[:, 4].max() - e0) / 100:.2f} us")
-    print("tile  T_hi | entry   qload  scores softmax     vp | dur   (means over heads, us; entry relative to the first workgroup)")
-    for qt in range(ntile):
-        r = t[t[:, 6] == qt]
-        rel = lambda j: float(((r[:, j] - r[:, 0]) / 100).mean())
-        print(f"{qt:4d} {int(r[0, 5]):5d} | {float(((r[:, 0] - e0) / 100).mean()):6.2f} {rel(1):6.2f} {rel(2):6.2f} {rel(3):6.2f} {rel(4):6.2f} | "
-              f"{rel(4):6.2f}")
+    report(t, ntile, N, n_past, H)
 
 
 if __name__ == "__main__":
