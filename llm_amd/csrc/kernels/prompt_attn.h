@@ -29,8 +29,6 @@ struct PAttnArgs {
     int64_t C;
     float scale;
     int row_bytes;       // LDS bytes per score row
-    const uint16_t *exp_tab;  // != nullptr: ggml's table_exp_f16 (65536 halves: f16(expf(f32(h))) for every f16 bit pattern h,
-                         // filled by the host's expf): the softmax looks its exponentials up exactly as ggml does
     const float *rope;   // != nullptr: q is the raw wq product; RoPE (cos, sin per pair: 128 floats per token, k_rope_table) is
                          // applied while its fragments are loaded — k_p_qkv_post's operations on the same values
     int64_t q_part;      // != 0: ... and q is the first partial of a K-split GEMM, the second lies q_part floats on
@@ -154,13 +152,24 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         const int nrow = min(RW, a.N - q0 - row0);  // rows of this wave that exist (ragged last tile), wave-uniform, may be <= 0
         const int lim0 = a.n_past + q0 + row0;      // row rr sees keys 0 .. lim0 + rr
         const int lim_hi = lim0 + nrow - 1;
+        // rows that do not exist (ragged last tile) alias the wave's first row for their reads and never write
+        const char *rp[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) rp[rr] = lds + (row0 + (rr < nrow ? rr : 0)) * rb;
+        // every pass reads its eight rows UNCONDITIONALLY (index i < Tp is inside every row) and predicates the update: with
+        // the loads under per-row branches the compiler waited for each LDS read before issuing the next row's
         float mx[RW];
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) mx[rr] = -INFINITY;
         for (int i = lane; i <= lim_hi; i += 64) {
+            float x[RW];
 #pragma unroll
-            for (int rr = 0; rr < RW; rr++)
-                if (rr < nrow && i <= lim0 + rr) mx[rr] = fmaxf(mx[rr], ((const float *)(lds + (row0 + rr) * rb))[i] * a.scale);
+            for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[i];
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++) {
+                const float v = x[rr] * a.scale;
+                mx[rr] = (rr < nrow && i <= lim0 + rr) ? fmaxf(mx[rr], v) : mx[rr];
+            }
         }
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) mx[rr] = wave_max_f32(mx[rr]);
@@ -168,18 +177,16 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) sum[rr] = 0.0;
         for (int i = lane; i <= lim_hi; i += 64) {
+            float x[RW], e[RW];
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[i];
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++) e[rr] = round_f16(expf(round_f16(x[rr] * a.scale - mx[rr])));
 #pragma unroll
             for (int rr = 0; rr < RW; rr++)
                 if (rr < nrow && i <= lim0 + rr) {
-                    float *p = (float *)(lds + (row0 + rr) * rb);
-                    const float t = p[i] * a.scale - mx[rr];
-                    float e;
-                    if (a.exp_tab)  // uniform: a 2-byte gather from a 128 KB table that lives in L1 / L2 instead of ~20 VALU operations
-                        e = __half2float(__ushort_as_half(a.exp_tab[__half_as_ushort(__float2half_rn(t))]));
-                    else
-                        e = round_f16(expf(round_f16(t)));
-                    sum[rr] += (double)e;
-                    p[i] = e;
+                    sum[rr] += (double)e[rr];
+                    ((float *)(lds + (row0 + rr) * rb))[i] = e[rr];
                 }
         }
         float inv[RW];
@@ -192,12 +199,14 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         // read in an earlier (or this) iteration — LDS operations of a wave execute in order
         for (int i0 = 0; i0 < npad; i0 += 64) {
             const int i = i0 + lane;
+            float x[RW];
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[min(i, npad - 1)];
 #pragma unroll
             for (int rr = 0; rr < RW; rr++)
-                if (rr < nrow) {
-                    float *p = (float *)(lds + (row0 + rr) * rb);
-                    const float e = i <= lim0 + rr ? p[i] : 0.0f;
-                    if (i < npad) ((_Float16 *)p)[i] = (_Float16)(e * inv[rr]);
+                if (rr < nrow && i < npad) {
+                    const float e = i <= lim0 + rr ? x[rr] : 0.0f;
+                    ((_Float16 *)(lds + (row0 + rr) * rb))[i] = (_Float16)(e * inv[rr]);
                 }
         }
     }
