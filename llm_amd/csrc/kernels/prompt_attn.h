@@ -59,6 +59,19 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     const int nkt = (T_hi + 31) >> 5;
     const int rb = a.row_bytes;
 
+    auto load_k = [&](int kt, f16x8 (&kb)[KS]) {
+        const int64_t t = min((int64_t)kt * 32 + fr, a.C - 1);
+        const __half *kp = a.mem_k + t * a.Egqa + hk * D + fh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) kb[ks] = *(const f16x8 *)(kp + ks * 16);
+    };
+    // the wave's first K tiles are requested before anything else: they depend on nothing, and the Q staging below is two
+    // barriers and a cold round trip long
+    constexpr int KR = 3;
+    f16x8 kb[KR][KS];
+#pragma unroll
+    for (int j = 0; j < KR - 1; j++)
+        if (wave + 4 * j < nkt) load_k(wave + 4 * j, kb[j]);
     // ---- Q tile -> LDS once per workgroup (f16, rotated if a.rope), then every wave's A fragments from there.  All four
     // waves need the whole tile: fetched per wave it is 64 KB of f32 (128 KB with the RoPE table) through an L1 that delivers
     // ~17 B per clock — the in-kernel timeline showed 10.8 us of Q load for every workgroup of the prompt plan.
@@ -107,20 +120,9 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     __syncthreads();  // the fragments are in registers: the S phase may overwrite the staging area
     if constexpr (INSTR) t1 = (long long)wall_clock64();
     // ---- S phase
-    auto load_k = [&](int kt, f16x8 (&kb)[KS]) {
-        const int64_t t = min((int64_t)kt * 32 + fr, a.C - 1);
-        const __half *kp = a.mem_k + t * a.Egqa + hk * D + fh * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) kb[ks] = *(const f16x8 *)(kp + ks * 16);
-    };
     {
         // K fragments of up to three of the wave's key tiles in flight (96 VGPRs for D = 128; 2 waves per SIMD leave 256):
         // with one tile ahead the phase ran at one L2 / HBM round trip per tile (in-kernel timeline, 2.1 us per tile)
-        constexpr int KR = 3;
-        f16x8 kb[KR][KS];
-#pragma unroll
-        for (int j = 0; j < KR - 1; j++)
-            if (wave + 4 * j < nkt) load_k(wave + 4 * j, kb[j]);
         for (int kt0 = wave; kt0 < nkt; kt0 += 4 * KR) {
 #pragma unroll
             for (int j = 0; j < KR; j++) {
