@@ -506,7 +506,8 @@ GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total
  * sendrecv = both in one RCCL group (needed when the peer is this rank itself).  librccl.so is opened on first use. */
 #define GGML_HIP_COMM_ID_BYTES 128
 GGML_API int ggml_hip_comm_unique_id(void *id_out /* GGML_HIP_COMM_ID_BYTES */);
-GGML_API int ggml_hip_comm_init(int rank, int world, const void *id); /* returns the rank count RCCL reports */
+GGML_API int ggml_hip_comm_init(int rank, int world, const void *id); /* returns the rank count RCCL reports; -1 (with a
+                                                                          message) if the communicator cannot be formed */
 GGML_API void ggml_hip_comm_destroy(void);
 GGML_API int ggml_hip_comm_ranks(void); /* 0 = no communicator */
 GGML_API void ggml_hip_comm_send(const void *dev_src, size_t nbytes, int peer);

@@ -242,7 +242,7 @@ def run_bench(args):
     hp, w = make(hp0, wtype, only=names)
     ctx = 2048 if args.model != "tiny" else 256
     stage = GpuStage(hp, w, (lb, le), ctx, n_batch=8)
-    comm_ranks = 0
+    comm_ranks, rccl_failed = 0, False
     if use_rccl:
         import ctypes
         idb = torch.zeros(ggml.COMM_ID_BYTES, dtype=torch.uint8)
@@ -253,10 +253,18 @@ def run_bench(args):
         dist.broadcast(idb, src=0)
         raw = (ctypes.c_ubyte * ggml.COMM_ID_BYTES)(*idb.tolist())
         comm_ranks = ggml.lib().ggml_hip_comm_init(rank, world, raw)
-        assert comm_ranks == world, (comm_ranks, world)
-        stage.comm_ready = True
+        # every rank must agree on the transport: one failed communicator sends all of them to host copies over gloo
+        ok = torch.tensor([1 if comm_ranks == world else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            stage.comm_ready = True
+        else:
+            if comm_ranks > 0:
+                ggml.lib().ggml_hip_comm_destroy()
+            comm_ranks, use_rccl, rccl_failed = 0, False, True
     backend = f"rccl inside libggml_hip.so ({comm_ranks} ranks) for the residual; gloo for token ids and the barrier" \
-        if use_rccl else "gloo (host copies: fewer GPUs than ranks on this node)"
+        if use_rccl else ("gloo (host copies: the RCCL communicator could not be formed)" if rccl_failed else
+                          "gloo (host copies: fewer GPUs than ranks on this node)")
     n_seq = world
     for s in range(n_seq):
         stage.new_sequence(s)
@@ -295,7 +303,9 @@ def run_bench(args):
                "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} greedy decode, layer split over "
                                       f"{world} GPUs ({le - lb} layers/GPU), {n_seq} sequences in flight (one per stage), "
                                       f"{args.prompt}-token prompts, ctx {ctx}, f16 KV",
-                          "parallelism": f"pp{world} layer split, residual hop: " + ("RCCL send/recv inside the library" if use_rccl else "host copies over gloo (fewer GPUs than ranks)"),
+                          "parallelism": f"pp{world} layer split, residual hop: " + ("RCCL send/recv inside the library" if use_rccl else
+                                                                                      "host copies over gloo (RCCL init failed)" if rccl_failed else
+                                                                                      "host copies over gloo (fewer GPUs than ranks)"),
                           "layer_ranges_by_rank": ranges,
                           "sequences_in_flight": n_seq,
                           "single_stream_tokens_per_s": round(args.steps / elapsed, 2),
