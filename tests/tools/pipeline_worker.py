@@ -37,7 +37,13 @@ def main():
         dist.broadcast(idb, src=0)
         raw = (ctypes.c_ubyte * ggml.COMM_ID_BYTES)(*idb.tolist())
         comm_ranks = ggml.lib().ggml_hip_comm_init(rank, world, raw)
-        stage.comm_ready = comm_ranks == world
+        ok = torch.tensor([1 if comm_ranks == world else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks take the same transport
+        stage.comm_ready = int(ok.item()) == 1
+        if not stage.comm_ready:
+            if comm_ranks > 0:
+                ggml.lib().ggml_hip_comm_destroy()
+            use_rccl, comm_ranks = False, 0
     n_seq = world
     for s in range(n_seq):
         stage.new_sequence(s)
