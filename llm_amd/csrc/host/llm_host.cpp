@@ -628,6 +628,13 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
     m->llama = new llm::Llama(h, p, std::move(tl));
     return m;
 }
+// The layer ranges an in-process split over G device slots gets for the fractions `split` (ggml_cuda_set_tensor_split's
+// convention: slot i takes split[i] / sum; NULL or all zero = equal shares): bounds_out[0..G], stage i = layers
+// [bounds_out[i], bounds_out[i+1]).  Pure host arithmetic (no device needed): what llm_llama_new applies.
+void llm_split_layers(int n_layer, int G, const float *split, int *bounds_out) {
+    const std::vector<size_t> b = split_layers((size_t)n_layer, G, split);
+    for (int i = 0; i <= G; i++) bounds_out[i] = (int)b[(size_t)i];
+}
 // the layer range and device slot of every stage of a model (1 entry for an unsplit one); returns the stage count
 int llm_model_stages(const llm_model *m, int *layer_begin, int *layer_end, int *device, int cap) {
     if (m->stages.empty()) {
@@ -1028,8 +1035,10 @@ size_t llm_session_snapshot(llm_session *s, void *buf, size_t cap) {
     h.npast = ss.n_past;
     h.n_tokens = ss.tokens.size();
     h.n_logits = ss.last_logits.size();
-    h.k_bytes = ss.memory_k.nbytes();
-    h.v_bytes = ss.memory_v.nbytes();
+    // a session split over device slots holds one K/V cache per stage: concatenated in layer order they ARE the unsplit
+    // layout (llm_session_kv), so a snapshot does not depend on how the model was split when it was taken
+    h.k_bytes = llm_session_kv(s, 0, 0, nullptr, 0);
+    h.v_bytes = llm_session_kv(s, 1, 0, nullptr, 0);
     h.memory_k_type = (int32_t)ss.config.memory_k_type;
     h.memory_v_type = (int32_t)ss.config.memory_v_type;
     h.n_batch = (int32_t)ss.config.n_batch;
@@ -1043,9 +1052,9 @@ size_t llm_session_snapshot(llm_session *s, void *buf, size_t cap) {
     p += h.n_tokens * 4;
     memcpy(p, ss.last_logits.data(), h.n_logits * 4);
     p += h.n_logits * 4;
-    ggml_hip_tensor_get(ss.memory_k.ptr(), p, 0, h.k_bytes);
+    llm_session_kv(s, 0, 0, p, h.k_bytes);
     p += h.k_bytes;
-    ggml_hip_tensor_get(ss.memory_v.ptr(), p, 0, h.v_bytes);
+    llm_session_kv(s, 1, 0, p, h.v_bytes);
     return need;
 }
 // NULL = SnapshotError (bad header, or MemorySizeMismatch: the model's session has other K/V sizes than the snapshot)
@@ -1058,7 +1067,8 @@ llm_session *llm_session_from_snapshot(llm_model *m, const void *buf, size_t n) 
     llm_session_config cfg{h.memory_k_type, h.memory_v_type, h.n_batch, h.n_threads};
     llm_session *s = llm_start_session(m, &cfg);
     llm::InferenceSession &ss = *s->s;
-    if (ss.memory_k.nbytes() != h.k_bytes || ss.memory_v.nbytes() != h.v_bytes || ss.last_logits.size() != h.n_logits) {
+    if (llm_session_kv(s, 0, 0, nullptr, 0) != h.k_bytes || llm_session_kv(s, 1, 0, nullptr, 0) != h.v_bytes ||
+        ss.last_logits.size() != h.n_logits) {
         llm_session_free(s);
         return nullptr;  // SnapshotError::MemorySizeMismatch
     }
@@ -1067,10 +1077,11 @@ llm_session *llm_session_from_snapshot(llm_model *m, const void *buf, size_t n) 
     p += h.n_tokens * 4;
     memcpy(ss.last_logits.data(), p, h.n_logits * 4);
     p += h.n_logits * 4;
-    ggml_hip_tensor_set(ss.memory_k.ptr(), p, 0, h.k_bytes);
+    llm_session_kv(s, 0, 1, (void *)p, h.k_bytes);
     p += h.k_bytes;
-    ggml_hip_tensor_set(ss.memory_v.ptr(), p, 0, h.v_bytes);
+    llm_session_kv(s, 1, 1, (void *)p, h.v_bytes);
     ss.n_past = h.npast;
+    for (auto *st : s->stage_sessions) st->n_past = h.npast;  // every stage of a split session is at the same position
     return s;
 }
 

@@ -293,3 +293,29 @@ def test_comm_entry_points_exist_and_report_no_communicator(G):
     assert G.COMM_ID_BYTES == 128
     maps = open("/proc/self/maps").read()
     assert "librccl" not in maps
+
+
+def test_layer_split_arithmetic_of_the_tensor_split_hook(G):
+    """llm_split_layers: how ggml_cuda_set_tensor_split's fractions (crates/ggml/sys/src/cuda.rs:11; device i takes
+    split[i] / sum) become contiguous LAYER ranges for an in-process split (contiguous L/G layers per GPU).  Pure
+    host arithmetic, no device: equal shares for NULL / all zero, proportional otherwise, at least one layer per stage."""
+    lib = C.CDLL(G.LIB_PATH)
+    lib.llm_split_layers.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+
+    def bounds(n_layer, fr):
+        g = len(fr) if fr is not None else 4
+        out = (C.c_int * (g + 1))()
+        arr = (C.c_float * g)(*fr) if fr is not None else None
+        lib.llm_split_layers(n_layer, g, arr, out)
+        return list(out)
+
+    assert bounds(32, None) == [0, 8, 16, 24, 32]                    # north_star: contiguous L/G
+    assert bounds(32, [0, 0, 0, 0, 0, 0, 0, 0]) == [0, 4, 8, 12, 16, 20, 24, 28, 32]
+    assert bounds(80, [1, 1, 1, 1, 1, 1, 1, 1]) == list(range(0, 81, 10))
+    assert bounds(32, [0.5, 0.25, 0.25]) == [0, 16, 24, 32]
+    assert bounds(5, [0.2, 0.8]) == [0, 1, 5]
+    assert bounds(40, [3, 1]) == [0, 30, 40]
+    # never an empty stage, always the whole model, monotone
+    for n_layer, fr in ((3, [100, 1, 1]), (7, [1e-6, 1, 1e-6, 1]), (2, [1, 1]), (33, [1, 2, 3, 4, 5, 6, 7, 8])):
+        b = bounds(n_layer, fr)
+        assert b[0] == 0 and b[-1] == n_layer and all(y > x for x, y in zip(b, b[1:])), (n_layer, fr, b)

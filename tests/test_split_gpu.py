@@ -76,3 +76,52 @@ def test_layer_split_over_device_slots_reproduces_the_unsplit_session(G, how):
     r2 = _run(G, again, toks, 64)
     again.free()
     assert np.array_equal(ref[4], r2[4])
+
+
+def test_snapshot_moves_between_a_split_and_an_unsplit_session(G):
+    """InferenceSnapshot (inference_session.rs:590-646) of a session that is split over device slots: the stages' K/V caches
+    concatenated in layer order are the unsplit layout, so a snapshot taken from a 3-slot session restores into an unsplit
+    model (and the other way round) and decoding continues with the same tokens and logits."""
+    from llm_amd import llama, synth
+    if G.lib().ggml_hip_get_main_device() != 0:
+        pytest.skip("another test left a different main device")
+    hp, w = synth.make_llama(HP, 2, seed=19)
+    toks = np.random.default_rng(4).integers(0, hp["n_vocab"], 30).astype(np.int32)
+    whole = llama.Llama(hp, w, context_size=96)
+    ref = whole.start_session(n_batch=8)
+    ref.feed_prompt(toks[:21])
+    ids_a = [ref.infer_next_token() for _ in range(3)]
+    snap_whole = ref.snapshot()
+    ids_b = [ref.infer_next_token() for _ in range(4)]
+    last = ref.last_logits()
+    os.environ["GGML_HIP_VIRTUAL_DEVICES"] = "3"
+    os.environ["GGML_HIP_LAYER_SPLIT"] = "3"
+    try:
+        split = llama.Llama(hp, w, context_size=96)
+        assert len(split.stages()) == 3
+        s = split.start_session(n_batch=8)
+        s.feed_prompt(toks[:21])
+        assert [s.infer_next_token() for _ in range(3)] == ids_a
+        snap_split = s.snapshot()
+        assert len(snap_split) == len(snap_whole)
+        # unsplit snapshot -> split session
+        s2 = split.session_from_snapshot(snap_whole)
+        assert s2 is not None
+        assert [s2.infer_next_token() for _ in range(4)] == ids_b
+        assert np.array_equal(s2.last_logits(), last)
+        s.free()
+        s2.free()
+        split.free()
+    finally:
+        os.environ.pop("GGML_HIP_LAYER_SPLIT", None)
+        G.lib().ggml_hip_set_main_device(0)
+        os.environ.pop("GGML_HIP_VIRTUAL_DEVICES", None)
+    # split snapshot -> unsplit session
+    r2 = whole.session_from_snapshot(snap_split)
+    assert r2 is not None
+    assert [r2.infer_next_token() for _ in range(4)] == ids_b
+    assert np.array_equal(r2.last_logits(), last)
+    assert snap_split == snap_whole  # the same bytes: the split is invisible in the snapshot
+    for x in (ref, r2):
+        x.free()
+    whole.free()
