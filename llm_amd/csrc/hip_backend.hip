@@ -667,8 +667,6 @@ static void set_option_here(const char *key, int value) {
         g.opt_mmq_persist = value;
     else if (k == "mmq_waves")
         g.opt_mmq_waves = value;
-    else if (k == "mmq_t256_var")
-        g.opt_mmq_t256_var = value;
     else if (k == "mmq_splits")
         g.opt_mmq_splits = value;
     else if (k == "mmq_t256") {

@@ -34,7 +34,7 @@
 // and the asm after (volatile asm statements and barriers keep their order).
 #define T256_PIN(t) asm volatile("" : "+v"(t))
 
-// VAR (measurement variants, option mmq_t256_var; 0 = production): bit 0 = the counted DMA wait sits behind the phase's MFMAs
+// VAR (variants measured neutral in round 3 and no longer instantiated; 0 = production): bit 0 = the counted DMA wait sits behind the phase's MFMAs
 // (issued, still executing) instead of in front of the barrier that precedes them; bit 1 = no s_setprio around the MFMAs.
 template <int VAR>
 __global__ void __launch_bounds__(512, 2) k_mmq_w16_256(const MmqArgs a, int n_items, int tiles_total, int splits) {

@@ -10,9 +10,10 @@ SHAPES = [("wq|wk|wv", 12288, 4096, 2), ("wo", 4096, 4096, 2), ("w1|w3", 22016, 
           ("lm_head", 32000, 4096, 1)]
 if len(sys.argv) > 2 and sys.argv[2] == "big":
     SHAPES = [("4096^3", 4096, 4096, 1), ("8192x4096", 8192, 4096, 1)]
-VARIANTS = (("t256", {"mmq_t256": 2}), ("t256 late-wait", {"mmq_t256": 2, "mmq_t256_var": 1}), ("t256 no-prio", {"mmq_t256": 2, "mmq_t256_var": 2}),
-            ("w16_128", {"mmq_t256": 0}), ("dma_p8", {"mmq_t256": 0, "mmq_w16": 0}))
-RESET = {"mmq_t256": 1, "mmq_t256_var": 0, "mmq_w16": 1}
+# (round 3 also measured two variants of the 256-tile kernel — counted wait one phase later, no s_setprio — both neutral;
+# their instantiations and the option that selected them are gone)
+VARIANTS = (("t256", {"mmq_t256": 2}), ("w16_128", {"mmq_t256": 0}), ("dma_p8", {"mmq_t256": 0, "mmq_w16": 0}))
+RESET = {"mmq_t256": 1, "mmq_w16": 1}
 L = G.lib()
 rng = np.random.default_rng(1)
 for name, M, K, sp in SHAPES:
