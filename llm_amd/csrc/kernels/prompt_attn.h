@@ -40,7 +40,9 @@ struct PAttnArgs {
 
 #define PATTN_Q 32
 
-template <int D, bool INSTR = false>
+// QR = queries per workgroup: 32, or 16 for rows too long for 32 score rows in LDS (T up to ~2300 keys: the last chunks of a
+// 2048-token context; the MFMA tiles stay 32 rows high, their upper half computes on duplicated queries and is dropped)
+template <int D, bool INSTR = false, int QR = PATTN_Q>
 __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     if constexpr (INSTR) t0 = (long long)wall_clock64();
@@ -50,12 +52,12 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
-    const int ntile = (a.N + PATTN_Q - 1) / PATTN_Q;
+    const int ntile = (a.N + QR - 1) / QR;
     const int h = (int)blockIdx.x % a.H, qt = ntile - 1 - (int)blockIdx.x / a.H;  // the longest rows first
     const int hk = h / a.r;
-    const int q0 = qt * PATTN_Q;
+    const int q0 = qt * QR;
     const int Ttot = a.n_past + a.N;                        // keys written so far
-    const int T_hi = min(a.n_past + q0 + PATTN_Q, Ttot);    // keys 0 .. T_hi - 1 are visible to some query of the tile
+    const int T_hi = min(a.n_past + q0 + QR, Ttot);    // keys 0 .. T_hi - 1 are visible to some query of the tile
     const int nkt = (T_hi + 31) >> 5;
     const int rb = a.row_bytes;
 
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     // ~17 B per clock — the in-kernel timeline showed 10.8 us of Q load for every workgroup of the prompt plan.
     constexpr int QROW = D * 2 + 16;  // bytes per staged row (+16: fragment reads of consecutive rows spread over the banks)
     char *s_q = lds;  // the score rows are not in use yet (32 x QROW <= 32 x row_bytes for every T the launcher accepts)
-    for (int idx = tid; idx < PATTN_Q * (D / 16); idx += 256) {
+    for (int idx = tid; idx < QR * (D / 16); idx += 256) {
         const int row = idx / (D / 16), c = idx % (D / 16);
         const int qn = min(q0 + row, a.N - 1);
         const float *qp = a.q + (int64_t)qn * a.E + h * D + c * 16;
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     __syncthreads();
     f16x8 qa[KS];  // A operand: row fr of the tile, 8 channels per k step and lane half
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) qa[ks] = *(const f16x8 *)(s_q + fr * QROW + (fh * 8 + ks * 16) * 2);
+    for (int ks = 0; ks < KS; ks++) qa[ks] = *(const f16x8 *)(s_q + (fr & (QR - 1)) * QROW + (fh * 8 + ks * 16) * 2);
     __syncthreads();  // the fragments are in registers: the S phase may overwrite the staging area
     if constexpr (INSTR) t1 = (long long)wall_clock64();
     // ---- S phase
@@ -136,7 +138,8 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
                     for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kb[j][ks], acc, 0, 0, 0);
                     float *sp = (float *)(lds + 4 * fh * rb) + kt * 32 + fr;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) *(float *)((char *)sp + ((r & 3) + 8 * (r >> 2)) * rb) = acc[r];
+                    for (int r = 0; r < 16; r++)  // row (r & 3) + 8 (r >> 2) + 4 fh: below 16 exactly for r < 8
+                        if (QR == 32 || r < 8) *(float *)((char *)sp + ((r & 3) + 8 * (r >> 2)) * rb) = acc[r];
                 }
             }
         }
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         // The wave's 8 rows side by side: each row's three passes are chains of LDS read -> exp -> LDS write that ran at one
         // latency per step when the rows went one after the other (20 of the kernel's 35 us); per element and per row the
         // operations and their order are unchanged.
-        constexpr int RW = 8;
+        constexpr int RW = QR / 4;  // rows per wave
         const int row0 = wave * RW;
         const int nrow = min(RW, a.N - q0 - row0);  // rows of this wave that exist (ragged last tile), wave-uniform, may be <= 0
         const int lim0 = a.n_past + q0 + row0;      // row rr sees keys 0 .. lim0 + rr
@@ -219,7 +222,8 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         const int nch = npad >> 4;
         const int d0 = wave * 32;
         const __half *vp = a.mem_v + ((int64_t)hk * D + d0 + fr) * a.C + fh * 8;
-        const char *pa = lds + fr * rb + fh * 16;
+        const char *pa = lds + (fr & (QR - 1)) * rb + fh * 16;
+        constexpr int NR = QR / 2;  // accumulator registers that hold real query rows (row (r & 3) + 8 (r >> 2) + 4 fh < QR)
         auto load_v = [&](int c) {
             const int valid = Ttot - (c * 16 + fh * 8);  // the cache beyond the last written key may hold anything,
             u32x4 v = {0, 0, 0, 0};                      // and a row ends at C (C % 8 == 0: a group of 8 is inside or outside)
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
             // the wave's 32 channels are one Q8 block of the merged row: amax over the 32 lanes of a half, k_p_quant4's formula
             _Float16 *xp = a.x16 + (int64_t)(q0 + 4 * fh) * a.E + h * D + d0 + mmq_kperm_inv(fr);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < NR; r++) {
                 const int row = (r & 3) + 8 * (r >> 2);
                 const float v = acc[r];
                 // max over the 32 lanes of this half: DPP inside each row of 16, then the two rows' results through scalar
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         } else {
             float *op = a.out + (int64_t)(q0 + 4 * fh) * a.E + h * D + d0 + fr;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < NR; r++) {
                 const int row = (r & 3) + 8 * (r >> 2);
                 if (q0 + 4 * fh + row < a.N) op[(int64_t)row * a.E] = acc[r];
             }

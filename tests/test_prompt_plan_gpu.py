@@ -256,7 +256,8 @@ def test_prompt_plan_with_a_k_split_on_wk_wv_only(G):
 def test_fused_prompt_attention_kernel_matches_the_three_launch_path(G):
     """kernels/prompt_attn.h (K.Q, scale + mask + softmax and V.P in one launch, scores in LDS) against k_gemm_f16 ->
     k_p_soft_max -> k_gemm_f16_b16 on random Q / K / V through ggml_hip_debug_prompt_attention: head sizes 32 / 64 / 128,
-    grouped-query attention, ragged batches, rows up to ~1100 keys (the fused kernel's LDS limit is 1184).  Both paths
+    grouped-query attention, ragged batches, rows up to ~1100 keys with 32 queries per workgroup (LDS limit 1184) and up to
+    2237 keys with 16.  Both paths
     perform the same operations; their scores can differ in the last f32 bit, which moves about one probability in a
     hundred rows across an f16 rounding boundary (measured: 1..8 % of rows differ, by <= 5e-5): bound 2e-4 of max|out|."""
     import ctypes as C
@@ -264,10 +265,13 @@ def test_fused_prompt_attention_kernel_matches_the_three_launch_path(G):
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int]
     cases = [(64, 4, 4, 32, 0), (128, 4, 4, 32, 230), (33, 2, 1, 64, 500), (512, 8, 8, 128, 1), (200, 4, 2, 128, 700), (96, 4, 4, 32, 1000),
-             (70, 4, 4, 128, 1050), (1, 4, 4, 64, 77)]
+             (70, 4, 4, 128, 1050), (1, 4, 4, 64, 77),
+             # rows longer than 1184 keys: 16 queries per workgroup (the last chunks of a 2048-token context)
+             (64, 4, 4, 128, 1500), (100, 4, 2, 64, 1948), (37, 2, 2, 32, 2200), (512, 4, 4, 128, 1536)]
     for N, H, Hkv, D, n_past in cases:
         rng = np.random.default_rng([N, H, D, n_past])
-        Cc, E, Eg, T = 1184, H * D, Hkv * D, n_past + N
+        E, Eg, T = H * D, Hkv * D, n_past + N
+        Cc = 1184 if T <= 1184 else 2304
         q = rng.standard_normal((N, E)).astype(np.float32)
         k = np.full((Cc, Eg), np.nan, np.float16)  # unwritten cache rows must not matter
         v = np.full((Eg, Cc), np.nan, np.float16)
