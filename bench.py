@@ -258,6 +258,9 @@ def prefill_leg(L, ggml, model, hp, n, steps, warmup, wname):
                          "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "launches_per_step": launches,
                          "algo_flops_per_step": flops, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                          "method": "per-launch HIP events on the backend stream, one extra untimed step"},
+            "logits_read_back": "the last token's row only (128 KB): feed_prompt evaluates with OutputRequest::default() "
+                                "(crates/llm-base/src/inference_session.rs:315-316), so the host mirror keeps the [n_vocab, N] logits node on "
+                                "the device and read_last_token fetches one row; an evaluation that asks for all logits reads all 65 MB back",
             "class_ms_per_step": {k: round(v[0], 3) for k, v in cls.items()},
             "class_launches_per_step": {k: v[1] for k, v in cls.items()}}
 

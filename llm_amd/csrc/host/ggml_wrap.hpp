@@ -368,7 +368,12 @@ inline size_t Tensor::element_size() const {
 inline void Tensor::write_data(const void *src, size_t n) { memcpy(data(), src, n); }
 inline void Tensor::zero_data() { memset(data(), 0, nbytes()); }
 inline void Tensor::read_data(size_t offset, void *dst, size_t n) const {
-    memcpy(dst, (const char *)ggml_get_data(ptr_) + offset, n);
+    // tensor.rs:206-209 reads host memory; a node that lives on the device (backend Gpu) is fetched through the backend
+    // (what INTEGRATION.md tells a Rust maintainer to do for offloaded tensors)
+    if (ptr_->backend != GGML_BACKEND_CPU)
+        ggml_hip_tensor_get(ptr_, dst, offset, n);
+    else
+        memcpy(dst, (const char *)ggml_get_data(ptr_) + offset, n);
 }
 inline bool Tensor::is_contiguous() const { return ggml_is_contiguous(ptr_); }
 inline void Tensor::free_accelerator() { ggml_hip_free_data(ptr_); }

@@ -357,8 +357,12 @@ class Llama {
 
     // The graph builder of Llama::evaluate (models/llama/src/lib.rs:166-362) for `input_len` tokens at position
     // `session_len`, as a value so that the session can also build the graph of the next call ahead of time.
-    InferenceSession::Builder make_builder(InferenceSession *session_ptr, size_t input_len, size_t session_len) {
-        return [this, session_ptr, input_len, session_len](BuildContext &builder) {
+    // logits_on_device: the logits node stays in HBM (like every other node) instead of being mirrored to the host after the
+    // compute — taken for a multi-token evaluation that did not ask for all logits (feed_prompt: OutputRequest::default()):
+    // read_last_token then fetches the one row it wants (65 MB of read-back per 512-token batch otherwise)
+    InferenceSession::Builder make_builder(InferenceSession *session_ptr, size_t input_len, size_t session_len,
+                                           bool logits_on_device = false) {
+        return [this, session_ptr, input_len, session_len, logits_on_device](BuildContext &builder) {
             InferenceSession &session = *session_ptr;
             const size_t ctx_size = params.context_size;
             const size_t n_embd = hyperparameters.n_embd, n_head = hyperparameters.n_head,
@@ -449,7 +453,7 @@ class Llama {
             input_layer = ctx0.op_rms_norm(input_layer);  // :343
             input_layer = ctx0.op_mul(input_layer, norm);  // :346
             Tensor embedding_result = input_layer.share();
-            ctx0.set_offloading(false);  // :350
+            ctx0.set_offloading(logits_on_device && params.use_gpu);  // :350 (false in the reference: the logits live on the host)
             input_layer = ctx0.op_mul_mat(output, input_layer);  // :352 lm_head
             ctx0.use_scratch(nullptr);  // :354
             return std::make_pair(gf, GraphOutputs{input_layer, embedding_result});
@@ -465,7 +469,7 @@ class Llama {
 
         InferenceSession *sp = &session;
         GraphOutputs outputs = session.compute(
-            input_tokens, make_builder(sp, input_len, session_len),
+            input_tokens, make_builder(sp, input_len, session_len, input_len > 1 && !output_request.all_logits),
             [this, sp](size_t next_len) { return make_builder(sp, 1, next_len); }, this, ctx_size);
         if (!is_last()) return;
         // finish evaluation (:364-367)
