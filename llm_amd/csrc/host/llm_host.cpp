@@ -923,19 +923,10 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
         abort();
     }
     const double t0 = llm::InferenceSession::now_ns();
-    // first index of the maximum (`if (l[i] > l[best]) best = i`), as two passes the compiler vectorizes: the maximum value,
-    // then the first position that holds it (7 -> 2 us for 32000 logits; a NaN in front keeps index 0 as the scalar loop does)
     const std::vector<float> &l = s->s->last_logits;
-    const float *lp = l.data();
-    const size_t nl = l.size();
-    float mx = lp[0];
-    for (size_t i = 1; i < nl; i++) mx = lp[i] > mx ? lp[i] : mx;
     size_t best = 0;
-    for (size_t i = 0; i < nl; i++)
-        if (lp[i] == mx) {
-            best = i;
-            break;
-        }
+    for (size_t i = 1; i < l.size(); i++)
+        if (l[i] > l[best]) best = i;
     const llm::TokenId next = (llm::TokenId)best;
     s->s->tokens.push_back(next);
     llm::OutputRequest req;
