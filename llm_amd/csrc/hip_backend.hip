@@ -661,6 +661,8 @@ static void set_option_here(const char *key, int value) {
     }
     else if (k == "mmq_fuse")
         g.opt_mmq_fuse = value;
+    else if (k == "spin_wait")
+        g.opt_spin_wait = value;
     else if (k == "chain_k")
         g.opt_chain_k = std::min(64, std::max(0, value));
     else if (k == "mmq_persist")

@@ -636,8 +636,9 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
 // convention: slot i takes split[i] / sum; NULL or all zero = equal shares): bounds_out[0..G], stage i = layers
 // [bounds_out[i], bounds_out[i+1]).  Pure host arithmetic (no device needed): what llm_llama_new applies.
 void llm_split_layers(int n_layer, int G, const float *split, int *bounds_out) {
-    const std::vector<size_t> b = split_layers((size_t)n_layer, G, split);
-    for (int i = 0; i <= G; i++) bounds_out[i] = (int)b[(size_t)i];
+    const int Gu = std::max(1, std::min(G, n_layer));  // more slots than layers: the surplus slots get empty ranges at the end
+    const std::vector<size_t> b = split_layers((size_t)std::max(1, n_layer), Gu, split);
+    for (int i = 0; i <= G; i++) bounds_out[i] = i <= Gu ? (int)b[(size_t)i] : n_layer;
 }
 // the layer range and device slot of every stage of a model (1 entry for an unsplit one); returns the stage count
 int llm_model_stages(const llm_model *m, int *layer_begin, int *layer_end, int *device, int cap) {

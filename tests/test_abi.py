@@ -315,6 +315,7 @@ def test_layer_split_arithmetic_of_the_tensor_split_hook(G):
     assert bounds(32, [0.5, 0.25, 0.25]) == [0, 16, 24, 32]
     assert bounds(5, [0.2, 0.8]) == [0, 1, 5]
     assert bounds(40, [3, 1]) == [0, 30, 40]
+    assert bounds(2, [1, 1, 1, 1]) == [0, 1, 2, 2, 2]  # more slots than layers: the surplus ones stay empty
     # never an empty stage, always the whole model, monotone
     for n_layer, fr in ((3, [100, 1, 1]), (7, [1e-6, 1, 1e-6, 1]), (2, [1, 1]), (33, [1, 2, 3, 4, 5, 6, 7, 8])):
         b = bounds(n_layer, fr)
