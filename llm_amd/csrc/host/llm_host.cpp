@@ -7,6 +7,9 @@
 // names and call order so that the graph handed to ggml_graph_compute is node-for-node the graph the
 // Rust code builds (tests/test_graph_shape.py counts the nodes).  All compute goes through the C ABI
 // of include/ggml_hip.h.
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include "llm_host.h"
 
 #include <chrono>
@@ -917,6 +920,50 @@ void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *tokens, int n)
         for (auto tk : batch) s->s->tokens.push_back(tk);
     }
 }
+// Greedy sampling on the host: the index the loop `best = 0; if (l[i] > l[best]) best = i` returns (first maximum; NaNs never win;
+// a NaN in front keeps index 0).  The AVX2 version finds the maximum with the same `>` rule lane by lane, then the first
+// position that holds it: 7 -> ~1.5 us for 32000 logits, on the critical path of every decoded token.
+static size_t argmax_first_scalar(const float *l, size_t n) {
+    size_t best = 0;
+    for (size_t i = 1; i < n; i++)
+        if (l[i] > l[best]) best = i;
+    return best;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static size_t argmax_first_avx2(const float *l, size_t n) {
+    if (n < 16) return argmax_first_scalar(l, n);
+    __m256 mx = _mm256_set1_ps(l[0]);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m256 v = _mm256_loadu_ps(l + i);
+        mx = _mm256_blendv_ps(mx, v, _mm256_cmp_ps(v, mx, _CMP_GT_OQ));
+    }
+    float lanes[8];
+    _mm256_storeu_ps(lanes, mx);
+    float m = l[0];
+    for (int k = 0; k < 8; k++) m = lanes[k] > m ? lanes[k] : m;
+    for (; i < n; i++) m = l[i] > m ? l[i] : m;
+    if (!(m == m)) return 0;  // l[0] is NaN: nothing compares greater
+    const __m256 mv = _mm256_set1_ps(m);
+    for (i = 0; i + 8 <= n; i += 8) {
+        const int mask = _mm256_movemask_ps(_mm256_cmp_ps(_mm256_loadu_ps(l + i), mv, _CMP_EQ_OQ));
+        if (mask) return i + (size_t)__builtin_ctz((unsigned)mask);
+    }
+    for (; i < n; i++)
+        if (l[i] == m) return i;
+    return 0;
+}
+#endif
+static size_t argmax_first(const float *l, size_t n) {
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) return argmax_first_avx2(l, n);
+#endif
+    return argmax_first_scalar(l, n);
+}
+// test hook: which = 0 the dispatching version, 1 the scalar loop
+int llm_argmax_first(const float *l, int n, int which) { return (int)(which ? argmax_first_scalar(l, (size_t)n) : argmax_first(l, (size_t)n)); }
+
 int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
     // inference_session.rs:381-424 with the sampler chain replaced by argmax over last_logits
     if (s->s->n_past + 1 >= m->llama->params.context_size) {
@@ -925,10 +972,7 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
     }
     const double t0 = llm::InferenceSession::now_ns();
     const std::vector<float> &l = s->s->last_logits;
-    size_t best = 0;
-    for (size_t i = 1; i < l.size(); i++)
-        if (l[i] > l[best]) best = i;
-    const llm::TokenId next = (llm::TokenId)best;
+    const llm::TokenId next = (llm::TokenId)argmax_first(l.data(), l.size());
     s->s->tokens.push_back(next);
     llm::OutputRequest req;
     const double t1 = llm::InferenceSession::now_ns();

@@ -110,6 +110,8 @@ GGML_API void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, i
 GGML_API void llm_session_stage_buffers(llm_session *s, void **in_dev, void **out_dev, size_t *nbytes);
 /* raw K/V memory of a session (which: 0 = memory_k, 1 = memory_v; set: 0 = read into buf, 1 = write from buf);
  * buf == NULL returns the size.  The InferenceSnapshot payload (inference_session.rs:599-646). */
+/* test hook: the greedy sampler's index (first maximum under `>`, NaNs never win); which = 1: the scalar loop */
+GGML_API int llm_argmax_first(const float *logits, int n, int which);
 /* layer ranges of an in-process split over G device slots for the fractions `split` (NULL = equal): bounds_out[0..G] */
 GGML_API void llm_split_layers(int n_layer, int G, const float *split, int *bounds_out);
 GGML_API size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbytes);

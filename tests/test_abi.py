@@ -320,3 +320,36 @@ def test_layer_split_arithmetic_of_the_tensor_split_hook(G):
     for n_layer, fr in ((3, [100, 1, 1]), (7, [1e-6, 1, 1e-6, 1]), (2, [1, 1]), (33, [1, 2, 3, 4, 5, 6, 7, 8])):
         b = bounds(n_layer, fr)
         assert b[0] == 0 and b[-1] == n_layer and all(y > x for x, y in zip(b, b[1:])), (n_layer, fr, b)
+
+
+def test_host_greedy_argmax_follows_the_scalar_rule(G):
+    """llm_infer_next_token_greedy's sampler (the reference's sampler chain reduced to argmax): the AVX2 version must return
+    the index of `best = 0; if (l[i] > l[best]) best = i` — first maximum, NaNs never win, a NaN in front keeps 0, -0.0 == 0.0."""
+    lib = C.CDLL(G.LIB_PATH)
+    lib.llm_argmax_first.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(3)
+
+    def ref(l):
+        best = 0
+        for i in range(1, len(l)):
+            if l[i] > l[best]:
+                best = i
+        return best
+
+    cases = []
+    for n in (1, 2, 7, 8, 15, 16, 17, 31, 100, 257, 32000):
+        a = rng.standard_normal(n).astype(np.float32)
+        cases.append(a)
+        b = np.round(a, 1).astype(np.float32)  # many ties
+        cases.append(b)
+        if n >= 8:
+            c = a.copy(); c[rng.integers(0, n, 3)] = np.nan; cases.append(c)
+            d = a.copy(); d[0] = np.nan; cases.append(d)
+            e = np.zeros(n, np.float32); e[n // 2] = -0.0; e[n - 1] = 0.0; cases.append(e)
+            f = np.full(n, -np.inf, np.float32); cases.append(f)
+            g_ = a.copy(); g_[n - 1] = a.max() ; cases.append(g_)  # the maximum again at the end: the first one wins
+    for a in cases:
+        a = np.ascontiguousarray(a)
+        want = ref(a) if a.size <= 300 else int(np.flatnonzero(a == np.nanmax(a))[0]) if not np.isnan(a[0]) else 0
+        for which in (0, 1):
+            assert lib.llm_argmax_first(a.ctypes.data, a.size, which) == want, (a.size, which)
