@@ -147,8 +147,10 @@ PARITY_EDGE = 4e-2  # tests/test_llama_gpu.py EDGE: one int8 activation quant on
 
 
 def parity_check(args, hp, w, sess):
-    """The token the timed loop would evaluate next, evaluated by the device AND by the CPU oracle (mode 0 = ggml's scalar
-    path) from the same K/V state: the session's K/V cache (what the timed steps wrote) is copied into the oracle, both
+    """The token the timed loop would evaluate next, evaluated by the device AND by the CPU oracle from the same K/V state —
+    the oracle in the mode that restates what the reference's build EXECUTES (crates/ggml/sys/build.rs:46-62: ggml's AVX2
+    branches = mode 3 / 2; the device's activation quantizer follows that branch), with the scalar branch (mode 0) printed
+    beside it: the session's K/V cache (what the timed steps wrote) is copied into the oracle, both
     evaluate argmax(last logits) at the session's n_past.  The yardstick is the reference's OWN ambiguity measured in the
     same run: the oracle with its f32 block sums added in reverse order (a second legal order of ggml's vec_dot; upstream's
     scalar and AVX2 branches differ by as much) gives `band`, the math mode (no activation quantization) the noise floor.
@@ -160,7 +162,8 @@ def parity_check(args, hp, w, sess):
     n_past = sess.n_past
     tok = np.array([int(np.argmax(sess.last_logits()))], np.int32)
     k, v = sess.get_kv()
-    orcs = [oracle.Llama(hp, w, ctx) for _ in range(3)]
+    orcs = [oracle.Llama(hp, w, ctx) for _ in range(4)]
+    mode = oracle.ref_mode()
     for o in orcs:
         o.memory_k[:] = k
         o.memory_v[:] = v
@@ -168,16 +171,19 @@ def parity_check(args, hp, w, sess):
     assert sess.infer_next_token() == int(tok[0])  # InferenceSession::infer_next_token: argmax of the last logits, evaluated
     got = sess.last_logits()
     t = time.perf_counter()
-    ref = orcs[0].evaluate(tok, mode=0)[-1]
+    ref = orcs[0].evaluate(tok, mode=mode)[-1]
     ref_s = time.perf_counter() - t
-    rev = orcs[1].evaluate(tok, mode=0, reverse_blocks=True)[-1]
+    rev = orcs[1].evaluate(tok, mode=mode, reverse_blocks=True)[-1]
     mth = orcs[2].evaluate(tok, mode=1)[-1]
+    sca = orcs[3].evaluate(tok, mode=0)[-1]  # ggml's scalar branch, for the record
     k2, v2 = sess.get_kv()
     std = float(mth.std())
     d = float(np.max(np.abs(got - ref))) / std
     rms = float(np.sqrt(np.mean((got - ref) ** 2))) / std
     band = float(np.max(np.abs(ref - rev))) / std
     floor = float(np.max(np.abs(ref - mth))) / std
+    d_scalar = float(np.max(np.abs(got - sca))) / std
+    branches = float(np.max(np.abs(ref - sca))) / std
     # K/V rows the token wrote: layer 0 depends on the embedding and wk / wv only (must agree up to a last-bit rounding of a few
     # halves); deeper layers of a random-init model amplify a last-bit difference chaotically (that is what `band` measures)
     Eg = hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])
@@ -194,7 +200,11 @@ def parity_check(args, hp, w, sess):
            "kv_layer0_halves_that_differ": nk0, "kv_layer0_halves_written": int(2 * Eg),
            "kv_all_layers_halves_that_differ": nk, "kv_all_layers_halves_written": int(2 * hp["n_layer"] * Eg),
            "n_past": int(n_past),
-           "oracle": "oracle/ggml_oracle.c mode 0 (ggml scalar path restated; parity unpinned, DESIGN.md section 5)",
+           "oracle": f"oracle/ggml_oracle.c mode {mode} (ggml's AVX2 branch, what the reference's build runs: crates/ggml/sys/"
+                     "build.rs:46-62; restated, parity unpinned: DESIGN.md section 5); the device's activation quantizer follows "
+                     "that branch (option act_quant = 0)",
+           "vs_scalar_branch_mode0": {"device_max_over_std": float(f"{d_scalar:.3e}"),
+                                      "avx2_vs_scalar_oracle_max_over_std": float(f"{branches:.3e}")},
            "oracle_s": round(ref_s, 2),
            "what": "logits of the next decode token after the timed steps, device vs CPU oracle on the session's own K/V; band = "
                    "the oracle against itself with the block sums in reverse order, floor = against its math mode"}
@@ -243,6 +253,9 @@ def prefill_leg(L, ggml, model, hp, n, steps, warmup, wname):
     achieved = flops / 1e12 / (ms / 1e3) if ms > 0 else 0.0
     sess.free()
     return {"tokens": n, "steps": steps, "tokens_per_s": round(n * steps / elapsed, 1),
+            "dtype": "f16 x f16 MFMA, f32 accumulate: weights f16(d*q) from the resident copy (or dequantized in LDS), activations "
+                     "re-quantized to Q8 as ggml does and then f16(d*q) (north_star: MFMA-f16 tiles for batched prefill); attention "
+                     "f16 K/V x f16-rounded Q / probabilities, f32 accumulate",
             "ms_per_step": round(elapsed / steps * 1e3, 3),
             "ms_per_step_min_median_max": [round(x * 1e3, 3) for x in (min(per_step), float(np.median(per_step)), max(per_step))],
             "weights_f16_copy_bytes": w16_bytes,

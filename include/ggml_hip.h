@@ -458,8 +458,15 @@ GGML_API int ggml_hip_device_count(void);
  * ggml_hip_set_main_device (cuda.rs:62) makes a slot current for every following call.  GGML_HIP_VIRTUAL_DEVICES=n maps n
  * slots onto the visible GPUs round-robin (several slots on one GPU: how the split is tested on a 1-GPU box). */
 GGML_API int ggml_hip_get_main_device(void);
-/* the fractions last given to ggml_hip_set_tensor_split (cuda.rs:11), one per slot; returns the number written */
+/* ggml_hip_set_tensor_split / ggml_cuda_set_tensor_split read exactly ONE float: the reference passes the address of a
+ * single stack f32 (crates/ggml/src/accelerator/mod.rs:74-75).  get returns that value (out[0]; 1 written). */
 GGML_API int ggml_hip_get_tensor_split(float *out, int cap);
+/* A split of ONE model over several device slots of this process, by LAYERS (ggml's fractions convention: slot i takes
+ * fractions[i] / sum; all zero = equal shares; rows of one tensor are never split).  Explicit length, so nothing is read
+ * past the caller's array.  NULL or n <= 0 clears it.  llm_llama_new applies it (also: env GGML_HIP_LAYER_SPLIT=G for G
+ * equal shares).  get returns the number of fractions written. */
+GGML_API void ggml_hip_set_layer_split(const float *fractions, int n);
+GGML_API int ggml_hip_get_layer_split(float *out, int cap);
 /* dst (on slot dst_device) = src (on slot src_device), ordered after src_device's enqueued work and before dst_device's
  * later work: the residual hop of a layer split inside one process (peer copy over xGMI between two GPUs). */
 GGML_API void ggml_hip_copy_between_devices(int dst_device, void *dst, int src_device, const void *src, size_t nbytes);

@@ -86,6 +86,7 @@ static void fatal_note(const char *fmt, ...) {
         }                                                                                            \
     } while (0)
 
+extern "C" void ggml_hip_internal_set_option_here(const char *key, int value);
 namespace {
 #include "backend_state.inc"
 #include "backend_memory.inc"
@@ -234,17 +235,32 @@ void ggml_hip_set_main_device(int main_device) {
     if (g.inited) bind_device();
 }
 void ggml_hip_set_tensor_split(const float *tensor_split) {
-    // crates/ggml/sys/src/cuda.rs:11.  The reference passes a single 1.0 (crates/ggml/src/accelerator/mod.rs:74-75).
-    // Here the fractions (one per slot, ggml's convention: device i takes the share split[i] / sum) are kept for the host
-    // side, which turns them into a LAYER split (llm_split_layers, host/llm_host.cpp): rows of one tensor are never split.
+    // crates/ggml/sys/src/cuda.rs:11.  The reference's only caller passes the address of ONE stack float
+    // (crates/ggml/src/accelerator/mod.rs:74-75: `let split = 1.0f32; ggml_cuda_set_tensor_split(&split as *const f32)`,
+    // LLAMA_MAX_DEVICES = 1), so exactly one float is read here, whatever the number of visible devices: upstream's hook
+    // reads one per device, and on an 8-GPU box that is seven floats of the caller's stack.  A split over several slots is
+    // asked for through ggml_hip_set_layer_split (explicit length) or GGML_HIP_LAYER_SPLIT.
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    const int n = std::max(1, slot_count());
-    for (int i = 0; i < GGML_HIP_MAX_BACKENDS; i++) g_tensor_split[i] = tensor_split && i < n ? tensor_split[i] : 0.0f;
+    for (int i = 0; i < GGML_HIP_MAX_BACKENDS; i++) g_tensor_split[i] = 0.0f;
+    g_tensor_split[0] = tensor_split ? tensor_split[0] : 0.0f;
 }
 int ggml_hip_get_tensor_split(float *out, int cap) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    const int n = std::min(cap, std::max(1, slot_count()));
+    const int n = std::min(cap, GGML_HIP_MAX_BACKENDS);
     for (int i = 0; i < n; i++) out[i] = g_tensor_split[i];
+    return std::min(n, 1);
+}
+void ggml_hip_set_layer_split(const float *fractions, int n) {
+    // ggml's convention for a split (slot i takes fractions[i] / sum), applied to LAYERS: rows of one tensor are never
+    // split (llm_split_layers, host/llm_host.cpp).  n <= 0 or NULL clears it; all-zero fractions mean equal shares.
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    g_layer_split_n = fractions && n > 0 ? std::min(n, GGML_HIP_MAX_BACKENDS) : 0;
+    for (int i = 0; i < GGML_HIP_MAX_BACKENDS; i++) g_layer_split[i] = i < g_layer_split_n ? fractions[i] : 0.0f;
+}
+int ggml_hip_get_layer_split(float *out, int cap) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    const int n = std::min(cap, g_layer_split_n);
+    for (int i = 0; i < n; i++) out[i] = g_layer_split[i];
     return n;
 }
 void ggml_hip_set_mul_mat_q(bool) {}  // quantized kernels are always used
@@ -602,15 +618,35 @@ void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *al
         if (algo_bytes) *algo_bytes = g.timing.bytes[kclass];
     }
 }
-static void set_option_here(const char *key, int value);
-void ggml_hip_set_option(const char *key, int value) {  // options are process-wide: every slot gets them
+void ggml_hip_set_option(const char *key, int value) {
+    // Options are process-wide.  Slots that exist get the value now; a slot initialised later replays the log (ensure_init):
+    // setting an option never creates a stream, a context or a buffer on a device this process has not used yet.
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    for_each_slot([&] { set_option_here(key, value); });
+    if (strcmp(key, "w16_release") != 0) g_opt_log[key] = value;  // an action, not a state
+    bool known = false;
+    for_each_slot([&] {
+        if (g.inited) {
+            ggml_hip_internal_set_option_here(key, value);
+            known = true;
+        }
+    });
+    if (!known) {  // no slot yet: validate the key (an unknown one must fail here, not at the first graph)
+        Backend probe_state;
+        Backend *keep = g_cur;
+        g_cur = &probe_state;
+        const bool device_key = !strcmp(key, "timeline") || !strcmp(key, "act_quant") || !strcmp(key, "w16_release") || !strcmp(key, "mmq_w16");
+        if (!device_key) ggml_hip_internal_set_option_here(key, value);
+        g_cur = keep;
+    }
 }
-static void set_option_here(const char *key, int value) {
+void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on the current slot
     const std::string k(key);
     if (k == "fuse")
         g.opt_fuse = value;
+    else if (k == "act_quant") {  // 0 = ggml's AVX2 activation quantizer (what the reference's build runs), 1 = its scalar branch
+        g.opt_act_quant = value ? 1 : 0;
+        apply_act_quant();
+    }
     else if (k == "plan")
         g.opt_plan = value;
     else if (k == "graph")
@@ -627,7 +663,6 @@ static void set_option_here(const char *key, int value) {
             g.timeline = nullptr;
         }
         if (value && !g.timeline) {
-            ensure_init();
             g.timeline_wgs = value == 1 ? 4 : value;
             g.timeline_bytes = (size_t)1024 * g.timeline_wgs * 8 * 8;
             HIP_CHECK(hipMalloc((void **)&g.timeline, g.timeline_bytes));

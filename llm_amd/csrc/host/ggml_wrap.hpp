@@ -63,9 +63,8 @@ namespace accelerator {  // accelerator/mod.rs:66-94 (cublas arms → this libra
 inline void initialize(int device) {
     ggml_init_hipblas();
     ggml_hip_set_main_device(device);
-    // the reference passes a one-element array (mod.rs:74-75); the hook reads one fraction per device, so give it that many
-    const float split[16] = {1.0f};
-    ggml_hip_set_tensor_split(split);
+    const float split = 1.0f;  // mod.rs:74-75: the address of one stack float; the hook reads exactly one
+    ggml_hip_set_tensor_split(&split);
 }
 inline void set_scratch_size(size_t size) { ggml_hip_set_scratch_size(size); }
 inline void free_scratch() { ggml_hip_free_scratch(); }

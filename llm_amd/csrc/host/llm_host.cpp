@@ -195,17 +195,33 @@ class InferenceSession {
         last_graph = nullptr;
     }
 
-    void make_stage_buffers(size_t n_embd, bool in, bool out) {
-        stage_ctx_ = std::make_shared<Context>(Context::new_with_allocate(2 * (n_embd * config.n_batch * 4 + 1024)));
+    // hand-off buffers of a layer-split stage: n_embd * rows floats each, rows = n_batch to begin with.  Model::evaluate may
+    // be called with more tokens than n_batch (an unsplit model takes any count): the buffers then grow to that count
+    // (ensure_stage_rows, called by the graph builder before it makes its views).
+    void make_stage_buffers(size_t n_embd, bool in, bool out, size_t rows = 0) {
+        if (rows == 0) rows = config.n_batch;
+        stage_in = Tensor();
+        stage_out = Tensor();
+        stage_ctx_.reset();  // drops the old buffers' device copies (Context drop frees offloaded tensors)
+        stage_ctx_ = std::make_shared<Context>(Context::new_with_allocate(2 * (n_embd * rows * 4 + 1024)));
         if (in) {
-            stage_in = stage_ctx_->new_tensor_1d(GGML_TYPE_F32, n_embd * config.n_batch).set_name("stage_in");
+            stage_in = stage_ctx_->new_tensor_1d(GGML_TYPE_F32, n_embd * rows).set_name("stage_in");
             stage_in.offload_no_scratch();
         }
         if (out) {
-            stage_out = stage_ctx_->new_tensor_1d(GGML_TYPE_F32, n_embd * config.n_batch).set_name("stage_out");
+            stage_out = stage_ctx_->new_tensor_1d(GGML_TYPE_F32, n_embd * rows).set_name("stage_out");
             stage_out.offload_no_scratch();
         }
+        stage_rows_ = rows;
+        stage_has_in_ = in;
+        stage_has_out_ = out;
     }
+    void ensure_stage_rows(size_t n_embd, size_t rows) {
+        if (rows <= stage_rows_) return;
+        pre_.valid = false;  // a speculatively built graph holds views of the old buffers
+        make_stage_buffers(n_embd, stage_has_in_, stage_has_out_, rows);
+    }
+    size_t stage_rows() const { return stage_rows_; }
 
     InferenceSessionConfig config;
     Tensor memory_k, memory_v;
@@ -220,6 +236,8 @@ class InferenceSession {
    private:
     std::shared_ptr<Context> session_ctx_;
     std::shared_ptr<Context> stage_ctx_;
+    size_t stage_rows_ = 0;
+    bool stage_has_in_ = false, stage_has_out_ = false;
     size_t memory_size_ = 0;
     struct Built {
         ComputationGraph gf{nullptr};
@@ -376,10 +394,10 @@ class Llama {
             Context &ctx0 = *builder.ctx0;
             const Tensor &embd = *builder.embd;
             (void)n_layer;
-            // a stage of a layer split exchanges the residual through hand-off buffers of n_embd * n_batch floats;
-            // ggml_view_1d has no bounds check (upstream neither), so a larger batch would run past them silently
-            if ((!is_first() || !is_last()) && input_len > session.config.n_batch)
-                ggml::panic("evaluate: a layer-split stage takes at most n_batch tokens per call (hand-off buffer size)");
+            // a stage of a layer split exchanges the residual through hand-off buffers of n_embd * rows floats (rows = n_batch
+            // at first); ggml_view_1d has no bounds check (upstream neither), so the buffers must hold this call's rows
+            if ((!is_first() || !is_last()) && input_len > session.stage_rows())
+                ggml::panic("evaluate: the stage hand-off buffers hold fewer rows than this call (ensure_stage_rows not called)");
             Tensor input_layer = is_first()
                                      ? ctx0.op_get_rows(wte, embd)  // :170
                                      : ctx0.op_reshape_2d(ctx0.op_view_1d(session.stage_in, n_embd * input_len, 0), n_embd,
@@ -504,22 +522,41 @@ struct llm_model {
     llm_ggml_file *file = nullptr;  // mmap'd container the weights point into (llm_llama_load)
     std::vector<llm::Llama *> stages;  // empty: unsplit
     std::vector<int> devices;          // device slot of each stage
+    int device = ggml_hip_get_main_device();  // unsplit: the slot that was current when the model was made (its weights live there)
 };
 struct llm_session {
     llm::InferenceSession *s;
     std::vector<llm::InferenceSession *> stage_sessions;  // parallel to llm_model::stages
     std::vector<int> devices;
+    int device = 0;  // unsplit: the model's slot (K/V, shadows and plans of the session live there)
 };
 
 namespace {
 // Model::evaluate for both kinds of model
+// Every entry point leaves the caller's main device as it found it: an unsplit model runs on the slot it was loaded on
+// (llm_model::device), a split one walks its stages' slots.
+struct HomeDevice {
+    int home = ggml_hip_get_main_device();
+    void go(int d) const {
+        if (ggml_hip_get_main_device() != d) ggml_hip_set_main_device(d);
+    }
+    ~HomeDevice() { go(home); }
+};
 void model_evaluate(llm_model *m, llm_session *s, const std::vector<llm::TokenId> &toks, llm::OutputRequest &req) {
+    HomeDevice hd;
     if (m->stages.empty()) {
+        hd.go(m->device);
+        if (!m->llama->is_first() || !m->llama->is_last())  // one stage of a per-process split (llm_amd/pipeline.py)
+            s->s->ensure_stage_rows(m->llama->hyperparameters.n_embd, toks.size());
         m->llama->evaluate(*s->s, toks, req);
         return;
     }
     const size_t G = m->stages.size();
     const size_t hop_bytes = (size_t)m->llama->hyperparameters.n_embd * toks.size() * sizeof(float);
+    for (size_t i = 0; i < G; i++) {  // a call with more tokens than n_batch: the hand-off buffers grow to it first
+        hd.go(m->devices[i]);
+        s->stage_sessions[i]->ensure_stage_rows(m->llama->hyperparameters.n_embd, toks.size());
+    }
     for (size_t i = 0; i < G; i++) {
         ggml_hip_set_main_device(m->devices[i]);
         llm::InferenceSession &ss = *s->stage_sessions[i];
@@ -585,14 +622,15 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
         fprintf(stderr, "llm_llama_new: use_gpu=0 requested, but libggml_hip has no CPU compute path\n");
         abort();
     }
-    // Layer split inside this process: more than one device slot with a positive share in ggml_hip_set_tensor_split
-    // (the reference's hook for a split, crates/ggml/sys/src/cuda.rs:11), or GGML_HIP_LAYER_SPLIT=G for equal shares.
+    // Layer split inside this process: more than one device slot with a positive share in ggml_hip_set_layer_split (the
+    // explicit-length sibling of the reference's split hook, crates/ggml/sys/src/cuda.rs:11, which itself carries ONE float:
+    // accelerator/mod.rs:74-75), or GGML_HIP_LAYER_SPLIT=G for equal shares.
     // A caller that passes its own layer range (one process per GPU, llm_amd/pipeline.py) is left alone.
     std::vector<int> slots;     // the device slots that take part, in order
     std::vector<float> shares;  // their fractions (all zero = equal)
     {
         float split[16] = {0};
-        const int nslot = ggml_hip_get_tensor_split(split, 16);
+        const int nslot = std::min(ggml_hip_get_layer_split(split, 16), ggml_hip_device_count());
         for (int i = 0; i < nslot; i++)
             if (split[i] > 0.0f) {
                 slots.push_back(i);
@@ -649,7 +687,7 @@ int llm_model_stages(const llm_model *m, int *layer_begin, int *layer_end, int *
         if (cap > 0) {
             if (layer_begin) layer_begin[0] = (int)m->llama->params.layer_begin;
             if (layer_end) layer_end[0] = (int)std::min(m->llama->params.layer_end, m->llama->hyperparameters.n_layer);
-            if (device) device[0] = ggml_hip_get_main_device();
+            if (device) device[0] = m->device;
         }
         return 1;
     }
@@ -671,7 +709,11 @@ void llm_model_free(llm_model *m) {
         ggml_hip_set_main_device(home);
         m->llama = nullptr;
     }
-    delete m->llama;
+    if (m->llama) {
+        HomeDevice hd;
+        hd.go(m->device);
+        delete m->llama;
+    }
     if (m->file) llm_ggml_file_close(m->file);
     delete m;
 }
@@ -878,6 +920,9 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
         s->devices = m->devices;
         return s;
     }
+    HomeDevice hd;
+    hd.go(m->device);
+    s->device = m->device;
     s->s = m->llama->start_session(c);
     return s;
 }
@@ -892,7 +937,11 @@ void llm_session_free(llm_session *s) {
         ggml_hip_set_main_device(home);
         s->s = nullptr;
     }
-    delete s->s;
+    if (s->s) {
+        HomeDevice hd;
+        hd.go(s->device);
+        delete s->s;
+    }
     delete s;
 }
 void llm_evaluate(llm_model *m, llm_session *s, const int32_t *tokens, int n, float *all_logits, float *embeddings) {
@@ -1028,6 +1077,8 @@ void llm_session_last_graph_stats(const llm_session *s, int *n_nodes, int *n_lea
 // Device addresses of the layer-split hand-off buffers of a session (NULL when the stage has none): the residual
 // [n_embd * n_tokens] f32 is received into *in_dev before llm_evaluate and is in *out_dev after it.
 void llm_session_stage_buffers(llm_session *s, void **in_dev, void **out_dev, size_t *nbytes) {
+    HomeDevice hd;
+    if (s->stage_sessions.empty()) hd.go(s->device);
     if (in_dev) *in_dev = s->s->stage_in.is_null() ? nullptr : ggml_hip_tensor_device_ptr(s->s->stage_in.ptr());
     if (out_dev) *out_dev = s->s->stage_out.is_null() ? nullptr : ggml_hip_tensor_device_ptr(s->s->stage_out.ptr());
     if (nbytes) *nbytes = !s->s->stage_in.is_null() ? s->s->stage_in.nbytes() : !s->s->stage_out.is_null() ? s->s->stage_out.nbytes() : 0;
@@ -1059,6 +1110,8 @@ size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbyt
     const size_t n = t.nbytes();
     if (!buf) return n;
     if (nbytes > n) nbytes = n;
+    HomeDevice hd;
+    hd.go(s->device);
     if (set)
         ggml_hip_tensor_set(t.ptr(), buf, 0, nbytes);
     else
@@ -1150,6 +1203,8 @@ size_t llm_session_read_node(const llm_session *s, int index, const char *name, 
     }
     if (!t || !ggml_is_contiguous(t)) return 0;
     const size_t n = ggml_nbytes(t);
+    HomeDevice hd;
+    hd.go(s->stage_sessions.empty() ? s->device : s->devices.back());
     if (dst && n <= max_bytes) ggml_hip_tensor_get(t, dst, 0, n);
     return n;
 }
@@ -1162,6 +1217,8 @@ int llm_session_topk(const llm_session *s, int k, const int32_t *extra_ids, int 
     if (!g || g->n_nodes < 1) return -1;
     const ggml_tensor *t = g->nodes[g->n_nodes - 1];
     if (t->type != GGML_TYPE_F32 || (size_t)t->ne[0] != s->s->last_logits.size()) return -1;
+    HomeDevice hd;
+    hd.go(s->stage_sessions.empty() ? s->device : s->devices.back());
     return ggml_hip_topk(t, t->ne[1] - 1, k, extra_ids, n_extra, out_vals, out_ids);
 }
 

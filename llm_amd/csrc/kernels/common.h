@@ -163,3 +163,27 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // f32 -> f16 -> f32 round trip (RNE), the rounding ggml applies wherever it stores fp16.
 __device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+
+// ---- which branch of ggml's activation quantizer (quantize_row_q8_0 / quantize_row_q8_1) the kernels restate ---------
+// The reference builds ggml with -mavx2 -mfma -mf16c on every AVX2 host (crates/ggml/sys/build.rs:46-62), so what its CPU
+// mul_mat runs is upstream's `#elif defined(__AVX2__)` branch:   d = amax / 127 ;  id = amax != 0 ? 127 / amax : 0 ;
+// q = cvtps_epi32(round_ps(x * id, NEAREST))  (round half to EVEN = v_rndne_f32) ; Q8_1's s = d * (float)sum(q).
+// The scalar branch (`*_reference`, non-SIMD hosts) multiplies by id = d != 0 ? 1 / d : 0 and rounds with roundf (half away
+// from zero).  The two differ where x * id sits within an ulp of a rounding edge and on exact ties.  Default = the AVX2
+// branch (0); ggml_hip_set_option("act_quant", 1) / GGML_HIP_ACT_QUANT=scalar selects the scalar one.  Read through the
+// scalar cache once per kernel; a plan captured in a hipGraph follows the option without being re-captured.
+__constant__ int c_act_quant_scalar = 0;
+__device__ __forceinline__ bool aq_scalar() { return c_act_quant_scalar != 0; }
+template <bool SC>
+__device__ __forceinline__ float act_id(float amax, float d) {
+    if constexpr (SC) return d != 0.0f ? 1.0f / d : 0.0f;
+    return amax != 0.0f ? 127.0f / amax : 0.0f;
+}
+template <bool SC>
+__device__ __forceinline__ int act_q(float x) {
+    if constexpr (SC) return (int)roundf(x);
+    return (int)__builtin_rintf(x);  // v_rndne_f32
+}
+// the same with the branch taken at run time (kernels where the quantizer is a few instructions of a long launch)
+__device__ __forceinline__ float act_id(float amax, float d, bool sc) { return sc ? act_id<true>(amax, d) : act_id<false>(amax, d); }
+__device__ __forceinline__ int act_q(float x, bool sc) { return sc ? act_q<true>(x) : act_q<false>(x); }

@@ -162,8 +162,8 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
         float amax = fabsf(v);
         amax = g32_max_f32(amax);
         const float d = amax / 127.0f;
-        const float id = d != 0.0f ? 1.0f / d : 0.0f;
-        const int q = (int)roundf(v * id);
+        const float id = act_id(amax, d, aq_scalar());
+        const int q = act_q(v * id, aq_scalar());
         int sq = q;
         sq = g32_sum_i32(sq);
         (l < 16 ? lo : hi)[b * 16 + (l & 15)] = (int8_t)q;
@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(256) k_quant_row(const float *__restrict__ x, 
     float amax = fabsf(v);
     amax = g32_max_f32(amax);
     const float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int q = (int)roundf(v * id);
+    const float id = act_id(amax, d, aq_scalar());
+    const int q = act_q(v * id, aq_scalar());
     int sq = q;
     sq = g32_sum_i32(sq);
     (l < 16 ? lo : hi)[b * 16 + (l & 15)] = (int8_t)q;
@@ -248,15 +248,14 @@ struct DecMmvqArgs {
 enum { XSRC_Q8 = 0, XSRC_NORM = 1, XSRC_F32 = 2 };
 
 // thread t of the 256 owns elements 4i..4i+3 with i = it*256 + t; a Q8 block = 8 consecutive threads
-template <bool F16_D>
-__device__ __forceinline__ void quant4_to_lds(const f32x4 v, int64_t i4, int64_t nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
-                                              float *s_d, int *s_sum) {
+template <bool F16_D, bool SC>
+__device__ __forceinline__ void quant4_to_lds_t(const f32x4 v, int64_t i4, int64_t nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
+                                                float *s_d, int *s_sum) {
     float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     amax = g8_max_f32(amax);
     const float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int q0 = (int)roundf(v[0] * id), q1 = (int)roundf(v[1] * id), q2 = (int)roundf(v[2] * id),
-              q3 = (int)roundf(v[3] * id);
+    const float id = act_id<SC>(amax, d);
+    const int q0 = act_q<SC>(v[0] * id), q1 = act_q<SC>(v[1] * id), q2 = act_q<SC>(v[2] * id), q3 = act_q<SC>(v[3] * id);
     int sq = (q0 + q1) + (q2 + q3);
     sq = g8_sum_i32(sq);
     const int64_t b = i4 >> 3;  // block index
@@ -268,6 +267,15 @@ __device__ __forceinline__ void quant4_to_lds(const f32x4 v, int64_t i4, int64_t
         s_d[b] = F16_D ? round_f16(d) : d;
         s_sum[b] = sq;
     }
+}
+// the quantizer branch (common.h: act_quant) is wave-uniform: one scalar branch around two straight-line bodies
+template <bool F16_D>
+__device__ __forceinline__ void quant4_to_lds(const f32x4 v, int64_t i4, int64_t nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
+                                              float *s_d, int *s_sum) {
+    if (aq_scalar())
+        quant4_to_lds_t<F16_D, true>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+    else
+        quant4_to_lds_t<F16_D, false>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
 }
 
 template <bool F16_D, int XSRC>
@@ -696,8 +704,8 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
         float amax = fabsf(v);
         amax = g32_max_f32(amax);
         const float d = amax / 127.0f;
-        const float id = d != 0.0f ? 1.0f / d : 0.0f;
-        const int qv = (int)roundf(v * id);
+        const float id = act_id(amax, d, aq_scalar());
+        const int qv = act_q(v * id, aq_scalar());
         int sq = qv;
         sq = g32_sum_i32(sq);
         const int64_t gb = qn * (Eq / 32) + (int64_t)h * nblk + b;

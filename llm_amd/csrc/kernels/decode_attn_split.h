@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(256) k_attn_split_out(const AttnSplitArgs a) {
     float amax = fabsf(v);
     amax = g32_max_f32(amax);
     const float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int qv = (int)roundf(v * id);
+    const float id = act_id(amax, d, aq_scalar());
+    const int qv = act_q(v * id, aq_scalar());
     int sq = qv;
     sq = g32_sum_i32(sq);
     const int64_t gb = (int64_t)h * nblk + b;

@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) k_quant_act_f16(const char *__restrict__ 
     float amax = fabsf(v);
     amax = g32_max_f32(amax);
     float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int q = (int)roundf(v * id);
+    const float id = act_id(amax, d, aq_scalar());
+    const int q = act_q(v * id, aq_scalar());
     if (F16_D) d = round_f16(d);
     float r = d * (float)q;
     r = fminf(fmaxf(r, -65504.0f), 65504.0f);
@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(256) k_quant_act_q8p(const char *__restrict__ 
     float amax = fabsf(v);
     amax = g32_max_f32(amax);
     float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int q = (int)roundf(v * id);
+    const float id = act_id(amax, d, aq_scalar());
+    const int q = act_q(v * id, aq_scalar());
     q8[gblock * 32 + l] = (int8_t)q;
     if (l == 0) dx[gblock] = (_Float16)fminf(F16_D ? round_f16(d) : d, 65504.0f / 127.0f);
 }

@@ -65,8 +65,8 @@ __global__ void __launch_bounds__(256) k_quant_act_i8(const char *__restrict__ x
     float amax = fabsf(v);
     amax = g32_max_f32(amax);
     const float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int q = (int)roundf(v * id);
+    const float id = act_id(amax, d, aq_scalar());
+    const int q = act_q(v * id, aq_scalar());
     int s = q;
     s = g32_sum_i32(s);
     q8[gblock * 32 + l] = (int8_t)q;

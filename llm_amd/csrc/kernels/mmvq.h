@@ -51,7 +51,8 @@ __global__ void k_relayout_q(const uint8_t *__restrict__ raw, int qt, int64_t nb
 // ---------------------------------------------------------------------------------------------
 // activation re-quantization (ggml: quantize_row_q8_0 / quantize_row_q8_1 in the INIT phase of
 // mul_mat, into cplan.work_data).  32 lanes per block, 2 blocks per wave.
-//   d = amax/127 ; id = d ? 1/d : 0 ; q = roundf(x*id) ; sum = Σq
+//   d = amax/127 ; id = 127/amax, q = rne(x*id) (ggml's AVX2 branch, the default) or id = 1/d, q = roundf(x*id) (its scalar
+//   branch): common.h act_quant ; sum = Σq
 // Q8_0 kind stores d after an f16 round trip (block_q8_0.d is fp16); Q8_1 kind keeps d in f32.
 // ---------------------------------------------------------------------------------------------
 template <bool F16_D>
@@ -66,8 +67,8 @@ __global__ void __launch_bounds__(256) k_quantize_act(const char *__restrict__ x
     float amax = fabsf(v);
     amax = g32_max_f32(amax);
     const float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    const int q = (int)roundf(v * id);
+    const float id = act_id(amax, d, aq_scalar());
+    const int q = act_q(v * id, aq_scalar());
     int s = q;
     s = g32_sum_i32(s);
     int8_t *dst = (l < 16 ? lo : hi) + gblock * 16 + (l & 15);

@@ -120,12 +120,13 @@ __device__ __forceinline__ void p_requant4_store(const f32x4 v, int64_t i4 /* in
     float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     amax = g8_max_f32(amax);
     float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    const bool sc = aq_scalar();
+    const float id = act_id(amax, d, sc);
     const float dq = F16_D ? round_f16(d) : d;  // id comes from the unrounded d, as in k_quant_act_f16
     _Float16 h[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int q = (int)roundf(v[k] * id);
+        const int q = act_q(v[k] * id, sc);
         float r = dq * (float)q;
         r = fminf(fmaxf(r, -65504.0f), 65504.0f);
         h[k] = (_Float16)r;

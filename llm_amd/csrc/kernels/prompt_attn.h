@@ -269,9 +269,9 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
                     amax = fh ? fmaxf(r2, r3) : fmaxf(r0, r1);
                 }
                 const float d = amax / 127.0f;
-                const float id = d != 0.0f ? 1.0f / d : 0.0f;
+                const float id = act_id(amax, d, aq_scalar());
                 const float dq = a.f16d ? round_f16(d) : d;
-                const int qv = (int)roundf(v * id);
+                const int qv = act_q(v * id, aq_scalar());
                 float rq = dq * (float)qv;
                 rq = fminf(fmaxf(rq, -65504.0f), 65504.0f);
                 if (q0 + 4 * fh + row < a.N) xp[(int64_t)row * a.E] = (_Float16)rq;

@@ -1262,7 +1262,7 @@ static float vec_dot_simd(int type, int n, const void *vx, const void *vy) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float summs = 0.0f;
     int w[QK];
-    for (int i = 0; i < nb; i++) {
+    BLOCK_LOOP(i, nb) { /* ascending like upstream; descending = the re-association yardstick (orc_set_block_order) */
         switch (type) {
             case T_Q4_0: {
                 const block_q4_0 *x = (const block_q4_0 *)vx;
@@ -1585,7 +1585,8 @@ EXPORT void orc_mul_mat(int type, const void *A, int64_t M, int64_t K, const flo
                     for (int64_t k = 0; k < K; k++) s += (double)(fp16_to_fp32(x[k]) * fp16_to_fp32(y[k]));
                     r = (float)s;
                 } else {
-                    r = intr ? orc_vec_dot_avx2(type, (int)K, a, b) : simd ? vec_dot_simd(type, (int)K, a, b) : orc_vec_dot(type, (int)K, a, b);
+                    /* the intrinsics walk the blocks upwards only: the reversed-order yardstick takes their scalar restatement */
+                    r = intr && !g_rev ? orc_vec_dot_avx2(type, (int)K, a, b) : simd ? vec_dot_simd(type, (int)K, a, b) : orc_vec_dot(type, (int)K, a, b);
                 }
                 dst[n * M + m] = r;
             }
@@ -1795,6 +1796,9 @@ typedef struct {
     float *layer0_kq;   /* KQ_soft_max, layer 0 [P+N, N, H] */
     float *layer0_out;  /* layer 0 output residual [E,N] */
     float *final_norm;  /* embedding_result [E,N] */
+    float *layer_out_all; /* output residual of EVERY layer [L][N][E]: layer il's input is inpL0 (il = 0) or slab il-1 —
+                             the inputs and expected outputs of a teacher-forced per-layer check */
+    const float *inp_override; /* if set: replaces get_rows' output [E,N] (a layer fed with a given residual) */
 } orc_taps;
 
 EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int n_past, float *logits /* [V,N] */,
@@ -1819,6 +1823,7 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
     for (int n = 0; n < N; n++)
         orc_dequantize_row(m->wtype, (const uint8_t *)m->tok_embeddings + (size_t)tokens[n] * erow, inpL + (size_t)n * E,
                            (int)E);
+    if (taps && taps->inp_override) memcpy(inpL, taps->inp_override, (size_t)E * N * 4);
     if (taps && taps->inpL0) memcpy(taps->inpL0, inpL, (size_t)E * N * 4);
 
     for (int64_t il = 0; il < L; il++) {
@@ -1934,6 +1939,7 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
         orc_mul_mat(m->wtype, m->w2[il], E, F, t1, N, F, cur, mode);
         orc_add(cur, inpFF, inpL, E * N);
         if (il == 0 && taps && taps->layer0_out) memcpy(taps->layer0_out, inpL, (size_t)E * N * 4);
+        if (taps && taps->layer_out_all) memcpy(taps->layer_out_all + (size_t)il * E * N, inpL, (size_t)E * N * 4);
     }
     /* final norm + lm_head (:343-352) */
     orc_rms_norm(inpL, cur, E, N, m->rms_eps);

@@ -133,6 +133,14 @@ def have_avx2():
     return bool(lib().orc_have_avx2())
 
 
+def ref_mode():
+    """The mode that restates what the reference's build EXECUTES on an x86-64 host: crates/ggml/sys/build.rs:46-62 passes
+    -mavx2 -mfma -mf16c, so ggml's `#elif defined(__AVX2__)` branches run — mode 3 (the intrinsics) where this host has them,
+    else mode 2 (the same arithmetic order in scalar code; bit-identical, tests/test_oracle.py).  The device's default
+    activation quantizer (option act_quant = 0) follows this branch; the parity tests compare with this mode."""
+    return MODE_AVX2_INTRINSICS if have_avx2() else MODE_AVX2
+
+
 def dequantize(t, raw, n):
     raw = np.ascontiguousarray(raw, dtype=np.uint8)
     y = np.zeros(n, dtype=np.float32)
@@ -212,7 +220,8 @@ class _LlamaC(C.Structure):
 
 class _Taps(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("inpL0", "layer0_attn_norm", "layer0_q", "layer0_kq", "layer0_out", "final_norm")]
+                ("inpL0", "layer0_attn_norm", "layer0_q", "layer0_kq", "layer0_out", "final_norm", "layer_out_all",
+                 "inp_override")]
 
 
 class Llama:
@@ -257,17 +266,18 @@ class Llama:
         m.memory_v = self.memory_v.ctypes.data
         self._m = m
 
-    def evaluate(self, tokens, mode=0, taps=False, reverse_blocks=False):
+    def evaluate(self, tokens, mode=0, taps=False, reverse_blocks=False, inp=None):
         """Feeds `tokens` at the current n_past; returns logits f32 [N, n_vocab] (+ taps dict).
         reverse_blocks: add each row's block terms in descending order (a legal re-association of ggml's f32
-        block sum; the fwd-vs-rev distance is the yardstick for a model's own rounding sensitivity)."""
+        block sum; the fwd-vs-rev distance is the yardstick for a model's own rounding sensitivity).
+        inp: f32 [N, n_embd] that replaces the token embeddings (a layer stack fed with a given residual)."""
         lib().orc_set_block_order(1 if reverse_blocks else 0)
         try:
-            return self._evaluate(tokens, mode, taps)
+            return self._evaluate(tokens, mode, taps, inp)
         finally:
             lib().orc_set_block_order(0)
 
-    def _evaluate(self, tokens, mode, taps):
+    def _evaluate(self, tokens, mode, taps, inp=None):
         hp = self.hp
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
         N = tokens.size
@@ -280,10 +290,16 @@ class Llama:
             tap_arrays = {"inpL0": np.zeros((N, E), np.float32), "layer0_attn_norm": np.zeros((N, E), np.float32),
                           "layer0_q": np.zeros((N, H, E // H), np.float32),
                           "layer0_kq": np.zeros((H, N, T), np.float32), "layer0_out": np.zeros((N, E), np.float32),
-                          "final_norm": np.zeros((N, E), np.float32)}
+                          "final_norm": np.zeros((N, E), np.float32),
+                          "layer_out_all": np.zeros((hp["n_layer"], N, E), np.float32)}
             t = _Taps()
             for k, a in tap_arrays.items():
                 setattr(t, k, a.ctypes.data)
+        if inp is not None:
+            inp = np.ascontiguousarray(inp, dtype=np.float32).reshape(N, E)
+            if t is None:
+                t = _Taps()
+            t.inp_override = inp.ctypes.data
         lib().orc_llama_eval(C.byref(self._m), _p(tokens), N, self.n_past, _p(logits), mode,
                              C.byref(t) if t is not None else None)
         self.n_past += N
@@ -320,7 +336,7 @@ class Gpt2:
         wte = w["model/wte"]
         x = np.stack([dequantize(t, wte[int(tok) * rb:(int(tok) + 1) * rb], E) for tok in tokens])
         x = x + w["model/wpe"][P:T]  # :166-169
-        f16r = (lambda a: a.astype(np.float16).astype(np.float32)) if mode == 0 else (lambda a: a)
+        f16r = (lambda a: a.astype(np.float16).astype(np.float32)) if mode != MODE_MATH else (lambda a: a)
         for il in range(L):
             pre = f"model/h{il}/"
             cur = self._ln(x, pre + "ln_1/g", pre + "ln_1/b")  # :178-183

@@ -322,6 +322,38 @@ def test_layer_split_arithmetic_of_the_tensor_split_hook(G):
         assert b[0] == 0 and b[-1] == n_layer and all(y > x for x, y in zip(b, b[1:])), (n_layer, fr, b)
 
 
+def test_tensor_split_hook_reads_exactly_one_float(G):
+    """The reference hands ggml_cuda_set_tensor_split the address of ONE stack f32 (crates/ggml/src/accelerator/mod.rs:74-75).
+    Whatever follows it in memory must not be read, let alone become a layer split — also with 8 device slots addressable
+    (the hook used to read one float per slot).  A split over several slots has its own explicit-length entry point."""
+    import os
+    L = G.lib()
+    os.environ["GGML_HIP_VIRTUAL_DEVICES"] = "8"
+    try:
+        for name in ("ggml_hip_set_tensor_split", "ggml_cuda_set_tensor_split"):
+            stack = (C.c_float * 16)(*([1.0] + [777.0] * 15))  # the one float, then "stack garbage"
+            getattr(L, name)(C.cast(stack, C.c_void_p))
+            out = (C.c_float * 16)(*([-1.0] * 16))
+            assert L.ggml_hip_get_tensor_split(out, 16) == 1
+            assert out[0] == 1.0 and all(out[i] == 0.0 for i in range(1, 16)), list(out)
+            assert L.ggml_hip_get_layer_split(out, 16) == 0  # no split came out of the hook
+        L.ggml_hip_set_tensor_split(None)
+        assert L.ggml_hip_get_tensor_split(out, 16) == 1 and out[0] == 0.0
+        # the explicit-length sibling: exactly n fractions, capped at 16, cleared by (NULL, 0)
+        fr = (C.c_float * 3)(0.2, 0.8, 0.0)
+        L.ggml_hip_set_layer_split(fr, 3)
+        assert L.ggml_hip_get_layer_split(out, 16) == 3 and [round(out[i], 3) for i in range(3)] == [0.2, 0.8, 0.0]
+        L.ggml_hip_set_tensor_split(C.cast(stack, C.c_void_p))   # the reference's call leaves a configured split alone
+        assert L.ggml_hip_get_layer_split(out, 16) == 3
+        L.ggml_hip_set_layer_split(None, 0)
+        assert L.ggml_hip_get_layer_split(out, 16) == 0
+    finally:
+        one = C.c_float(1.0)
+        L.ggml_hip_set_tensor_split(C.byref(one))
+        L.ggml_hip_set_layer_split(None, 0)
+        os.environ.pop("GGML_HIP_VIRTUAL_DEVICES", None)
+
+
 def test_host_greedy_argmax_follows_the_scalar_rule(G):
     """llm_infer_next_token_greedy's sampler (the reference's sampler chain reduced to argmax): the AVX2 version must return
     the index of `best = 0; if (l[i] > l[best]) best = i` — first maximum, NaNs never win, a NaN in front keeps 0, -0.0 == 0.0."""

@@ -60,7 +60,7 @@ def test_c3_gemm_shapes_match_the_oracle_on_sampled_rows(G, O, shape):
     rows = np.unique(rows)
     rb = O.row_bytes(Q4_0, K)
     sub = np.concatenate([W_raw[r * rb:(r + 1) * rb] for r in rows])
-    exact = O.mul_mat(Q4_0, sub, len(rows), K, X, mode=0)
+    exact = O.mul_mat(Q4_0, sub, len(rows), K, X, mode=O.ref_mode())
     Wd = np.stack([O.dequantize(Q4_0, sub[i * rb:(i + 1) * rb], K) for i in range(len(rows))])
     scale = np.abs(X) @ np.abs(Wd).T
     outs = {}
@@ -100,8 +100,8 @@ def test_c3_prefill_512_tokens_two_full_size_layers_match_the_oracle(G, O):
     N, ctx = 512, 1024
     toks = np.random.default_rng(42).integers(0, hp["n_vocab"], N).astype(np.int32)
     orc = O.Llama(hp, w, ctx)
-    ref = orc.evaluate(toks, mode=0)
-    rev = O.Llama(hp, w, ctx).evaluate(toks, mode=0, reverse_blocks=True)
+    ref = orc.evaluate(toks, mode=O.ref_mode())
+    rev = O.Llama(hp, w, ctx).evaluate(toks, mode=O.ref_mode(), reverse_blocks=True)
     mth = O.Llama(hp, w, ctx).evaluate(toks, mode=1)
     std = float(mth.std())
     band, band_rms = float(np.max(np.abs(ref - rev))) / std, float(np.sqrt(np.mean((ref - rev) ** 2))) / std
@@ -156,8 +156,8 @@ def test_c3_decode_full_size_7b_gaussian_at_the_bench_operating_point(G, O):
         tok = np.array([int(np.argmax(sess.last_logits()))], np.int32)
         assert sess.infer_next_token() == int(tok[0])
         got = sess.last_logits()
-        ref = orc.evaluate(tok, mode=0)[-1]
-        rev = orc_r.evaluate(tok, mode=0, reverse_blocks=True)[-1]
+        ref = orc.evaluate(tok, mode=O.ref_mode())[-1]
+        rev = orc_r.evaluate(tok, mode=O.ref_mode(), reverse_blocks=True)[-1]
         mth = orc_m.evaluate(tok, mode=1)[-1]
         std = float(mth.std())
         d = float(np.max(np.abs(got - ref))) / std

@@ -26,8 +26,8 @@ def _run(G, O, hp0, wtype, n_prompt, n_decode, ctx=64):
     worst, n_strict, n = 0.0, 0, 0
     for chunk in (toks[:n_prompt],) + tuple(toks[n_prompt + i:n_prompt + i + 1] for i in range(n_decode)):
         got = sess.evaluate(chunk)
-        ref = orc.evaluate(chunk, mode=0)
-        rev = orc_r.evaluate(chunk, mode=0, reverse_blocks=True)
+        ref = orc.evaluate(chunk, mode=O.ref_mode())
+        rev = orc_r.evaluate(chunk, mode=O.ref_mode(), reverse_blocks=True)
         mth = orc_m.evaluate(chunk, mode=1)
         k, v = sess.get_kv()
         for o in (orc, orc_r, orc_m):

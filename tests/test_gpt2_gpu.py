@@ -25,7 +25,7 @@ def test_gpt2_logits_match_oracle_prompt_and_decode(G, O, wtype):
         orc.memory_k[:] = model.memory_k.device_get(np.float16).reshape(orc.memory_k.shape)  # same K/V state
         orc.memory_v[:] = model.memory_v.device_get(np.float16).reshape(orc.memory_v.shape)
         orc.n_past = model.n_past - len(chunk)
-        ref = orc.evaluate(chunk, mode=0)
+        ref = orc.evaluate(chunk, mode=O.ref_mode())
         d = float(np.max(np.abs(got - ref))) / float(ref.std())
         worst = max(worst, d)
         n += 1

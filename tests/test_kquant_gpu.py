@@ -52,7 +52,7 @@ def test_mul_mat_k_matches_oracle(G, O, wtype, shape, N):
     X = rng.standard_normal((N, K)).astype(np.float32)
     X[:, ::7] *= 4.0
     got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
-    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
+    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=O.ref_mode())
     scale = np.abs(X) @ np.abs(_dequant(O, wtype, W_raw, M, K)).T
     err = np.abs(got - exact)
     assert np.all(err <= 2e-5 * scale + 1e-7), float(np.max(err / (scale + 1e-12)))
@@ -71,7 +71,7 @@ def test_mul_mat_k_on_the_7b_shapes_and_a_prompt_batch(G, O, wtype):
         for N in (1, 40):
             X = rng.standard_normal((N, K)).astype(np.float32)
             got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
-            exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
+            exact = O.mul_mat(wtype, W_raw, M, K, X, mode=O.ref_mode())
             scale = np.abs(X) @ np.abs(_dequant(O, wtype, W_raw, M, K)).T
             err = np.abs(got - exact)
             assert np.all(err <= 2e-5 * scale + 1e-7), (M, K, N, float(np.max(err / (scale + 1e-12))))
@@ -92,7 +92,7 @@ def test_mul_mat_k_edge_blocks(G, O, wtype):
     X[1, 17], X[1, 200] = 1.5, -1.5
     X[2, 300], X[2, 290] = -2.5, 2.5
     got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
-    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
+    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=O.ref_mode())
     scale = np.abs(X) @ np.abs(_dequant(O, wtype, W_raw, M, K)).T
     assert np.all(np.abs(got - exact) <= 2e-5 * scale + 1e-7)
     assert np.all(got[:, 7] == 0.0)
@@ -148,7 +148,7 @@ def test_llama_with_k_quant_weights_matches_oracle(G, O, wtype):
     worst = 0.0
     for lo, hi in ((0, 8), (8, 13), (13, 14), (14, 15), (15, 16), (16, 20)):
         got = sess.evaluate(toks[lo:hi])
-        ref = orc.evaluate(toks[lo:hi], mode=0)
+        ref = orc.evaluate(toks[lo:hi], mode=O.ref_mode())
         std = float(ref.std())
         worst = max(worst, float(np.max(np.abs(got - ref))) / std)
         k, v = sess.get_kv()
@@ -181,7 +181,7 @@ def test_prompt_batch_of_a_k_quant_weight_runs_on_the_f16_gemm(G, O, wtype, shap
     rows = rng.choice(M, 48, replace=False)  # the oracle is a scalar loop
     rb = O.row_bytes(wtype, K)
     sub = np.concatenate([W_raw[m * rb:(m + 1) * rb] for m in rows])
-    exact = O.mul_mat(wtype, sub, len(rows), K, X, mode=0)
+    exact = O.mul_mat(wtype, sub, len(rows), K, X, mode=O.ref_mode())
     scale = np.abs(X) @ np.abs(_dequant(O, wtype, sub, len(rows), K)).T
     err = np.abs(got[:, rows] - exact)
     assert np.all(err <= 1e-3 * scale + 1e-6), float(np.max(err / (scale + 1e-12)))

@@ -83,7 +83,7 @@ def test_one_layer_node_by_node(G, O, wtype, N, P):
         got_v = mv.device_get(np.float16).reshape(E, C)
 
     def mm(name, src, M, K):
-        ref = O.mul_mat(wtype, raw[name], M, K, src.reshape(N, K), mode=0)
+        ref = O.mul_mat(wtype, raw[name], M, K, src.reshape(N, K), mode=O.ref_mode())
         return ref.reshape(-1)
 
     checks = []
@@ -107,7 +107,7 @@ def test_one_layer_node_by_node(G, O, wtype, N, P):
     Kf = got_k[:T].astype(np.float64).reshape(T, H, D)
     Qh = d["Qcur"].reshape(N, H, D).astype(np.float16).astype(np.float64)
     chk("KQ", np.einsum("thd,nhd->hnt", Kf, Qh), 1e-5)
-    chk("KQ_sm", O.scale_mask_softmax(d["KQ"].reshape(H, N, T), float(1.0 / np.sqrt(np.float32(D))), P, mode=0), 1.5e-3)
+    chk("KQ_sm", O.scale_mask_softmax(d["KQ"].reshape(H, N, T), float(1.0 / np.sqrt(np.float32(D))), P, mode=O.ref_mode()), 1.5e-3)
     Vf = got_v[:, :T].astype(np.float64).reshape(H, D, T)
     Ph = d["KQ_sm"].reshape(H, N, T).astype(np.float16).astype(np.float64)
     chk("KQV", np.einsum("hdt,hnt->hnd", Vf, Ph), 1e-5)
@@ -118,7 +118,7 @@ def test_one_layer_node_by_node(G, O, wtype, N, P):
     chk("cur2", d["rms2"].reshape(N, E) * fn, 1e-6)
     chk("t3", mm("w3", d["cur2"], F, E), 1e-5)
     chk("t1", mm("w1", d["cur2"], F, E), 1e-5)
-    chk("silu", O.silu(d["t1"], mode=0), 1.1e-3)
+    chk("silu", O.silu(d["t1"], mode=O.ref_mode()), 1.1e-3)
     chk("gate", d["silu"] * d["t3"], 0)
     chk("w2", mm("w2", d["gate"], E, F), 1e-5)
     chk("out", d["w2"] + d["inpFF"], 0)

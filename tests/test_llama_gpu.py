@@ -56,8 +56,8 @@ def test_logits_match_oracle_prompt_and_decode(G, O, wtype):
         p0 = _stat(G, "plan_tokens")
         for chunk in (toks[:8], toks[8:13]) + tuple(toks[13 + i:14 + i] for i in range(7)):
             got = sess.evaluate(chunk)
-            e0 = orcs[0].evaluate(chunk, mode=0)
-            e0r = orcs[1].evaluate(chunk, mode=0, reverse_blocks=True)
+            e0 = orcs[0].evaluate(chunk, mode=O.ref_mode())
+            e0r = orcs[1].evaluate(chunk, mode=O.ref_mode(), reverse_blocks=True)
             e1 = orcs[2].evaluate(chunk, mode=1)
             std = float(e1.std())
             d0 = float(np.max(np.abs(got - e0))) / std
@@ -108,14 +108,14 @@ def test_prefill_batch_on_mfma_matches_oracle(G, O, wtype, i8):
     _, launches, _ = G.timing_query(G.KCLASS_MMQ_MFMA)
     # integer GEMM: node by node (wq wk wv wo w1 w3 w2 per layer + lm_head); f16 GEMM: the prompt plan (wq|wk|wv, wo, w1|w3, w2)
     assert launches == (7 if i8 else 4) * hp["n_layer"] + 1, launches
-    ref = orc.evaluate(toks[:48], mode=0)
+    ref = orc.evaluate(toks[:48], mode=O.ref_mode())
     std = float(ref.std())
     d = np.abs(got - ref) / std
     print(f"type {wtype} i8 {i8} prefill N=48: max {d.max():.2e} rms {np.sqrt((d ** 2).mean()):.2e}")
     assert d.max() <= TOL_MATH and np.sqrt((d ** 2).mean()) <= (I8_RMS if i8 else 2e-2)
     for i in range(4):
         g1 = sess.evaluate(toks[48 + i:49 + i])
-        r1 = orc.evaluate(toks[48 + i:49 + i], mode=0)
+        r1 = orc.evaluate(toks[48 + i:49 + i], mode=O.ref_mode())
         assert float(np.max(np.abs(g1 - r1))) / std <= TOL_MATH
     sess.free()
     model.free()
@@ -129,7 +129,7 @@ def test_decode_attention_beyond_first_pass(G, O):
     sess = model.start_session(n_batch=64)
     orc = O.Llama(hp, w, 512)
     sess.feed_prompt(toks[:300])
-    orc.evaluate(toks[:300], mode=0)
+    orc.evaluate(toks[:300], mode=O.ref_mode())
     p0 = _stat(G, "plan_tokens")
     worst = 0.0
     for i in range(4):
@@ -137,7 +137,7 @@ def test_decode_attention_beyond_first_pass(G, O):
         orc.memory_k[:] = k
         orc.memory_v[:] = v
         got = sess.evaluate(toks[300 + i:301 + i])
-        ref = orc.evaluate(toks[300 + i:301 + i], mode=0)
+        ref = orc.evaluate(toks[300 + i:301 + i], mode=O.ref_mode())
         worst = max(worst, float(np.max(np.abs(got - ref))) / float(ref.std()))
     assert _stat(G, "plan_tokens") - p0 == 4
     print(f"decode at n_past 300..303: worst gpu-vs-exact {worst:.2e}")
@@ -166,7 +166,7 @@ def test_model_loaded_from_ggjt_file_equals_in_memory_model(G, O, wtype, tmp_pat
         s.free()
         model.free()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
-    ref = O.Llama(hp, w, 64).evaluate(toks[:6], mode=0)
+    ref = O.Llama(hp, w, 64).evaluate(toks[:6], mode=O.ref_mode())
     assert float(np.max(np.abs(outs[1][0] - ref))) / float(ref.std()) <= EDGE
 
 
@@ -222,7 +222,7 @@ def test_multi_token_plan_matches_generic_executor_and_oracle(G, O, wtype):
         p0, g0 = _stat(G, "plan_tokens"), _stat(G, "generic_graphs")
         gen = sg.evaluate(c)
         assert (_stat(G, "plan_tokens") - p0, _stat(G, "generic_graphs") - g0) == (0, 1)
-        ref = orc.evaluate(c, mode=0)
+        ref = orc.evaluate(c, mode=O.ref_mode())
         std = float(ref.std())
         d_pg = float(np.max(np.abs(got - gen))) / std
         d_po = float(np.max(np.abs(got - ref))) / std
@@ -247,7 +247,7 @@ def test_interior_taps_final_norm(G, O):
     orc = O.Llama(hp, w, 64)
     toks = np.array([1, 5, 200, 17], np.int32)
     logits, emb = sess.evaluate(toks, want_embeddings=True)
-    ref_logits, taps = orc.evaluate(toks, mode=0, taps=True)
+    ref_logits, taps = orc.evaluate(toks, mode=O.ref_mode(), taps=True)
     assert np.allclose(emb, taps["final_norm"][-1], rtol=1e-4, atol=1e-5)
     sess.free()
     model.free()
@@ -264,12 +264,12 @@ def test_greedy_is_deterministic_and_matches_oracle_tokens(G, O):
         s.free()
     assert runs[0] == runs[1]
     orc = O.Llama(hp, w, 64)
-    lg = orc.evaluate(prompt, mode=0)[-1]
+    lg = orc.evaluate(prompt, mode=O.ref_mode())[-1]
     ref = []
     for _ in range(24):
         t = int(np.argmax(lg))
         ref.append(t)
-        lg = orc.evaluate(np.array([t], np.int32), mode=0)[-1]
+        lg = orc.evaluate(np.array([t], np.int32), mode=O.ref_mode())[-1]
     # greedy chains may legitimately fork at a near-tie; require a long common prefix and report it
     common = next((i for i, (a, b) in enumerate(zip(runs[0], ref)) if a != b), len(ref))
     print("greedy tokens equal to the oracle for", common, "of", len(ref))
@@ -418,10 +418,10 @@ def test_long_context_split_attention_matches_single_launch_and_oracle(G, O, wty
         s.free()
     G.set_option("attn_split", 1)
     orc = O.Llama(hp, w, 1024)
-    orc.evaluate(toks, mode=0)
+    orc.evaluate(toks, mode=O.ref_mode())
     worst_ab = worst_o = 0.0
     for i, t in enumerate(nxt):
-        ref = orc.evaluate(np.array([t], np.int32), mode=0)[-1]
+        ref = orc.evaluate(np.array([t], np.int32), mode=O.ref_mode())[-1]
         worst_ab = max(worst_ab, float(np.max(np.abs(outs[1][i] - outs[0][i])) / ref.std()))
         worst_o = max(worst_o, float(np.max(np.abs(outs[1][i] - ref)) / ref.std()))
     print("split vs single launch:", worst_ab, " split vs oracle:", worst_o)
@@ -511,8 +511,8 @@ def test_decode_plan_and_hipgraph_replay_match_generic_executor(G, O, wtype):
     print(f"type {wtype}: big-vs-small workgroup decode kernels {d_small:.2e}")
     assert d_small <= EDGE
     orc = O.Llama(hp, w, 64)
-    orc.evaluate(toks[:6], mode=0)
-    ref = np.stack([orc.evaluate(toks[6 + i:7 + i], mode=0)[0] for i in range(8)])
+    orc.evaluate(toks[:6], mode=O.ref_mode())
+    ref = np.stack([orc.evaluate(toks[6 + i:7 + i], mode=O.ref_mode())[0] for i in range(8)])
     d_plan = np.max(np.abs(outs["plan-graph"] - ref)) / std
     d_gen = np.max(np.abs(outs["generic"] - ref)) / std
     d_pg = np.max(np.abs(outs["plan-graph"] - outs["generic"])) / std
@@ -532,8 +532,8 @@ def test_decode_plan_embeddings_and_f32_kv_fallback(G, O):
     logits, emb = s.evaluate(np.array([4], np.int32), want_embeddings=True)
     assert _stat(G, "plan_tokens") == p0 + 1
     orc = O.Llama(hp, w, 64)
-    orc.evaluate(np.array([1, 2, 3], np.int32), mode=0)
-    ref, taps = orc.evaluate(np.array([4], np.int32), mode=0, taps=True)
+    orc.evaluate(np.array([1, 2, 3], np.int32), mode=O.ref_mode())
+    ref, taps = orc.evaluate(np.array([4], np.int32), mode=O.ref_mode(), taps=True)
     assert np.allclose(emb, taps["final_norm"][-1], rtol=1e-4, atol=1e-5)
     assert np.max(np.abs(logits - ref)) <= EDGE * ref.std()
     s.free()
@@ -602,7 +602,7 @@ def test_gqa_prompt_plans_decode_plan_and_mfma_prefill_match_oracle(G, O, wtype)
         chunks = (toks[:8], toks[8:13]) + tuple(toks[13 + i:14 + i] for i in range(5)) + (toks[18:58],)
         for chunk in chunks:
             got = sess.evaluate(chunk)
-            e0 = orc.evaluate(chunk, mode=0)
+            e0 = orc.evaluate(chunk, mode=O.ref_mode())
             e1 = orc_m.evaluate(chunk, mode=1)
             std = float(e1.std())
             d0 = float(np.max(np.abs(got - e0))) / std
@@ -633,14 +633,14 @@ def test_gqa_split_attention_and_layer_split(G, O):
     s = model.start_session(n_batch=8)
     s.feed_prompt(toks)
     orc = O.Llama(hp, w, 1024)
-    orc.evaluate(toks, mode=0)
+    orc.evaluate(toks, mode=O.ref_mode())
     before = _stat(G, "attn_split_tokens")
     for t in nxt:
         k, v = s.get_kv()
         orc.memory_k[:] = k[:orc.memory_k.size]
         orc.memory_v[:] = v[:orc.memory_v.size]
         got = s.evaluate(np.array([t], np.int32))[-1]
-        ref = orc.evaluate(np.array([t], np.int32), mode=0)[-1]
+        ref = orc.evaluate(np.array([t], np.int32), mode=O.ref_mode())[-1]
         assert float(np.max(np.abs(got - ref)) / ref.std()) <= EDGE
     assert _stat(G, "attn_split_tokens") - before == len(nxt)
     s.free()
@@ -681,11 +681,11 @@ def test_decode_plan_with_a_16k_context_needs_more_than_64k_of_lds(G, O):
         sess.feed_prompt(toks[:8])
         assert (_stat(G, "plan_tokens") - c0 == 8) == chunk_on_plan, ctx
         on_plan = True
-        orc.evaluate(toks[:8], mode=0)
+        orc.evaluate(toks[:8], mode=O.ref_mode())
         p0 = _stat(G, "plan_tokens")
         for i in range(4):
             got = sess.evaluate(toks[8 + i:9 + i])[-1]
-            ref = orc.evaluate(toks[8 + i:9 + i], mode=0)[-1]
+            ref = orc.evaluate(toks[8 + i:9 + i], mode=O.ref_mode())[-1]
             assert float(np.max(np.abs(got - ref)) / ref.std()) <= EDGE, (ctx, i)
         assert (_stat(G, "plan_tokens") - p0 == 4) == on_plan, ctx
         sess.free()

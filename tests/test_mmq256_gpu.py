@@ -61,7 +61,7 @@ def test_mmq256_bit_identical_to_the_128_tile_kernel_and_close_to_the_oracle(G, 
     rows = np.unique(np.concatenate([[0, M - 1], rng.choice(M, min(M, 96), replace=False)]))
     rb = O.row_bytes(wtype, K)
     sub = np.concatenate([W_raw[r * rb:(r + 1) * rb] for r in rows])
-    exact = O.mul_mat(wtype, sub, len(rows), K, X, mode=0)
+    exact = O.mul_mat(wtype, sub, len(rows), K, X, mode=O.ref_mode())
     Wd = np.stack([O.dequantize(wtype, sub[i * rb:(i + 1) * rb], K) for i in range(len(rows))])
     scale = np.abs(X) @ np.abs(Wd).T
     err = np.abs(outs["t256"][:, rows] - exact)

@@ -44,7 +44,7 @@ def test_cols_mat_mul_matches_the_oracle_at_op_level(G, O, wtype, shape, N):
     rows = np.arange(M) if M <= 512 else np.sort(rng.choice(M, 256, replace=False))
     rb = O.row_bytes(wtype, K)
     sub = np.concatenate([W_raw[m * rb:(m + 1) * rb] for m in rows])
-    exact = O.mul_mat(wtype, sub, len(rows), K, X, mode=0)
+    exact = O.mul_mat(wtype, sub, len(rows), K, X, mode=O.ref_mode())
     D = np.stack([O.dequantize(wtype, sub[i * rb:(i + 1) * rb], K) for i in range(len(rows))])
     scale = np.abs(X) @ np.abs(D).T
     err = np.abs(got[:, rows] - exact)
@@ -85,7 +85,7 @@ def test_cols_kernel_matches_big8_and_the_oracle(G, O, wtype, cfg):
                 G.set_option("mmq_cols", 1)
         orc = O.Llama(hp, w, 64)
         for c, a, b in zip(chunks, outs[1], outs[0]):
-            ref = orc.evaluate(c, mode=0)
+            ref = orc.evaluate(c, mode=O.ref_mode())
             std = float(ref.std())
             d_ab = float(np.max(np.abs(a - b))) / std
             d_ref = float(np.max(np.abs(a - ref))) / std

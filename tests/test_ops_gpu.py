@@ -46,7 +46,7 @@ def test_mul_mat_q_matches_oracle_exact(G, O, wtype, shape, N):
     W_raw = G.quantize(wtype, W)
     assert (W_raw == O.quantize(wtype, W)).all()
     got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
-    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
+    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=O.ref_mode())
     math = O.mul_mat(wtype, W_raw, M, K, X, mode=1)
     scale = _abs_scale(O, wtype, W_raw, M, K, X)
     # vs ggml-exact semantics: f32 summation-order noise only
@@ -77,7 +77,7 @@ def test_mul_mat_q_prefill_mfma_matches_oracle(G, O, wtype, shape, N, i8):
         got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
     finally:
         G.set_option("mmq_i8", 0)
-    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
+    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=O.ref_mode())
     scale = _abs_scale(O, wtype, W_raw, M, K, X)
     err = np.abs(got - exact)
     if i8 and (K // 32) % 2 == 0:
@@ -117,7 +117,7 @@ def test_mul_mat_q_prefill_mfma_is_used_and_handles_extremes(G, O):
     assert launches == 1 and flops == 2.0 * M * N * K and ms > 0
     assert np.all(got[3] == 0.0) and np.all(got[:, 5] == 0.0)
     assert np.isfinite(got).all()
-    exact = O.mul_mat(2, W_raw, M, K, X, mode=0)
+    exact = O.mul_mat(2, W_raw, M, K, X, mode=O.ref_mode())
     assert np.allclose(got, exact, rtol=2e-5, atol=2e-5 * float(np.abs(exact).max()))
     G.lib().ggml_hip_timing_begin()
     got16 = _mul_mat_gpu(G, 2, W_raw, M, K, X)
@@ -156,7 +156,7 @@ def test_mul_mat_q_edge_blocks(G, O, wtype):
     X[1, 17] = 1e4
     W_raw = G.quantize(wtype, W)
     got = _mul_mat_gpu(G, wtype, W_raw, M, K, X)
-    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=0)
+    exact = O.mul_mat(wtype, W_raw, M, K, X, mode=O.ref_mode())
     assert np.all(got[0] == 0.0) and np.all(got[:, 3] == 0.0)
     assert np.allclose(got, exact, rtol=1e-4, atol=1e-4)
 
@@ -226,7 +226,7 @@ def test_scale_mask_softmax(G, O, fuse, n_past, N):
         ctx.graph().build_forward_expand(y).compute()
         got = y.read_data().reshape(H, N, T)
     G.lib().ggml_hip_set_option(b"fuse", 1)
-    ref = O.scale_mask_softmax(x, float(scale), n_past, mode=0)
+    ref = O.scale_mask_softmax(x, float(scale), n_past, mode=O.ref_mode())
     # exp goes through f16 on both sides; device expf vs glibc expf may land on the other side of an f16
     # rounding boundary for a few elements: one f16 ulp (2^-11 relative) on those, renormalised.
     assert np.allclose(got, ref, rtol=1.5e-3, atol=1e-7), np.max(np.abs(got - ref))
@@ -251,7 +251,7 @@ def test_silu_mul(G, O, fuse):
         ctx.graph().build_forward_expand(y).compute()
         got = y.read_data()
     G.lib().ggml_hip_set_option(b"fuse", 1)
-    ref = O.silu(a, mode=0) * b
+    ref = O.silu(a, mode=O.ref_mode()) * b
     bad = np.abs(got - ref) > 1e-6 * np.abs(ref) + 1e-9
     # identical up to f16-boundary flips of the device expf (<0.1% of elements, each one f16 ulp)
     assert bad.mean() < 2e-3, bad.mean()
@@ -354,7 +354,7 @@ def test_kv_store_and_attention_matmuls(G, O, dims):
     Qf = q.astype(np.float16).astype(np.float32)
     ref_kq = np.einsum("thd,nhd->hnt", Kf.astype(np.float64), Qf.astype(np.float64))
     assert np.allclose(got_kq, ref_kq, rtol=1e-5, atol=1e-4 if D > 32 else 1e-5)
-    pr = O.soft_max(got_kq, mode=0)
+    pr = O.soft_max(got_kq, mode=O.ref_mode())
     Vf = memv[:, :T].astype(np.float64).reshape(H, D, T)
     ref = np.einsum("hdt,hnt->nhd", Vf, pr.astype(np.float16).astype(np.float64)).reshape(N, E)
     assert np.allclose(got_merged, ref, rtol=2e-3, atol=2e-4)

@@ -90,7 +90,7 @@ def test_prompt_plan_matches_the_oracle(G, O):
         p0 = _stat(G, "prompt_plan_tokens")
         got = sess.evaluate(c)
         assert _stat(G, "prompt_plan_tokens") - p0 == len(c)
-        ref = orc.evaluate(c, mode=0)
+        ref = orc.evaluate(c, mode=O.ref_mode())
         std = float(ref.std())
         rms = float(np.sqrt(np.mean((got - ref) ** 2))) / std
         assert rms <= 2e-2, rms

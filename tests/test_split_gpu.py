@@ -1,6 +1,7 @@
 """ONE InferenceSession over several device slots of one process: the ggml-style layer split behind the C ABI (SURVEY.md
 section 8e; the reference's hooks are ggml_cuda_set_tensor_split / ggml_cuda_set_main_device, crates/ggml/sys/src/cuda.rs:11,
-:62, driven from crates/ggml/src/accelerator/mod.rs:68-77).  A 1-GPU box has one device, so the slots are made virtual
+:62, driven from crates/ggml/src/accelerator/mod.rs:68-77; the reference's split hook carries ONE float, so a split over
+several slots is asked for through its explicit-length sibling ggml_hip_set_layer_split or GGML_HIP_LAYER_SPLIT).  A 1-GPU box has one device, so the slots are made virtual
 (GGML_HIP_VIRTUAL_DEVICES: several slots — own stream, arena shadows, weight records, plan cache each — on the same GPU);
 the residual then crosses between slots with a device copy instead of a peer copy over xGMI, everything else is the code a
 multi-GPU node runs.  The split session must reproduce the unsplit one BIT FOR BIT: same kernels, same order, and the hop
@@ -49,7 +50,7 @@ def test_layer_split_over_device_slots_reproduces_the_unsplit_session(G, how):
             want = [(0, 2, 0), (2, 3, 1), (3, 5, 2)]
         else:
             fr = (np.array([0.2, 0.8, 0.0], np.float32))  # ggml's fractions: slot 0 takes 20 %, slot 1 the rest, slot 2 nothing
-            G.lib().ggml_hip_set_tensor_split(fr.ctypes.data)
+            G.lib().ggml_hip_set_layer_split(fr.ctypes.data, 3)
             want = None
         split = llama.Llama(hp, w, context_size=96)
         st = split.stages()
@@ -62,8 +63,7 @@ def test_layer_split_over_device_slots_reproduces_the_unsplit_session(G, how):
         split.free()
     finally:
         os.environ.pop("GGML_HIP_LAYER_SPLIT", None)
-        one = np.array([1.0] + [0.0] * 15, np.float32)
-        G.lib().ggml_hip_set_tensor_split(one.ctypes.data)
+        G.lib().ggml_hip_set_layer_split(None, 0)
         G.lib().ggml_hip_set_main_device(0)
         os.environ.pop("GGML_HIP_VIRTUAL_DEVICES", None)
     for a, b in zip(ref[0], got[0]):
