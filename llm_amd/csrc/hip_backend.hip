@@ -46,6 +46,7 @@
 #include "kernels/ops.h"
 #include "kernels/decode.h"
 #include "kernels/decode_big.h"
+#include "kernels/decode_fused.h"
 #include "kernels/decode_big8.h"
 #include "kernels/mmq_cols.h"
 #include "kernels/decode_attn_split.h"
@@ -732,6 +733,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
     else if (k == "plan_multi") {
         if (g.opt_plan_multi != value) drop_all_plans();
         g.opt_plan_multi = value;
+    }
+    else if (k == "fuse_attn") {
+        if (g.opt_fuse_attn != value) drop_all_plans();
+        g.opt_fuse_attn = value;
     }
     else if (k == "big") {
         if (g.opt_big != value) drop_all_plans();

@@ -164,6 +164,18 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // f32 -> f16 -> f32 round trip (RNE), the rounding ggml applies wherever it stores fp16.
 __device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
 
+// ---- 8-byte granules: a 32-bit value handed to other workgroups of the SAME launch, tagged with the launch's epoch ---------
+// One naturally aligned 8-byte agent-scope store {tag, value} (global_store_dwordx2 sc1: write-through) on the producer, 8-byte
+// agent-scope loads on the consumer until the tag matches: the data is the flag, no fence, no counter, nothing to drain
+// (cdna_hip_programming.md Guideline 16, form R2).  Global address space on both sides, never flat, never a plain store.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ void gran_store(unsigned long long *g_, unsigned epoch, unsigned value) {
+    __hip_atomic_store((gu64 *)g_, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long gran_load(const unsigned long long *g_) {
+    return __hip_atomic_load((gu64 *)g_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- which branch of ggml's activation quantizer (quantize_row_q8_0 / quantize_row_q8_1) the kernels restate ---------
 // The reference builds ggml with -mavx2 -mfma -mf16c on every AVX2 host (crates/ggml/sys/build.rs:46-62), so what its CPU
 // mul_mat runs is upstream's `#elif defined(__AVX2__)` branch:   d = amax / 127 ;  id = amax != 0 ? 127 / amax : 0 ;

@@ -73,9 +73,16 @@ __global__ void __launch_bounds__(1024) k_argmax_next(const float *__restrict__ 
 // theta_kk = freq_scale*p * theta_scale^kk by repeated f32 multiplication (reference ggml.c rope, f32 branch).  One
 // launch per token; the wq|wk|wv mat-vec of every layer reads the table instead of re-deriving it (64 dependent
 // multiplies + sincos on two waves held up the whole workgroup's first barrier by ~2.5 us per layer).
+// Block 0 also opens the token's epoch (`epoch`, nullable): the tag of the granules that k_qkv_attn's mat-vec workgroups hand
+// to its attention workgroups (kernels/decode_fused.h) — bumped on the device, once per token, so that a replayed hipGraph
+// never meets its own previous granules as current; 0 is skipped (a zeroed granule is never valid).
 __global__ void __launch_bounds__(128) k_rope_table(const DecParams *__restrict__ prm, float theta_scale, float freq_scale,
-                                                    int half_d, float *__restrict__ out) {
+                                                    int half_d, float *__restrict__ out, unsigned *epoch = nullptr) {
     const int kk = threadIdx.x, c = blockIdx.x;  // block c: token c of a prompt chunk (position n_past + c), 128 floats each
+    if (epoch && kk == 0 && c == 0) {
+        const unsigned e = *epoch + 1u;
+        *epoch = e ? e : 1u;
+    }
     if (kk >= half_d) return;
     float theta = freq_scale * (float)(prm->n_past + c);
     for (int t = 0; t < kk; t++) theta *= theta_scale;

@@ -74,6 +74,12 @@ struct BigArgs {
     int probe;          // measurement only (ggml_hip_set_option("probe", n), tests/tools/launch_probe.py): 1 = return before
                         // the first weight request, 2 = return once x is staged and the ring requested, 3 = no epilogue stores, 4 = every
                         // other step's dots skipped, 5 = no wave reductions; 0 = normal
+    // EPI_QKV inside k_qkv_attn (kernels/decode_fused.h): the epilogue also PUBLISHES every row pair to the attention workgroups
+    // of the same launch, as one 8-byte {tag = epoch, two f16} granule per pair (index = the pair's index over wq|wk|wv); Q is
+    // not stored as f32 then (nothing else reads it).  nullptr = plain launch.
+    unsigned long long *gran;
+    const unsigned *epoch;  // device word, bumped once per token by k_rope_table: this token's tag
+    int wdeal;              // waves of a workgroup that take units (0 = all of blockDim); the rest only help staging
 };
 __device__ __forceinline__ long long big_now() { return (long long)wall_clock64(); }  // 100 MHz, chip-wide
 
@@ -201,8 +207,10 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
 
 // INSTR: the measurement build (BigArgs::probe early exits, BigArgs::ts timeline stamps), launched only while option
 // "probe" or "timeline" is set; the production instantiation (INSTR = false) carries none of those branches.
-template <int QT, int EPI, int XSRC, bool INSTR = false>
-__global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
+// `bid` of `G` workgroups run the launch (blockIdx.x / gridDim.x for k_mmvq_big itself; the producer workgroups of
+// k_qkv_attn pass their index among the producers).
+template <int QT, int EPI, int XSRC, bool INSTR>
+__device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const int G) {
     const DecMmvqArgs &a = ba.d;
     const int probe = INSTR ? ba.probe : 0;
     long long *const ts = INSTR ? ba.ts : nullptr;
@@ -223,7 +231,8 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     float *s_d = (float *)(s_hi + nbp);
     int *s_sum = (int *)(s_d + nbp);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int T = (int)blockDim.x, W = T >> 6;  // waves per workgroup: chosen per launch (launch_big)
+    const int T = (int)blockDim.x;
+    const int W = ba.wdeal > 0 ? ba.wdeal : T >> 6;  // waves per workgroup that take units: chosen per launch (launch_big)
     // wave-uniform values must be uniform FOR THE COMPILER too (scalar registers, scalar selects of the matrix
     // pointers): a kernarg array indexed by a "divergent" segment id is fetched with vector loads, and waiting for
     // those drains the whole in-order load queue at every step
@@ -232,7 +241,11 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     const long long t_entry = ts ? big_now() : 0;
     // ---- 1. the activation's loads go first (see BigX); so does the position (needed by the QKV epilogue only)
     int n_past = 0;
-    if constexpr (EPI == EPI_QKV) n_past = a.prm->n_past;
+    unsigned epoch = 0;
+    if constexpr (EPI == EPI_QKV) {
+        n_past = a.prm->n_past;
+        if (ba.gran) epoch = *ba.epoch;
+    }
     BigX<XSRC> xr;
     xr.load(ba, nb, tid, T);
     // EPI_QKV: the last two waves fetch the token's RoPE table (k_rope_table); every wave issues the load so that all
@@ -247,14 +260,10 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
     // contiguous window of G*16 units of the matrix.  Lane i of the wave owns unit i's epilogue.
     const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0, M2 = EPI == EPI_QKV ? (int)a.w[2].M : 0;
     const int Utot = (M0 + M1 + M2) / RU;
-#ifdef BIG_DEAL_WG_MAJOR
-    const int u_first = (int)blockIdx.x * W + wave, u_stride = (int)gridDim.x * W;
-#else
     // wave-major within a round: the units of the last, partial round go to waves 0..k of EVERY workgroup, so all CUs
     // stream the same number of rows (11008 w1|w3 rows: 43 per CU instead of 45 on 222 CUs and 30 on 34)
-    const int u_first = wave * (int)gridDim.x + (int)blockIdx.x, u_stride = (int)gridDim.x * W;
-#endif
-    const int nu = u_first < Utot ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
+    const int u_first = wave * G + bid, u_stride = G * W;
+    const int nu = (wave < W && u_first < Utot) ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
     const int S = nu * nbl;
     // EPI_ADD: lane i preloads the residual of unit i (a load issued in the epilogue would drain the queue)
     float res_pre = 0.0f;
@@ -431,29 +440,44 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
             a.dst[m0] = silu_table(myv[0]) * myv[1];
         } else {  // EPI_QKV, see k_mmvq_dec
             const int p = n_past;
+            __half h0, h1;  // the pair as f16: what the K/V cache holds, and what ggml's F16 mat-mul makes of Q (src1 -> f16)
             if (sg == 2) {
-                a.mem_v[(int64_t)m0 * a.C + p] = __float2half_rn(myv[0]);
-                a.mem_v[(int64_t)(m0 + 1) * a.C + p] = __float2half_rn(myv[1]);
+                h0 = __float2half_rn(myv[0]);
+                h1 = __float2half_rn(myv[1]);
+                a.mem_v[(int64_t)m0 * a.C + p] = h0;
+                a.mem_v[(int64_t)(m0 + 1) * a.C + p] = h1;
             } else {
                 const int kk = (m0 % a.D) >> 1;
                 const float c = s_rope[2 * kk], sn = s_rope[2 * kk + 1];
                 const float r0 = myv[0] * c - myv[1] * sn, r1 = myv[0] * sn + myv[1] * c;
+                h0 = __float2half_rn(r0);
+                h1 = __float2half_rn(r1);
                 if (sg == 0) {
-                    a.dst[m0] = r0;
-                    a.dst[m0 + 1] = r1;
+                    if (!ba.gran) {
+                        a.dst[m0] = r0;
+                        a.dst[m0 + 1] = r1;
+                    }
                 } else {
-                    a.mem_k[(int64_t)p * a.Egqa + m0] = __float2half_rn(r0);
-                    a.mem_k[(int64_t)p * a.Egqa + m0 + 1] = __float2half_rn(r1);
+                    a.mem_k[(int64_t)p * a.Egqa + m0] = h0;
+                    a.mem_k[(int64_t)p * a.Egqa + m0 + 1] = h1;
                 }
+            }
+            if (ba.gran) {  // one aligned 8-byte agent-scope (write-through) store: the data is the flag
+                const unsigned v2 = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
+                gran_store(ba.gran + (u_first + u_stride * lane), epoch, v2);
             }
         }
     }
     if (ts && wave == 0 && lane == 0) {
-        const int q = (int)gridDim.x / ba.ts_wgs;
-        if (q > 0 && blockIdx.x % q == 0 && (int)blockIdx.x / q < ba.ts_wgs) {
-            long long *o = ts + ((int)blockIdx.x / q) * 8;
+        const int q = G / ba.ts_wgs;
+        if (q > 0 && bid % q == 0 && bid / q < ba.ts_wgs) {
+            long long *o = ts + (bid / q) * 8;
             o[0] = t_entry; o[1] = t_issued; o[2] = t_staged; o[3] = t_barrier; o[4] = t_first; o[5] = big_now();
-            o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = blockIdx.x;
+            o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = bid;
         }
     }
+}
+template <int QT, int EPI, int XSRC, bool INSTR = false>
+__global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
+    big_body<QT, EPI, XSRC, INSTR>(ba, (int)blockIdx.x, (int)gridDim.x);
 }

@@ -1,0 +1,244 @@
+// decode_fused.h — wq|wk|wv and the attention of a decode token in ONE launch (k_qkv_attn).
+//
+// The two launches it replaces are a dependent pair: k_mmvq_big<EPI_QKV> streams 28 MB on all CUs, then k_attn_decode runs a
+// latency chain on n_head CUs with HBM idle — its K/V round trip, a kernel boundary and a cold start for ~100 KB of work per
+// head (7.3-8.4 us of a 39 us layer at 7B).  Here the n_head attention workgroups are part of the mat-vec's launch:
+//   * workgroups 0 .. n_head-1 (dispatched first): one head each.  They request the first 256 positions of the head's K and V
+//     at kernel entry — that traffic overlaps the weight stream instead of following it — and then wait for the token's own
+//     Q / K / V rows of their head;
+//   * the other G - n_head workgroups run the mat-vec (big_body) over all row pairs, dealt exactly as in k_mmvq_big, and
+//     publish every finished pair as an 8-byte {epoch, f16 x 2} granule besides storing K / V into the cache.  Q travels as
+//     f16 because that is what ggml's F16 mat-mul makes of its src1 (k_attn_decode rounds the f32 Q the same way); the K / V
+//     halves are the very halves the cache gets, so this token's row of the scores / of V.P comes from the granules and the
+//     cache row that is being written concurrently is never read.
+// The hand-off is Guideline 16's form R2 (the data is the flag: one aligned 8-byte agent-scope store per pair, agent-scope
+// polling loads, no fence, no counter); it does not depend on which XCD or in which order workgroups run: producers never
+// wait, consumers wait only for producers, and all G workgroups fit the chip at once (one 1024-thread workgroup per CU).  The
+// tag is a device word bumped once per token (k_rope_table), so a replayed hipGraph never sees its own previous granules as
+// current.  Every spin is bounded (FusedAttnArgs::err is raised, the token's logits are then garbage but nothing hangs).
+// Arithmetic = k_attn_decode's, hence ggml's: f32 dot of f16 K with f16 Q, scale, row max, f16-rounded exp of the f16-rounded
+// difference, f64 sum, f16 probabilities, f32 V.P, Q8 re-quantization for wo.
+#pragma once
+#include "decode_big.h"
+
+struct FusedAttnArgs {
+    const __half *mem_k, *mem_v;  // + layer offset, layouts of DecMmvqArgs
+    const DecParams *prm;
+    const unsigned *epoch;
+    const unsigned long long *gran;  // this layer's granules: one per row pair of wq|wk|wv
+    int k_pair0, v_pair0;            // index of the first K / V pair (= rows of wq / 2, rows of wq|wk / 2)
+    float scale;
+    int D, n_rep, n_head;
+    int64_t Egqa, C, Clds;
+    int8_t *lo, *hi;  // the head's D outputs re-quantized for wo
+    float *dq;
+    int *sumq;
+    long long *ts;  // optional timeline slot (as k_attn_decode)
+    unsigned *err;  // raised when a wait gave up
+};
+
+__device__ __forceinline__ f16x2 u32_as_h2(unsigned u) { return __builtin_bit_cast(f16x2, u); }
+
+template <bool F16_D>
+__device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int h) {
+    const long long t_entry = f.ts ? (long long)wall_clock64() : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t Clds = f.Clds, C = f.C, Egqa = f.Egqa;
+    const int D = f.D;
+    float *s_s = (float *)smem;             // Clds scores
+    float *s_o = s_s + Clds;                // D outputs
+    _Float16 *s_p = (_Float16 *)(s_o + D);  // Clds probabilities as f16
+    __shared__ float s_red[16];
+    __shared__ double s_redd[16];
+    __shared__ __attribute__((aligned(16))) unsigned s_new[3 * 64];  // this token's Q | K | V of the head, f16 pairs (D <= 128)
+    const int hk = h / f.n_rep;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_past = f.prm->n_past;
+    const unsigned epoch = *f.epoch;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- the head's cache, first 256 positions, requested before anything is known (k_attn_decode's speculative pass)
+    const int g = tid >> 4, gl = tid & 15;
+    const int d0 = gl * 8;
+    const bool act = d0 < D;
+    const __half *kbase = f.mem_k + (int64_t)hk * D + d0;
+    f16x8 kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int t = g + 64 * u;
+        kv[u] = zero8;
+        if (act && t < C) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+    }
+    const int cv = wave * 8 + (lane >> 3), pj = (lane & 7) * 8;
+    const bool vact = cv < D;
+    const __half *vbase = f.mem_v + ((int64_t)hk * D + cv) * C + pj;
+    f16x8 vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        vv[u] = zero8;
+        if (vact && 64 * u + pj + 8 <= C) vv[u] = *(const f16x8 *)(vbase + 64 * u);
+    }
+
+    // ---- this token's rows of the head: waves 0 / 1 / 2 sweep the D/2 granules of Q / K / V until every tag is the epoch
+    if (wave < 3) {
+        const int half_d = D >> 1;
+        const int base = wave == 0 ? h * half_d : wave == 1 ? f.k_pair0 + hk * half_d : f.v_pair0 + hk * half_d;
+        const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
+        const long long t0 = (long long)wall_clock64();
+        unsigned long long x;
+        for (;;) {
+            x = gran_load(gp);
+            const bool ok = (unsigned)(x >> 32) == epoch;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((long long)wall_clock64() - t0 > 5000000) {  // 50 ms at 100 MHz: a producer never arrived
+                if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        s_new[wave * 64 + lane] = (unsigned)x;
+    }
+    __syncthreads();
+    const long long t_loaded = f.ts ? (long long)wall_clock64() : 0;
+    f16x2 qh2[4];
+    f16x8 knew = zero8;
+    if (act) {
+        const u32x4 q4 = *(const u32x4 *)(s_new + (d0 >> 1));
+        const u32x4 k4 = *(const u32x4 *)(s_new + 64 + (d0 >> 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            qh2[j] = u32_as_h2(q4[j]);
+            const f16x2 kk = u32_as_h2(k4[j]);
+            knew[2 * j] = kk[0];
+            knew[2 * j + 1] = kk[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) qh2[j] = f16x2{(_Float16)0.0f, (_Float16)0.0f};
+    }
+    const int T = n_past + 1;
+    const int T8 = (T + 7) & ~7;
+
+    // ---- scores ----
+#pragma unroll 1
+    for (int t0 = g; t0 < T; t0 += 256) {
+        if (t0 != g) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 64 * u;
+                kv[u] = zero8;
+                if (act && t < n_past) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + 64 * u;
+            const f16x8 kr = t == n_past ? knew : kv[u];  // the token's own row comes from the granules
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) s = __builtin_amdgcn_fdot2(f16x2{kr[2 * j], kr[2 * j + 1]}, qh2[j], s, false);
+            s = g16_sum_f32(s);
+            if (gl == 0 && t < T) s_s[t] = s * f.scale;
+        }
+    }
+    __syncthreads();
+    const long long t_scores = f.ts ? (long long)wall_clock64() : 0;
+    // ---- softmax (ggml: max, f16-rounded exp of the f16-rounded difference, f64 sum, scale by 1/sum) ----
+    float mx = -INFINITY;
+    for (int t = tid; t < T; t += 1024) mx = fmaxf(mx, s_s[t]);
+    mx = wave_max_f32(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, s_red[i]);
+    double sum = 0.0;
+    for (int t = tid; t < T; t += 1024) {
+        const float e = round_f16(expf(round_f16(s_s[t] - mx)));
+        s_s[t] = e;
+        sum += (double)e;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) s_redd[wave] = sum;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) tot += s_redd[i];
+    const float inv = (float)(1.0 / tot);
+    for (int t = tid; t < T8; t += 1024) s_p[t] = t < T ? (_Float16)(s_s[t] * inv) : (_Float16)0.0f;
+    __syncthreads();
+    const long long t_softmax = f.ts ? (long long)wall_clock64() : 0;
+    // ---- V.P ----
+    {
+        // this token's V of channel cv: element cv of the V granules
+        const unsigned vpair = vact ? s_new[128 + (cv >> 1)] : 0u;
+        const _Float16 vnew = u32_as_h2(vpair)[cv & 1];
+        float acc = 0.0f;
+#pragma unroll 1
+        for (int p0 = 0; p0 < T8; p0 += 256) {
+            if (p0 != 0) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    vv[u] = zero8;
+                    if (vact && p0 + 64 * u + pj < T8) vv[u] = *(const f16x8 *)(vbase + p0 + 64 * u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pos = p0 + 64 * u + pj;
+                if (pos < T8) {
+                    f16x8 vr = vv[u];
+                    const int e = n_past - pos;  // the token's own position inside this 8-chunk?
+#pragma unroll
+                    for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
+                    const f16x8 pp = *(const f16x8 *)(s_p + pos);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc = __builtin_amdgcn_fdot2(f16x2{vr[2 * j], vr[2 * j + 1]}, f16x2{pp[2 * j], pp[2 * j + 1]}, acc, false);
+                }
+            }
+        }
+        acc = g8_sum_f32(acc);
+        if ((lane & 7) == 0 && vact) s_o[cv] = acc;
+    }
+    __syncthreads();
+    const long long t_vp = f.ts ? (long long)wall_clock64() : 0;
+    // ---- the head's D outputs as Q8 blocks for wo ----
+    const int nblk = D / 32, l = tid & 31, b = tid >> 5;
+    if (b < nblk) {
+        const float v = s_o[b * 32 + l];
+        float amax = fabsf(v);
+        amax = g32_max_f32(amax);
+        const float d = amax / 127.0f;
+        const float id = act_id(amax, d, aq_scalar());
+        const int qv = act_q(v * id, aq_scalar());
+        int sq = qv;
+        sq = g32_sum_i32(sq);
+        const int64_t gb = (int64_t)h * nblk + b;
+        (l < 16 ? f.lo : f.hi)[gb * 16 + (l & 15)] = (int8_t)qv;
+        if (l == 0) {
+            f.dq[gb] = F16_D ? round_f16(d) : d;
+            f.sumq[gb] = sq;
+        }
+    }
+    if (f.ts && tid == 0) {
+        const int q4 = f.n_head / 4;
+        if (q4 > 0 && h % q4 == 0 && h / q4 < 4) {
+            long long *o = f.ts + (h / q4) * 8;
+            o[0] = t_entry; o[1] = t_loaded; o[2] = t_scores; o[3] = t_softmax; o[4] = t_vp;
+            o[5] = (long long)wall_clock64(); o[6] = T; o[7] = h;
+        }
+    }
+}
+
+template <int QT, bool INSTR = false>
+__global__ void __launch_bounds__(1024) k_qkv_attn(const BigArgs ba, const FusedAttnArgs fa) {
+    constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
+    const int H = fa.n_head;
+    if ((int)blockIdx.x < H) {
+        attn_consumer<F16_D>(fa, (int)blockIdx.x);
+        return;
+    }
+    big_body<QT, EPI_QKV, XSRC_NORM, INSTR>(ba, (int)blockIdx.x - H, (int)gridDim.x - H);
+}

@@ -1,0 +1,126 @@
+"""wq|wk|wv and the decode attention as ONE launch (k_qkv_attn, llm_amd/csrc/kernels/decode_fused.h; the nodes of
+crates/models/llama/src/lib.rs:191-307 for one token) against the two-launch pair it replaces.
+
+The fused launch performs the pair's operations in the pair's order — Q reaches the attention as the f16 the pair rounds it
+to, this token's K / V rows as the very halves the cache receives — so logits, K/V cache and greedy ids must be BIT-IDENTICAL
+to option fuse_attn = 0, in every mode the plan runs in (hipGraph replay, eager, the device-sampled chain, after a rewind to a
+position whose granules still sit in memory under an older epoch), for MHA and GQA shapes and head sizes 32 / 64 / 128.  The
+hand-off counters must show that the fused launch really ran and that no attention workgroup ever gave up waiting."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "tiny": dict(n_vocab=256, n_embd=128, n_head=4, n_head_kv=4, n_layer=2, n_rot=32, n_ff=352, n_mult=32),
+    "gqa": dict(n_vocab=256, n_embd=256, n_head=8, n_head_kv=2, n_layer=2, n_rot=32, n_ff=352, n_mult=32),
+    "d64": dict(n_vocab=256, n_embd=512, n_head=8, n_head_kv=8, n_layer=3, n_rot=64, n_ff=704, n_mult=32),
+    "d128": dict(n_vocab=512, n_embd=1024, n_head=8, n_head_kv=8, n_layer=2, n_rot=128, n_ff=1408, n_mult=32),
+    "d128gqa": dict(n_vocab=512, n_embd=1024, n_head=8, n_head_kv=4, n_layer=2, n_rot=128, n_ff=1408, n_mult=32),
+}
+
+
+def _stat(G, key):
+    return int(G.lib().ggml_hip_get_stat(key.encode()))
+
+
+def _decode(G, model, toks, n_dec, fuse, rewind=False, device_chain=0):
+    G.set_option("fuse_attn", fuse)
+    sess = model.start_session(n_batch=8)
+    f0, p0 = _stat(G, "fused_attn_tokens"), _stat(G, "plan_tokens")
+    sess.feed_prompt(toks)
+    out = []
+    for _ in range(n_dec):
+        tok = sess.infer_next_token()
+        out.append((tok, sess.last_logits()))
+    if rewind:  # back two positions, decode again: the same positions under a new epoch
+        assert sess.rewind(2) == 0
+        for _ in range(3):
+            tok = sess.infer_next_token()
+            out.append((tok, sess.last_logits()))
+    ids = None
+    if device_chain:
+        ids = sess.infer_tokens_device(device_chain)
+        out.append((int(ids[-1]), sess.last_logits()))
+    k, v = sess.get_kv()
+    n_fused = _stat(G, "fused_attn_tokens") - f0
+    n_plan = _stat(G, "plan_tokens") - p0
+    assert _stat(G, "fused_attn_timeouts") == 0
+    sess.free()
+    return out, k, v, n_fused, n_plan, ids
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+@pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
+def test_fused_launch_equals_the_two_launch_pair(G, wtype, shape):
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(SHAPES[shape], wtype, seed=31)
+    model = llama.Llama(hp, w, context_size=96)
+    toks = np.random.default_rng(8).integers(0, hp["n_vocab"], 13).astype(np.int32)
+    try:
+        ref, k0, v0, nf0, np0, _ = _decode(G, model, toks, 9, 0, rewind=True)
+        got, k1, v1, nf1, np1, _ = _decode(G, model, toks, 9, 2, rewind=True)
+    finally:
+        G.set_option("fuse_attn", 1)
+        model.free()
+    assert nf0 == 0 and nf1 == 12 and np0 == np1  # 9 + 3 decode tokens took the fused launch, none without the option
+    for (ta, la), (tb, lb) in zip(ref, got):
+        assert ta == tb and np.array_equal(la, lb)
+    assert np.array_equal(k0, k1) and np.array_equal(v0, v1)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_fused_launch_eager_graph_and_device_chain(G, graph):
+    """eager launches (option graph = 0: what rocprofv3 traces), hipGraph replay, and the device-sampled greedy chain (the
+    epoch advances on the device there, not on the host): the same tokens and logits as the two-launch pair."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(SHAPES["d64"], 2, seed=5)
+    model = llama.Llama(hp, w, context_size=96)
+    toks = np.random.default_rng(3).integers(0, hp["n_vocab"], 10).astype(np.int32)
+    try:
+        G.set_option("graph", graph)
+        ref, k0, v0, _, _, ids0 = _decode(G, model, toks, 3, 0, device_chain=9)
+        got, k1, v1, nf, _, ids1 = _decode(G, model, toks, 3, 2, device_chain=9)
+    finally:
+        G.set_option("graph", 1)
+        G.set_option("fuse_attn", 1)
+        model.free()
+    assert nf >= 3 + 9
+    assert np.array_equal(ids0, ids1)
+    for (ta, la), (tb, lb) in zip(ref, got):
+        assert ta == tb and np.array_equal(la, lb)
+    assert np.array_equal(k0, k1) and np.array_equal(v0, v1)
+
+
+def test_fused_launch_is_the_default_at_7b_width_and_matches_the_pair(G, O):
+    """The shape the option exists for: 4096-wide layers with 32 heads on 256 CUs (224 mat-vec workgroups x 14 waves deal the
+    6144 row pairs as evenly as 256 x 12).  Default option value (1) must pick the fused launch there, up to the split-attention
+    threshold, and leave the logits bit-identical to the pair; beyond 255 positions the attention workgroups fetch the second
+    256-position pass inside the launch."""
+    from llm_amd import llama, synth
+    hp0 = dict(synth.LLAMA_7B)
+    hp0["n_layer"], hp0["n_vocab"] = 2, 512
+    hp, w = synth.make_llama_gaussian(hp0, 2)
+    model = llama.Llama(hp, w, context_size=1024)
+    toks = np.random.default_rng(1).integers(0, hp["n_vocab"], 300).astype(np.int32)
+    res = {}
+    try:
+        for fuse in (0, 1):
+            G.set_option("fuse_attn", fuse)
+            sess = model.start_session(n_batch=64)
+            f0 = _stat(G, "fused_attn_tokens")
+            outs = []
+            sess.feed_prompt(toks[:40])
+            outs += [(sess.infer_next_token(), sess.last_logits()) for _ in range(4)]       # short context
+            sess.feed_prompt(toks[40:292])                                                   # -> n_past 296
+            outs += [(sess.infer_next_token(), sess.last_logits()) for _ in range(4)]       # second 256-position pass
+            res[fuse] = (outs, sess.get_kv(), _stat(G, "fused_attn_tokens") - f0)
+            assert _stat(G, "fused_attn_timeouts") == 0
+            sess.free()
+    finally:
+        G.set_option("fuse_attn", 1)
+        model.free()
+    assert res[0][2] == 0 and res[1][2] == 8
+    for (ta, la), (tb, lb) in zip(res[0][0], res[1][0]):
+        assert ta == tb and np.array_equal(la, lb)
+    assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])

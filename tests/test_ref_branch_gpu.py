@@ -6,11 +6,16 @@ whole-model band.
    EVEN) — oracle mode 2, written with the intrinsics as mode 3.  The device follows that branch by default (option
    act_quant = 0, kernels/common.h) and the scalar branch (id = 1/d, roundf) under act_quant = 1.  Both are held to their
    oracle mode here, op level, on inputs where the two branches provably disagree (exact ties) and on random ones.
-2. Teacher forcing at LLaMA-7B width with the bench's gaussian weights: every layer of a 4-layer stack is run ALONE on the
+2. Teacher forcing at LLaMA-7B width with the bench's gaussian weights: five layers of a 6-layer stack are each run ALONE on the
    device (a layer-split stage, the graphs the fused plans accept) on the ORACLE's input residual and the oracle's K/V, and
    that one layer's output is bounded — chaos cannot accumulate across layers, so the bound is the arithmetic's, not the
-   model's: STRICT when no int8 activation quant flips, EDGE_LAYER when some do (one flip moves one activation by
-   amax/127: ~4e-4 of the layer update's std at K = 4096)."""
+   model's.  What one layer does to a last-bit difference, measured here: nothing (2e-6 of the update's std: STRICT) when no
+   int8 activation quant flips; when one does (the normed row sits within an ulp of a rounding edge in ~half of the rows),
+   the row's 3e-4 perturbation of wq..w3's outputs flips ~1e-2 of the 11008 quants of w2's input, and the layer's output
+   moves by 2e-2 max / 5e-3 rms of its update's std — for ANY two implementations, the oracle's own two summation orders
+   included.  So the yardstick is measured in the test on the same rows: the oracle against itself with its block sums in
+   reverse order (a legal re-association, orc_set_block_order), per layer and case; the device must stay within 2x the
+   worst of those (and under a fixed 1e-1 cap: a wrong term, scale or position shows up as O(1))."""
 import ctypes as C
 
 import numpy as np
@@ -20,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 QTYPES = [2, 3, 6, 7, 8]  # q4_0 q4_1 q5_0 q5_1 q8_0
 STRICT = 2e-5       # f32 summation order only
-EDGE_LAYER = 1e-2   # max |delta| of ONE 7B-wide layer, in units of std(layer update); rms bound 1.5e-3
+LAYER_CAP = 1e-1    # no layer output may be further from the oracle than this (units: std of the layer's update), whatever the band
 
 
 def _mul_mat_gpu(G, wtype, W_raw, M, K, X):
@@ -137,7 +142,7 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
     from llm_amd import llama, synth
     Q4_0 = 2
     hp0 = dict(synth.LLAMA_7B)
-    hp0["n_layer"], hp0["n_vocab"] = 4, 512
+    hp0["n_layer"], hp0["n_vocab"] = 6, 512  # layers 0..4 are checked (the last one ends in the lm_head, not in a residual)
     hp, w = synth.make_llama_gaussian(hp0, Q4_0)
     L, E, ctx = hp["n_layer"], hp["n_embd"], 64
     P = 21
@@ -152,13 +157,30 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
     k_full, v_full = orc.memory_k.copy(), orc.memory_v.copy()
     Eg = E  # n_head_kv == n_head
     per = ctx * Eg
-    worst, n_strict, n_cases = 0.0, 0, 0
-    for il in range(L):
+    worst, n_strict, n_cases, results = 0.0, 0, 0, []
+    band_mx, band_rms = 0.0, 0.0
+
+    def oracle_layer_rev(il, rows_in, n_past, tsl, kb, vb):
+        """layer il alone in the oracle with its block sums in reverse order, on the same input rows and K/V"""
+        hp1 = dict(hp)
+        hp1["n_layer"] = 1
+        w1 = {k: v for k, v in w.items() if not k.startswith("layers.")}
+        for k, v in w.items():
+            if k.startswith(f"layers.{il}."):
+                w1["layers.0." + k.split(".", 2)[2]] = v
+        o = O.Llama(hp1, w1, ctx)
+        o.memory_k[:] = kb[il * per:(il + 1) * per]
+        o.memory_v[:] = vb[il * per:(il + 1) * per]
+        o.n_past = n_past
+        _, tt = o.evaluate(tsl, mode=mode, taps=True, reverse_blocks=True, inp=rows_in)
+        return tt["layer_out_all"][0]
+
+    for il in range(L - 1):
         names = synth.stage_tensor_names(hp, il, il + 1)
         stage = llama.Llama(hp, {k: v for k, v in w.items() if k in names}, context_size=ctx, layer_range=(il, il + 1))
         sess = stage.start_session(n_batch=32)
         in_dev, out_dev, nbytes = sess.stage_buffers()
-        assert in_dev and out_dev and nbytes >= 13 * E * 4
+        assert (in_dev or il == 0) and out_dev and nbytes >= 13 * E * 4  # layer 0 starts from the token ids (get_rows)
         zero = np.zeros(per, np.uint16)
 
         def run(rows_in, n_past, tok_slice, k_before, v_before):
@@ -171,7 +193,8 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
                 assert sess.rewind(sess.n_past - n_past) == 0
             assert sess.n_past == n_past
             x = np.ascontiguousarray(rows_in, np.float32)
-            G.lib().ggml_hip_memcpy(C.c_void_p(in_dev), C.c_void_p(x.ctypes.data), x.nbytes, 0)
+            if il > 0:
+                G.lib().ggml_hip_memcpy(C.c_void_p(in_dev), C.c_void_p(x.ctypes.data), x.nbytes, 0)
             sess.evaluate(tok_slice, want_all_logits=False)
             out = np.zeros_like(x)
             G.lib().ggml_hip_memcpy(C.c_void_p(out.ctypes.data), C.c_void_p(out_dev), out.nbytes, 1)
@@ -202,11 +225,20 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
             vcols_o = vo.reshape(Eg, ctx)[:, n_past:n_past + len(tsl)]
             nv = int(np.count_nonzero(vcols_d != vcols_o))
             print(f"layer {il} {name}: max {mx:.2e} rms {rms:.2e} of std(update) {s:.3e}; K/V halves differing {nk}+{nv} of {2 * len(tsl) * Eg}")
-            assert mx <= EDGE_LAYER and rms <= 1.5e-3, (il, name, mx, rms)
-            assert nk + nv <= 0.01 * 2 * len(tsl) * Eg, (il, name, nk, nv)
+            rev = oracle_layer_rev(il, rows_in, n_past, tsl, kb, vb)
+            dr = np.abs(rev - want)
+            bmx, brms = float(dr.max()) / s, float(np.sqrt(np.mean(dr ** 2))) / s
+            print(f"         oracle fwd vs reversed block order on the same rows: max {bmx:.2e} rms {brms:.2e}")
+            band_mx, band_rms = max(band_mx, bmx), max(band_rms, brms)
+            results.append((il, name, mx, rms, nk + nv, 2 * len(tsl) * Eg))
             worst = max(worst, mx)
             n_strict += mx <= STRICT
             n_cases += 1
         sess.free()
         stage.free()
-    print(f"per-layer teacher forcing: worst max {worst:.2e}, {n_strict} of {n_cases} evaluations within STRICT {STRICT}")
+    print(f"per-layer teacher forcing: device worst max {worst:.2e}, {n_strict} of {n_cases} evaluations within STRICT {STRICT}; "
+          f"oracle's own band over the same cases: max {band_mx:.2e} rms {band_rms:.2e}")
+    assert n_strict >= 1  # a row without a flipped quant exists among 15 evaluations, and there the device is exact to 2e-5
+    for il, name, mx, rms, nkv, tot in results:
+        assert mx <= LAYER_CAP and mx <= max(2 * band_mx, 10 * STRICT) and rms <= max(2 * band_rms, 10 * STRICT), (il, name, mx, rms, band_mx, band_rms)
+        assert nkv <= 0.01 * tot, (il, name, nkv, tot)
