@@ -308,6 +308,7 @@ def run_single(args):
     L.ggml_hip_synchronize()
     stat = lambda k: int(L.ggml_hip_get_stat(k.encode()))
     h0 = {k: stat(k) for k in ("ns_match", "ns_launch", "ns_wait", "ns_compute", "plan_tokens")}
+    fused0 = stat("fused_attn_tokens")
     sess.host_timing(reset=True)
     per_step = np.zeros(args.steps)
     t0 = time.perf_counter()
@@ -320,6 +321,10 @@ def run_single(args):
     L.ggml_hip_synchronize()
     elapsed = time.perf_counter() - t0
     tok_s = args.steps / elapsed
+    fused_tokens = stat("fused_attn_tokens") - fused0
+    fused_timeouts = stat("fused_attn_timeouts")
+    if fused_timeouts:
+        raise SystemExit(f"bench.py: {fused_timeouts} attention workgroup(s) of k_qkv_attn gave up waiting for their rows")
     parity = parity_check(args, hp, w, sess) if not args.no_parity_check else None
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
     h1 = {k: stat(k) - v for k, v in h0.items()}
@@ -437,6 +442,12 @@ def run_single(args):
                                   f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",
                       "n_past_at_start": args.prompt + args.warmup, "parallelism": "1 GPU",
                       "weights_in_hbm_before_timing": True, "host_split_per_token": host_split,
+                      "decode_launches": {"qkv_and_attention_in_one_launch_tokens": int(fused_tokens), "of_timed_tokens": int(args.steps),
+                                          "per_layer": "k_qkv_attn (wq|wk|wv mat-vec on G - n_head workgroups + one attention workgroup per head "
+                                                       "in the same launch, rows handed over as epoch-tagged 8-byte granules) -> wo -> w1|w3 -> w2"
+                                                       if fused_tokens else "wq|wk|wv -> k_attn_decode -> wo -> w1|w3 -> w2",
+                                          "note": "roofline.per_kind.qkv is the fused launch when it ran: its bytes include the K/V read of the "
+                                                  "attention, its time the hand-off wait and the attention tail"},
                       "long_context": long_ctx,
                       "device_sampling": {"tokens_per_s": round(args.steps / dev_s, 2), "ms_per_token": round(dev_s / args.steps * 1e3, 4),
                                           "note": "same greedy tokens via llm_infer_tokens_greedy_device (argmax kernel feeds the next "

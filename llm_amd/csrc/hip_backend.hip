@@ -778,7 +778,12 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     DecParams saved, park;
     HIP_CHECK(hipMemcpy(&saved, p->prm, sizeof(saved), hipMemcpyDeviceToHost));
     park = saved;
-    if (kclass == GGML_HIP_KCLASS_MMVQ) park.n_past = (int)p->m.C - 1;  // K/V stores go to a scratch slot
+    if (kclass == GGML_HIP_KCLASS_MMVQ) {  // K/V stores go to a scratch slot: the replay runs on the last token's stale activations
+        if (g.opt_big)
+            park.store_at = (int)p->m.C - 1;  // ... and the fused attention (k_qkv_attn) still meets the real context length
+        else
+            park.n_past = (int)p->m.C - 1;
+    }
     HIP_CHECK(hipMemcpy(p->prm, &park, sizeof(park), hipMemcpyHostToDevice));
     PlanStats st;
     hipGraph_t gr = nullptr;

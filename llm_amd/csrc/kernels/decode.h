@@ -19,7 +19,9 @@
 struct DecParams {
     int n_past;   // tokens already in the KV cache = position of the (first) token being evaluated
     int token;    // its id (row of tok_embeddings)
-    int pad[2];
+    int store_at; // k_mmvq_big / k_qkv_attn: cache position the token's K / V rows are WRITTEN to; 0 = n_past (always, outside the
+                  // roofline leg: a replay of the mat-vec class alone runs on stale activations and parks its rows in the last slot)
+    int pad1;
     int tokens[32];  // multi-token plan (2..31 tokens of a prompt chunk): ids of all tokens, tokens[0] == token
 };
 

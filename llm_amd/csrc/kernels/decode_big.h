@@ -240,10 +240,11 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
 
     const long long t_entry = ts ? big_now() : 0;
     // ---- 1. the activation's loads go first (see BigX); so does the position (needed by the QKV epilogue only)
-    int n_past = 0;
+    int n_past = 0, store_at = 0;
     unsigned epoch = 0;
     if constexpr (EPI == EPI_QKV) {
         n_past = a.prm->n_past;
+        store_at = a.prm->store_at;
         if (ba.gran) epoch = *ba.epoch;
     }
     BigX<XSRC> xr;
@@ -439,7 +440,7 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
         } else if constexpr (EPI == EPI_GATE) {
             a.dst[m0] = silu_table(myv[0]) * myv[1];
         } else {  // EPI_QKV, see k_mmvq_dec
-            const int p = n_past;
+            const int p = store_at ? store_at : n_past;
             __half h0, h1;  // the pair as f16: what the K/V cache holds, and what ggml's F16 mat-mul makes of Q (src1 -> f16)
             if (sg == 2) {
                 h0 = __float2half_rn(myv[0]);

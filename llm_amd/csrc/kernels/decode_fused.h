@@ -134,6 +134,7 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + 64 * u;
+            if ((t0 - g) + 64 * u >= T) break;  // the slab starts beyond the context (uniform over the workgroup)
             const f16x8 kr = t == n_past ? knew : kv[u];  // the token's own row comes from the granules
             float s = 0.0f;
 #pragma unroll
@@ -145,6 +146,34 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
     __syncthreads();
     const long long t_scores = f.ts ? (long long)wall_clock64() : 0;
     // ---- softmax (ggml: max, f16-rounded exp of the f16-rounded difference, f64 sum, scale by 1/sum) ----
+    // Up to 256 positions one wave does it alone (4 per lane, DPP reductions): no exchange through LDS, no barrier between the
+    // passes.  The f64 sum of f16-valued terms is exact, so its order is immaterial.
+    if (T <= 256) {
+        if (wave == 0) {
+            float sv[4], e[4];
+            float mx1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = lane + 64 * i;
+                sv[i] = t < T ? s_s[t] : -INFINITY;
+                mx1 = fmaxf(mx1, sv[i]);
+            }
+            mx1 = wave_max_f32(mx1);
+            double sum1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                e[i] = lane + 64 * i < T ? round_f16(expf(round_f16(sv[i] - mx1))) : 0.0f;
+                sum1 += (double)e[i];
+            }
+            sum1 = wave_sum_f64(sum1);
+            const float inv1 = (float)(1.0 / sum1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = lane + 64 * i;
+                if (t < T8) s_p[t] = t < T ? (_Float16)(e[i] * inv1) : (_Float16)0.0f;
+            }
+        }
+    } else {
     float mx = -INFINITY;
     for (int t = tid; t < T; t += 1024) mx = fmaxf(mx, s_s[t]);
     mx = wave_max_f32(mx);
@@ -167,6 +196,7 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
     for (int i = 0; i < 16; i++) tot += s_redd[i];
     const float inv = (float)(1.0 / tot);
     for (int t = tid; t < T8; t += 1024) s_p[t] = t < T ? (_Float16)(s_s[t] * inv) : (_Float16)0.0f;
+    }
     __syncthreads();
     const long long t_softmax = f.ts ? (long long)wall_clock64() : 0;
     // ---- V.P ----
@@ -189,9 +219,11 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
                 const int pos = p0 + 64 * u + pj;
                 if (pos < T8) {
                     f16x8 vr = vv[u];
-                    const int e = n_past - pos;  // the token's own position inside this 8-chunk?
+                    if (((p0 + 64 * u) >> 6) == (n_past >> 6)) {  // the 64-slab of the token's own position (uniform)
+                        const int e = n_past - pos;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
+                        for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
+                    }
                     const f16x8 pp = *(const f16x8 *)(s_p + pos);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
