@@ -58,26 +58,31 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
     const unsigned epoch = *f.epoch;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- the head's cache, first 256 positions, requested before anything is known (k_attn_decode's speculative pass)
+    // ---- the head's cache: up to 512 positions (the split-attention threshold) go into registers now, while the mat-vec
+    //      workgroups stream — exactly the rows the context has (the position is known after one scalar round trip; the
+    //      requests have microseconds of slack), so a short context costs the weight stream next to nothing
+    constexpr int NPRE = 8;
+    const int T = n_past + 1;
+    const int T8 = (T + 7) & ~7;
     const int g = tid >> 4, gl = tid & 15;
     const int d0 = gl * 8;
     const bool act = d0 < D;
     const __half *kbase = f.mem_k + (int64_t)hk * D + d0;
-    f16x8 kv[4];
+    f16x8 kv[NPRE];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < NPRE; u++) {
         const int t = g + 64 * u;
         kv[u] = zero8;
-        if (act && t < C) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+        if (act && t < n_past) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
     }
     const int cv = wave * 8 + (lane >> 3), pj = (lane & 7) * 8;
     const bool vact = cv < D;
     const __half *vbase = f.mem_v + ((int64_t)hk * D + cv) * C + pj;
-    f16x8 vv[4];
+    f16x8 vv[NPRE];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < NPRE; u++) {
         vv[u] = zero8;
-        if (vact && 64 * u + pj + 8 <= C) vv[u] = *(const f16x8 *)(vbase + 64 * u);
+        if (vact && 64 * u + pj < T8) vv[u] = *(const f16x8 *)(vbase + 64 * u);  // T8 <= C: the chunk lies inside the cache
     }
 
     // ---- this token's rows of the head: waves 0 / 1 / 2 sweep the D/2 granules of Q / K / V until every tag is the epoch
@@ -117,31 +122,30 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
 #pragma unroll
         for (int j = 0; j < 4; j++) qh2[j] = f16x2{(_Float16)0.0f, (_Float16)0.0f};
     }
-    const int T = n_past + 1;
-    const int T8 = (T + 7) & ~7;
 
     // ---- scores ----
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        if (64 * u >= T) break;  // the slab starts beyond the context (uniform over the workgroup)
+        const int t = g + 64 * u;
+        const f16x8 kr = t == n_past ? knew : kv[u];  // the token's own row comes from the granules
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) s = __builtin_amdgcn_fdot2(f16x2{kr[2 * j], kr[2 * j + 1]}, qh2[j], s, false);
+        s = g16_sum_f32(s);
+        if (gl == 0 && t < T) s_s[t] = s * f.scale;
+    }
 #pragma unroll 1
-    for (int t0 = g; t0 < T; t0 += 256) {
-        if (t0 != g) {
+    for (int t0 = 64 * NPRE; t0 < T; t0 += 64) {  // contexts beyond the register window (option attn_split raised): from the cache
+        const int t = t0 + g;
+        f16x8 kr = zero8;
+        if (act && t < n_past) kr = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+        if (t == n_past) kr = knew;
+        float s = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int t = t0 + 64 * u;
-                kv[u] = zero8;
-                if (act && t < n_past) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = t0 + 64 * u;
-            if ((t0 - g) + 64 * u >= T) break;  // the slab starts beyond the context (uniform over the workgroup)
-            const f16x8 kr = t == n_past ? knew : kv[u];  // the token's own row comes from the granules
-            float s = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; j++) s = __builtin_amdgcn_fdot2(f16x2{kr[2 * j], kr[2 * j + 1]}, qh2[j], s, false);
-            s = g16_sum_f32(s);
-            if (gl == 0 && t < T) s_s[t] = s * f.scale;
-        }
+        for (int j = 0; j < 4; j++) s = __builtin_amdgcn_fdot2(f16x2{kr[2 * j], kr[2 * j + 1]}, qh2[j], s, false);
+        s = g16_sum_f32(s);
+        if (gl == 0 && t < T) s_s[t] = s * f.scale;
     }
     __syncthreads();
     const long long t_scores = f.ts ? (long long)wall_clock64() : 0;
@@ -205,32 +209,25 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
         const unsigned vpair = vact ? s_new[128 + (cv >> 1)] : 0u;
         const _Float16 vnew = u32_as_h2(vpair)[cv & 1];
         float acc = 0.0f;
-#pragma unroll 1
-        for (int p0 = 0; p0 < T8; p0 += 256) {
-            if (p0 != 0) {
+        auto chunk = [&](f16x8 vr, const int pos) {  // 8 positions of channel cv against their probabilities
+            if ((pos >> 6) == (n_past >> 6)) {  // the 64-slab of the token's own position (uniform)
+                const int e = n_past - pos;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    vv[u] = zero8;
-                    if (vact && p0 + 64 * u + pj < T8) vv[u] = *(const f16x8 *)(vbase + p0 + 64 * u);
-                }
+                for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
             }
+            const f16x8 pp = *(const f16x8 *)(s_p + pos);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int pos = p0 + 64 * u + pj;
-                if (pos < T8) {
-                    f16x8 vr = vv[u];
-                    if (((p0 + 64 * u) >> 6) == (n_past >> 6)) {  // the 64-slab of the token's own position (uniform)
-                        const int e = n_past - pos;
+            for (int j = 0; j < 4; j++)
+                acc = __builtin_amdgcn_fdot2(f16x2{vr[2 * j], vr[2 * j + 1]}, f16x2{pp[2 * j], pp[2 * j + 1]}, acc, false);
+        };
 #pragma unroll
-                        for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
-                    }
-                    const f16x8 pp = *(const f16x8 *)(s_p + pos);
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        acc = __builtin_amdgcn_fdot2(f16x2{vr[2 * j], vr[2 * j + 1]}, f16x2{pp[2 * j], pp[2 * j + 1]}, acc, false);
-                }
-            }
+        for (int u = 0; u < NPRE; u++) {
+            if (64 * u >= T8) break;  // uniform
+            if (64 * u + pj < T8) chunk(vv[u], 64 * u + pj);
         }
+#pragma unroll 1
+        for (int p0 = 64 * NPRE; p0 < T8; p0 += 64)
+            if (p0 + pj < T8) chunk(vact ? *(const f16x8 *)(vbase + p0) : zero8, p0 + pj);
         acc = g8_sum_f32(acc);
         if ((lane & 7) == 0 && vact) s_o[cv] = acc;
     }
