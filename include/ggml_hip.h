@@ -456,8 +456,14 @@ GGML_API int ggml_hip_device_count(void);
 /* Several devices in one process (the ggml-style layer split of one InferenceSession).  A device
  * "slot" owns a stream, the device shadows of the host arenas, the weights uploaded while it was current and its plan cache;
  * ggml_hip_set_main_device (cuda.rs:62) makes a slot current for every following call.  GGML_HIP_VIRTUAL_DEVICES=n maps n
- * slots onto the visible GPUs round-robin (several slots on one GPU: how the split is tested on a 1-GPU box). */
+ * slots onto the visible GPUs round-robin (several slots on one GPU: how the split is tested on a 1-GPU box).
+ * Threads: the current slot is per thread.  ggml_hip_set_main_device sets the process default (followed by every thread
+ * that never chose a slot — the reference sets it once at load, accelerator/mod.rs:72) and pins the calling thread;
+ * ggml_hip_bind_thread_device pins the calling thread only.  Entry points lock the slot they act on, not the library:
+ * sessions on different slots run concurrently (crates/llm-base/src/inference_session.rs:43-48: sessions are Send and
+ * one model serves several of them), calls on one slot are serialised.  ggml_hip_get_main_device = the caller's slot. */
 GGML_API int ggml_hip_get_main_device(void);
+GGML_API void ggml_hip_bind_thread_device(int device);
 /* ggml_hip_set_tensor_split / ggml_cuda_set_tensor_split read exactly ONE float: the reference passes the address of a
  * single stack f32 (crates/ggml/src/accelerator/mod.rs:74-75).  get returns that value (out[0]; 1 written). */
 GGML_API int ggml_hip_get_tensor_split(float *out, int cap);

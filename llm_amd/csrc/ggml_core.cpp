@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "internal.h"
 
@@ -723,9 +724,24 @@ struct ggml_cplan ggml_graph_plan(struct ggml_cgraph *cgraph, int n_threads) {
     return cplan;
 }
 
+static int64_t wall_us() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000 + ts.tv_nsec / 1000;
+}
 int ggml_graph_compute(struct ggml_cgraph *cgraph, struct ggml_cplan *cplan) {
     (void)cplan;
+    // ggml's tracing hook (crates/ggml/sys/src/lib.rs:253-255, 542-544): upstream bumps perf_runs of the graph and of every
+    // node on each compute; the time fields only move in a GGML_PERF build, which the reference's build.rs does not enable.
+    // Here the graph's fields carry the wall time of the call (enqueue + device wait: what a caller timing the FFI call
+    // would see); a node's time stays 0 — under the fused plans a node has no launch of its own to time.
+    const int64_t t0 = wall_us();
+    const clock_t c0 = clock();
     ggml_hip_internal_graph_compute(cgraph);
+    cgraph->perf_runs++;
+    cgraph->perf_cycles += (int64_t)(clock() - c0);
+    cgraph->perf_time_us += wall_us() - t0;
+    for (int i = 0; i < cgraph->n_nodes; i++) cgraph->nodes[i]->perf_runs++;
     return GGML_EXIT_SUCCESS;
 }
 

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -103,11 +104,9 @@ namespace {
 static void register_arena_here(void *host_base, size_t size, int is_scratch);
 static void unregister_arena_here(void *host_base);
 extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size, int is_scratch) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
     for_each_slot([&] { register_arena_here(host_base, size, is_scratch); });
 }
 extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
     for_each_slot([&] { unregister_arena_here(host_base); });
 }
 static void register_arena_here(void *host_base, size_t size, int is_scratch) {
@@ -181,7 +180,7 @@ static void unregister_arena_here(void *host_base) {
 }
 
 extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     const uint64_t t0 = now_ns();
     execute_graph(cgraph);
     g.ns_compute += now_ns() - t0;
@@ -191,7 +190,7 @@ extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
 // (fused decode plan), 0 if it was executed synchronously (any other graph); end() waits and finishes the
 // read-back of the host-visible results.  Nothing else may read results before end().
 extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     const uint64_t t0 = now_ns();
     ensure_init();
     finish_pending();
@@ -211,7 +210,7 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     return async;
 }
 extern "C" void ggml_hip_graph_compute_end(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     const uint64_t t0 = now_ns();
     finish_pending();
     g.ns_compute += now_ns() - t0;
@@ -223,16 +222,25 @@ extern "C" void ggml_hip_graph_compute_end(void) {
 extern "C" {
 
 void ggml_init_hipblas(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
 }
 void ggml_hip_set_main_device(int main_device) {
-    // crates/ggml/sys/src/cuda.rs:62 (accelerator/mod.rs:72): the slot every following call acts on
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    // crates/ggml/sys/src/cuda.rs:62 (accelerator/mod.rs:72): the slot every following call acts on — the process default
+    // (threads that never chose a slot follow it) and the calling thread's slot
     if (main_device < 0 || main_device >= std::max(1, slot_count()))
         die("ggml_hip_set_main_device(%d): %d device slot(s) available", main_device, slot_count());
-    g_cur = &g_backends[main_device];
-    g.slot = main_device;
+    g_default_slot.store(main_device, std::memory_order_relaxed);
+    ggml_hip_bind_thread_device(main_device);
+}
+void ggml_hip_bind_thread_device(int device) {
+    // the calling thread's slot only: sessions of one process driven from several threads bind their own model's slot
+    if (device < 0 || device >= std::max(1, slot_count()))
+        die("ggml_hip_bind_thread_device(%d): %d device slot(s) available", device, slot_count());
+    tl_pinned = true;
+    g_cur = &g_backends[device];
+    SlotLock lk(g_cur);
+    g.slot = device;
     if (g.inited) bind_device();
 }
 void ggml_hip_set_tensor_split(const float *tensor_split) {
@@ -267,7 +275,7 @@ int ggml_hip_get_layer_split(float *out, int cap) {
 void ggml_hip_set_mul_mat_q(bool) {}  // quantized kernels are always used
 void ggml_hip_set_scratch_size(size_t) {}  // activations live in arena shadows, there is no scratch pool
 void ggml_hip_free_scratch(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     if (!g.inited) return;
     HIP_CHECK(hipStreamSynchronize(g.stream));
     // Cached decode plans (and the plan a greedy chain may continue) hold device addresses inside these shadows
@@ -294,7 +302,7 @@ void ggml_hip_free_scratch(void) {
     g.dead_shadow_bytes = 0;
 }
 void *ggml_hip_host_malloc(size_t size) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     void *p = nullptr;
     if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess) return nullptr;
@@ -304,7 +312,7 @@ void ggml_hip_host_free(void *ptr) {
     if (ptr) HIP_CHECK(hipHostFree(ptr));
 }
 void ggml_hip_transform_tensor(void *data, struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     if (extra_of(tensor)) return;
     tensor->backend = GGML_BACKEND_GPU;
     tensor->extra = upload_tensor(data, tensor, false);
@@ -324,7 +332,7 @@ static void launch_quantize_blocks(const void *src_dev, bool f16_src, int type, 
     HIP_CHECK(hipGetLastError());
 }
 size_t ggml_hip_quantize(enum ggml_type type, const float *src, void *dst, int64_t n, int64_t k, int64_t *hist) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     if (!quantizable(type)) die("ggml_hip_quantize: %s has no device encoder", ggml_type_name(type));
     if (k % 32 != 0 || n % k != 0) die("ggml_hip_quantize: n = %lld must be rows of k = %lld, k %% 32 == 0", (long long)n, (long long)k);
@@ -355,7 +363,7 @@ size_t ggml_hip_quantize(enum ggml_type type, const float *src, void *dst, int64
     return (size_t)nblocks * bs;
 }
 int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor *dst, int64_t *hist) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     if (!quantizable(dst->type) || (src->type != GGML_TYPE_F32 && src->type != GGML_TYPE_F16)) return -1;
     if (!ggml_is_contiguous(src) || src->ne[2] != 1 || src->ne[3] != 1 || src->ne[0] % 32 != 0 || src->ne[0] != dst->ne[0] ||
@@ -402,7 +410,7 @@ int ggml_hip_quantize_resident(const struct ggml_tensor *src, struct ggml_tensor
 // ---- device top-k prefilter (kernels/topk.h) ----
 int ggml_hip_topk(const struct ggml_tensor *t, int64_t row, int k, const int32_t *extra_ids, int n_extra, float *out_vals,
                   int32_t *out_ids) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     if (!t || t->type != GGML_TYPE_F32 || t->nb[0] != 4 || row < 0 || row >= t->ne[1] * t->ne[2] * t->ne[3] || t->ne[2] != 1 ||
         t->ne[3] != 1 || k < 1 || k > TOPK_MAX || k > t->ne[0] || n_extra < 0 || t->ne[0] > 0x7FFFFFFF || !out_vals || !out_ids ||
@@ -432,10 +440,12 @@ int ggml_hip_topk(const struct ggml_tensor *t, int64_t row, int k, const int32_t
 }
 
 void ggml_hip_free_data(struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!tensor || !tensor->extra) return;
     DevTensor *e = (DevTensor *)tensor->extra;
     if (e->magic != 0x48495054) return;  // scratch-assigned node: nothing to free (as in the reference)
+    // the OWNER slot's lock (the record, its plans and its accounting live there), whichever slot this thread is on
+    const int owner = (e->slot >= 0 && e->slot < GGML_HIP_MAX_BACKENDS) ? e->slot : g_cur_slot();
+    SlotLock lk(&g_backends[owner]);
     free_dev_tensor(e);
     tensor->extra = nullptr;
 }
@@ -446,7 +456,7 @@ void ggml_hip_assign_buffers(struct ggml_tensor *tensor) {
 }
 void ggml_hip_assign_buffers_force_inplace(struct ggml_tensor *tensor) { tensor->backend = GGML_BACKEND_GPU; }
 void ggml_hip_assign_buffers_no_scratch(struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     tensor->backend = GGML_BACKEND_GPU;
     if (tensor->op != GGML_OP_NONE || extra_of(tensor)) return;
     // persistent, zero-initialised device tensor (the K/V memory: inference_session.rs:996-1021)
@@ -465,13 +475,13 @@ size_t ggml_hip_mul_mat_get_wsize(const struct ggml_tensor *, const struct ggml_
 }
 void ggml_hip_mul_mat(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst, void *,
                       size_t) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     BK_ASSERT(dst->src[0] == src0 && dst->src[1] == src1);
     op_mul_mat(dst);
 }
 void ggml_hip_mul(const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     BK_ASSERT(dst->src[0] == src0 && dst->src[1] == src1);
     op_bin(dst, BIN_MUL);
@@ -479,7 +489,7 @@ void ggml_hip_mul(const struct ggml_tensor *src0, const struct ggml_tensor *src1
 bool ggml_hip_compute_forward(struct ggml_compute_params *params, struct ggml_tensor *tensor) {
     // Per-node hook of the reference's CPU executor. This library executes whole graphs itself
     // (ggml_graph_compute), so the hook only has to answer for callers that drive nodes one by one.
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     if (params && (params->ith != 0 || params->type != GGML_TASK_COMPUTE)) return true;
     ensure_init();
     ggml_cgraph *gr = (ggml_cgraph *)calloc(1, sizeof(ggml_cgraph));
@@ -521,48 +531,64 @@ bool ggml_cuda_compute_forward(struct ggml_compute_params *p, struct ggml_tensor
 // exported: extensions
 // ===================================================================================================
 int ggml_hip_device_count(void) { return slot_count(); }
-int ggml_hip_get_main_device(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+int ggml_hip_get_main_device(void) {  // the calling thread's slot
+    if (!tl_pinned) g_cur = &g_backends[g_default_slot.load(std::memory_order_relaxed)];
     return (int)(g_cur - g_backends);
 }
 // The residual of a layer split crossing from one slot to another: dst on slot dst_device's stream waits for what
 // src_device's stream has enqueued so far, then copies (peer copy over xGMI between two GPUs, a device copy when both slots
 // sit on one GPU).  Asynchronous; ordered with both slots' later work on their own streams.
 void ggml_hip_copy_between_devices(int dst_device, void *dst, int src_device, const void *src, size_t nbytes) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (dst_device < 0 || src_device < 0 || dst_device >= GGML_HIP_MAX_BACKENDS || src_device >= GGML_HIP_MAX_BACKENDS)
         die("ggml_hip_copy_between_devices: bad slot");
     Backend &S = g_backends[src_device], &D = g_backends[dst_device];
+    // both slots, lower index first (the only place two slot locks are held together)
+    SlotLock lk_a(&g_backends[std::min(src_device, dst_device)]);
+    SlotLock lk_b(&g_backends[std::max(src_device, dst_device)]);  // recursive: the same slot twice is fine
     if (!S.inited || !D.inited) die("ggml_hip_copy_between_devices: slot not initialised");
     Backend *keep = g_cur;
     g_cur = &S;
     bind_device();
-    hipEvent_t ev;
-    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(ev, S.stream));
+    // one event per source slot, re-recorded per hop (a later record does not disturb a wait already enqueued on it)
+    if (!S.xfer_ev) HIP_CHECK(hipEventCreateWithFlags(&S.xfer_ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(S.xfer_ev, S.stream));
     g_cur = &D;
     bind_device();
-    HIP_CHECK(hipStreamWaitEvent(D.stream, ev, 0));
+    HIP_CHECK(hipStreamWaitEvent(D.stream, S.xfer_ev, 0));
     if (S.device == D.device)
         HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, D.stream));
-    else
+    else {
+        // direct xGMI path: the destination device maps the source's memory (once per ordered pair); without peer access the
+        // runtime stages the copy through host memory, which is still correct
+        static bool peer_tried[GGML_HIP_MAX_BACKENDS][GGML_HIP_MAX_BACKENDS];
+        if (!peer_tried[dst_device][src_device]) {
+            peer_tried[dst_device][src_device] = true;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, D.device, S.device) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(S.device, 0);  // current device = D.device (bind_device above)
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    fprintf(stderr, "ggml-hip: peer access %d -> %d not enabled (%s): copies go through the host\n", D.device, S.device,
+                            hipGetErrorString(e));
+            }
+            (void)hipGetLastError();
+        }
         HIP_CHECK(hipMemcpyPeerAsync(dst, D.device, src, S.device, nbytes, D.stream));
-    HIP_CHECK(hipEventDestroy(ev));  // released once the recorded work completes
+    }
     g_cur = keep;
     if (g.inited) bind_device();
 }
 void ggml_hip_synchronize(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     if (g.inited) HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void ggml_hip_tensor_get(const struct ggml_tensor *tensor, void *host_dst, size_t offset, size_t nbytes) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     d2h_queue(host_dst, dev_ptr(tensor) + offset, nbytes);
     d2h_finish();
 }
 void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_t offset, size_t nbytes) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     h2d_bulk(dev_ptr(tensor) + offset, host_src, nbytes);
     HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -570,7 +596,7 @@ void ggml_hip_tensor_set(struct ggml_tensor *tensor, const void *host_src, size_
 // Raw copies on the backend stream, synchronous (layer-split driver: moving the residual between a stage's
 // hand-off buffer and the communication library's buffers). kind: 0 = host→device, 1 = device→host, 2 = device→device.
 void ggml_hip_memcpy(void *dst, const void *src, size_t nbytes, int kind) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     if (kind == 0) {
         h2d_bulk((char *)dst, src, nbytes);
@@ -584,12 +610,12 @@ void ggml_hip_memcpy(void *dst, const void *src, size_t nbytes, int kind) {
     }
 }
 void *ggml_hip_tensor_device_ptr(const struct ggml_tensor *tensor) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     return dev_ptr(tensor);
 }
 void ggml_hip_timing_begin(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     ensure_init();
     HIP_CHECK(hipStreamSynchronize(g.stream));
     for (int k = 0; k < GGML_HIP_KCLASS_COUNT; k++) {
@@ -601,12 +627,12 @@ void ggml_hip_timing_begin(void) {
     g.timing.on = true;
 }
 void ggml_hip_timing_end(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     g.timing.on = false;
     if (g.inited) HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     double total = 0;
     if (kclass >= 0 && kclass < GGML_HIP_KCLASS_COUNT) {
         for (auto &r : g.timing.recs[kclass]) {
@@ -622,8 +648,10 @@ void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *al
 void ggml_hip_set_option(const char *key, int value) {
     // Options are process-wide.  Slots that exist get the value now; a slot initialised later replays the log (ensure_init):
     // setting an option never creates a stream, a context or a buffer on a device this process has not used yet.
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (strcmp(key, "w16_release") != 0) g_opt_log[key] = value;  // an action, not a state
+    if (strcmp(key, "w16_release") != 0) {  // an action, not a state
+        std::lock_guard<std::recursive_mutex> lk(g_mu);
+        g_opt_log[key] = value;
+    }
     bool known = false;
     for_each_slot([&] {
         if (g.inited) {
@@ -766,7 +794,7 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
 // included, which rocprof's per-kernel durations exclude).  KV writes of the replay go to the last cache slot.
 int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
                               double *algo_bytes_per_replay) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    SlotLock lk;
     unsigned kind_mask = ~0u;
     if (kclass >= GGML_HIP_KKIND_BASE && kclass < GGML_HIP_KKIND_BASE + 5) {  // one kind of mat-vec launch alone
         kind_mask = 1u << (kclass - GGML_HIP_KKIND_BASE);

@@ -538,7 +538,7 @@ namespace {
 struct HomeDevice {
     int home = ggml_hip_get_main_device();
     void go(int d) const {
-        if (ggml_hip_get_main_device() != d) ggml_hip_set_main_device(d);
+        if (ggml_hip_get_main_device() != d) ggml_hip_bind_thread_device(d);  // this thread only: the process default stays
     }
     ~HomeDevice() { go(home); }
 };
@@ -558,14 +558,14 @@ void model_evaluate(llm_model *m, llm_session *s, const std::vector<llm::TokenId
         s->stage_sessions[i]->ensure_stage_rows(m->llama->hyperparameters.n_embd, toks.size());
     }
     for (size_t i = 0; i < G; i++) {
-        ggml_hip_set_main_device(m->devices[i]);
+        ggml_hip_bind_thread_device(m->devices[i]);
         llm::InferenceSession &ss = *s->stage_sessions[i];
         if (i > 0) {  // the residual [n_embd, N] f32 of the previous stage -> this stage's hand-off buffer, device to device
             void *dst = ggml_hip_tensor_device_ptr(ss.stage_in.ptr());
-            ggml_hip_set_main_device(m->devices[i - 1]);
+            ggml_hip_bind_thread_device(m->devices[i - 1]);
             const void *src = ggml_hip_tensor_device_ptr(s->stage_sessions[i - 1]->stage_out.ptr());
             ggml_hip_copy_between_devices(m->devices[i], dst, m->devices[i - 1], src, hop_bytes);
-            ggml_hip_set_main_device(m->devices[i]);
+            ggml_hip_bind_thread_device(m->devices[i]);
         }
         llm::OutputRequest none;
         m->stages[i]->evaluate(ss, toks, i + 1 == G ? req : none);
@@ -661,16 +661,20 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
             ps.layer_begin = bounds[i];
             ps.layer_end = bounds[i + 1];
             ps.main_device = slots[i];
-            ggml_hip_set_main_device(slots[i]);
+            ggml_hip_bind_thread_device(slots[i]);
             m->stages.push_back(new llm::Llama(h, ps, llm::TensorLoader(tensors, n_tensors)));
             m->devices.push_back(slots[i]);
         }
-        ggml_hip_set_main_device(home);
+        ggml_hip_bind_thread_device(home);
         m->llama = m->stages.back();
         return m;
     }
     llm::TensorLoader tl(tensors, n_tensors);
-    m->llama = new llm::Llama(h, p, std::move(tl));
+    llm::ModelParameters pu = p;
+    // a whole model made while a slot other than 0 is this thread's: its sessions stay on that slot (the reference's
+    // InferenceSession::new always initialises device 0 — it knows one device)
+    if (pu.main_device < 0 && m->device != 0) pu.main_device = m->device;
+    m->llama = new llm::Llama(h, pu, std::move(tl));
     return m;
 }
 // The layer ranges an in-process split over G device slots gets for the fractions `split` (ggml_cuda_set_tensor_split's
@@ -703,10 +707,10 @@ void llm_model_free(llm_model *m) {
     if (!m->stages.empty()) {
         const int home = ggml_hip_get_main_device();
         for (size_t i = 0; i < m->stages.size(); i++) {
-            ggml_hip_set_main_device(m->devices[i]);
+            ggml_hip_bind_thread_device(m->devices[i]);
             delete m->stages[i];
         }
-        ggml_hip_set_main_device(home);
+        ggml_hip_bind_thread_device(home);
         m->llama = nullptr;
     }
     if (m->llama) {
@@ -912,10 +916,10 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
     if (!m->stages.empty()) {
         const int home = ggml_hip_get_main_device();
         for (size_t i = 0; i < m->stages.size(); i++) {
-            ggml_hip_set_main_device(m->devices[i]);
+            ggml_hip_bind_thread_device(m->devices[i]);
             s->stage_sessions.push_back(m->stages[i]->start_session(c));
         }
-        ggml_hip_set_main_device(home);
+        ggml_hip_bind_thread_device(home);
         s->s = s->stage_sessions.back();
         s->devices = m->devices;
         return s;
@@ -931,10 +935,10 @@ void llm_session_free(llm_session *s) {
     if (!s->stage_sessions.empty()) {
         const int home = ggml_hip_get_main_device();
         for (size_t i = 0; i < s->stage_sessions.size(); i++) {
-            ggml_hip_set_main_device(s->devices[i]);
+            ggml_hip_bind_thread_device(s->devices[i]);
             delete s->stage_sessions[i];
         }
-        ggml_hip_set_main_device(home);
+        ggml_hip_bind_thread_device(home);
         s->s = nullptr;
     }
     if (s->s) {
@@ -1096,14 +1100,14 @@ size_t llm_session_kv(llm_session *s, int which, int set, void *buf, size_t nbyt
         for (size_t i = 0; i < s->stage_sessions.size() && off < nbytes; i++) {
             ggml::Tensor &t = which == 0 ? s->stage_sessions[i]->memory_k : s->stage_sessions[i]->memory_v;
             const size_t n = std::min(t.nbytes(), nbytes - off);
-            ggml_hip_set_main_device(s->devices[i]);
+            ggml_hip_bind_thread_device(s->devices[i]);
             if (set)
                 ggml_hip_tensor_set(t.ptr(), (char *)buf + off, 0, n);
             else
                 ggml_hip_tensor_get(t.ptr(), (char *)buf + off, 0, n);
             off += n;
         }
-        ggml_hip_set_main_device(home);
+        ggml_hip_bind_thread_device(home);
         return off;
     }
     ggml::Tensor &t = which == 0 ? s->s->memory_k : s->s->memory_v;

@@ -371,3 +371,21 @@ def test_cpu_backend_nodes_are_mirrored_to_host_and_gpu_nodes_are_not(G, O):
         assert np.array_equal(b.read_data(), 3 * x)
         assert np.array_equal(a.device_get(), 2 * x)
         assert not np.array_equal(a.read_data(), 2 * x)  # host copy untouched (uninitialised arena bytes)
+
+
+def test_graph_compute_bumps_ggml_perf_counters(G):
+    """ggml's tracing hook (crates/ggml/sys/src/lib.rs:253-255 on the tensor, :542-544 on the graph): every
+    ggml_graph_compute bumps perf_runs of the graph and of each node; the graph's perf_time_us accumulates the call's
+    wall time (upstream moves the time fields only in a GGML_PERF build, the counters always)."""
+    x = np.arange(64, dtype=np.float32).reshape(2, 32)
+    with G.Context(1 << 20) as ctx:
+        tx = ctx.tensor_from(x)
+        y = ctx.op_mul(ctx.op_rms_norm(tx, 1e-5), tx)
+        gr = ctx.graph().build_forward_expand(y)
+        for run in (1, 2, 3):
+            gr.compute()
+            c = gr.ptr.contents
+            assert c.perf_runs == run and c.perf_time_us >= 0
+            assert all(c.nodes[i].contents.perf_runs == run for i in range(c.n_nodes))
+            assert all(c.leafs[i].contents.perf_runs == 0 for i in range(c.n_leafs))
+        assert gr.ptr.contents.perf_time_us > 0
