@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the token after the timed loop")
     ap.add_argument("--roofline-steps", type=int, default=20)
-    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "feed"],
+    ap.add_argument("--split", type=int, default=2, help="--mode split: device slots ONE session is layer-split over (one process)")
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "feed", "split"],
                     help="decode = BASELINE configs[1] (the metric); prefill = configs[2], 512-token prompt batch on MFMA; "
                          "feed = InferenceSession::feed_prompt in chunks of --n-batch (profiling leg)")
     ap.add_argument("--n-batch", type=int, default=8, help="--mode feed: tokens per Model::evaluate (the reference's default is 8)")
@@ -570,6 +571,57 @@ def run_feed(args):
     model.free()
 
 
+def run_split(args):
+    """ONE InferenceSession layer-split over --split device slots of this process (the ggml-style split:
+    contiguous layer ranges, the f32 residual crosses with ggml_hip_copy_between_devices = a peer copy over xGMI between two
+    GPUs), single-stream greedy decode, against the unsplit session in the same process: the flat curve a layer split of
+    batch-1 decode gives, and what a hop costs.  With fewer visible GPUs than slots the slots are virtual (several on one
+    GPU, the hop a device copy) and the figure isolates the host + hand-off overhead of the split itself."""
+    from llm_amd import ggml, llama
+    L = ggml.lib()
+    G = max(1, args.split)
+    n_dev = L.ggml_hip_device_count()
+    virtual = n_dev < G
+    res = {}
+    for name, split in (("unsplit", 0), ("split", G)):
+        if split:
+            if virtual:
+                os.environ["GGML_HIP_VIRTUAL_DEVICES"] = str(G)
+            os.environ["GGML_HIP_LAYER_SPLIT"] = str(G)
+        hp, w, model, prep = build_model(args)
+        stages = model.stages()
+        sess = model.start_session(n_batch=8)
+        prompt = np.random.default_rng(42).integers(0, hp["n_vocab"], args.prompt).astype(np.int32)
+        sess.feed_prompt(prompt)
+        ids = [sess.infer_next_token() for _ in range(args.warmup)]
+        for sl in range(G if split else 1):
+            L.ggml_hip_bind_thread_device(sl)
+            L.ggml_hip_synchronize()
+        L.ggml_hip_bind_thread_device(0)
+        t0 = time.perf_counter()
+        ids += [sess.infer_next_token() for _ in range(args.steps)]
+        elapsed = time.perf_counter() - t0
+        res[name] = {"tokens_per_s": round(args.steps / elapsed, 2), "ms_per_token": round(elapsed / args.steps * 1e3, 4),
+                     "stages": stages, "ids": ids}
+        sess.free()
+        model.free()
+        os.environ.pop("GGML_HIP_LAYER_SPLIT", None)
+    os.environ.pop("GGML_HIP_VIRTUAL_DEVICES", None)
+    same = res["unsplit"]["ids"] == res["split"]["ids"]
+    hop_us = (res["split"]["ms_per_token"] - res["unsplit"]["ms_per_token"]) * 1e3 / max(G - 1, 1)
+    out = {"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}, ONE session layer-split over {G} device slots of one process",
+           "value": res["split"]["tokens_per_s"], "unit": "tokens/s", "n_gpus": min(n_dev, G), "device_slots": G,
+           "virtual_slots": virtual, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["split"]["ms_per_token"],
+           "higher_is_better": True, "scaling": "strong", "data": "synthetic",
+           "unsplit": {k: v for k, v in res["unsplit"].items() if k != "ids"},
+           "split": {k: v for k, v in res["split"].items() if k != "ids"},
+           "same_greedy_ids": same, "overhead_per_hop_us": round(hop_us, 1),
+           "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-stream greedy decode, {args.prompt}-token prompt, ctx 2048"}}
+    print(json.dumps(out), flush=True)
+    if not same:
+        raise SystemExit("bench.py --mode split: the split session produced different tokens")
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -582,6 +634,9 @@ def main():
         return
     if args.mode == "feed":
         run_feed(args)
+        return
+    if args.mode == "split":
+        run_split(args)
         return
     run_single(args)
 

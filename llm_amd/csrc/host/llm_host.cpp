@@ -175,7 +175,9 @@ class InferenceSession {
                 pre_.valid = true;
             }
             lap(3);
-            if (single && speculate) GraphExecutionPlan::execute_end();
+            // a middle stage of an in-process layer split has nothing for the host to read: its wait is left to the slot's next
+            // begin (finish_pending), so the host goes straight on to enqueue the next stage while this one runs
+            if (single && speculate && !defer_end) GraphExecutionPlan::execute_end();
             lap(4);
         }
         last_n_nodes = built.gf.raw()->n_nodes;
@@ -270,6 +272,7 @@ class InferenceSession {
 
    public:
     bool speculate = true;  // build the next single-token graph while the device runs (LLM_HOST_SPECULATE=0 disables)
+    bool defer_end = false;  // set for the stages of an in-process split that produce no logits (Llama::start_session)
 };
 
 // crates/llm-base/src/model/common.rs:6-59
@@ -373,6 +376,7 @@ class Llama {
                                                    hyperparameters.n_vocab);
         // stage hand-off buffers: persistent device tensors (like memory_k/v) that RCCL sends from / receives into
         if (!is_first() || !is_last()) s->make_stage_buffers(hyperparameters.n_embd, !is_first(), !is_last());
+        s->defer_end = params.main_device >= 0 && !is_last();
         return s;
     }
 
