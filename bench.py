@@ -125,9 +125,7 @@ MMQ_KERNELS = (  # stat key suffix -> what the launch is (ggml_hip_get_stat("mmq
                "quantized weights, v_mfma_f32_32x32x16_f16)"),
     ("dma_p8", "k_mmq_dma_p8 (persistent 128x128x64 GEMM, 8 waves, quantized blocks by LDS-DMA, in-LDS dequant to f16, "
                "v_mfma_f32_32x32x16_f16)"),
-    ("dma_p", "k_mmq_dma_p (persistent 128x128x64 GEMM, 4 waves, in-LDS dequant to f16)"),
-    ("dma", "k_mmq_dma (one workgroup per tile, in-LDS dequant to f16)"),
-    ("plain", "k_mmq (register-staged, in-LDS dequant to f16)"),
+    ("plain", "k_mmq (K/32 odd only: one workgroup per tile, register-staged, in-LDS dequant to f16)"),
     ("i8", "k_mmq_i8 (integer MFMA, exact block dots)"),
 )
 
@@ -193,7 +191,9 @@ def parity_check(args, hp, w, sess):
     nk0 = int(np.count_nonzero(kg != ko)) + int(np.count_nonzero(vg != vo))
     nk = int(np.count_nonzero(k2 != orcs[0].memory_k)) + int(np.count_nonzero(v2 != orcs[0].memory_v))
     bound = max(PARITY_EDGE, 2.0 * band)
-    ok = d <= bound and d <= max(floor, PARITY_EDGE) and nk0 <= 0.01 * 2 * Eg
+    # ... and no further than the math mode is (dropping the activation quantization altogether) — unless the oracle's own two
+    # summation orders already differ by more than that (6-bit weights: floor ~ band ~ 5e-2)
+    ok = d <= bound and d <= max(floor, PARITY_EDGE, band) and nk0 <= 0.01 * 2 * Eg
     out = {"max_over_std": float(f"{d:.3e}"), "rms_over_std": float(f"{rms:.3e}"),
            "argmax_equal": bool(int(np.argmax(got)) == int(np.argmax(ref))),
            "oracle_fwd_vs_rev_band_over_std": float(f"{band:.3e}"), "oracle_exact_vs_math_floor_over_std": float(f"{floor:.3e}"),

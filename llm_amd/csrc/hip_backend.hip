@@ -33,8 +33,7 @@
 #include "kernels/common.h"
 #include "kernels/mmvq.h"
 #include "kernels/mmq.h"
-#include "kernels/mmq_dma.h"
-#include "kernels/mmq_dmap.h"
+#include "kernels/mmq_plain.h"
 #include "kernels/mmq_dmap8.h"
 #include "kernels/mmq_w16.h"
 #include "kernels/mmq_w16_256.h"
@@ -197,7 +196,6 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     ws_reset();
     g_qact.valid = false;
     g_xf16.valid = false;
-    g_xq8.valid = false;
     g_xi8.valid = false;
     g_xk.valid = false;
     int async = 0;
@@ -707,34 +705,12 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_attn_split != value) drop_all_plans();
         g.opt_attn_split = value;
     }
-    else if (k == "prefetch") {
-        if (g.opt_prefetch != value) drop_all_plans();
-        g.opt_prefetch = value;
-    }
-    else if (k == "prefetch_wo") {
-        if (g.opt_prefetch_wo != value) drop_all_plans();
-        g.opt_prefetch_wo = value;
-    }
-    else if (k == "prefetch_wgs") {
-        if (g.opt_prefetch_wgs != value) drop_all_plans();
-        g.opt_prefetch_wgs = value;
-    }
-    else if (k == "prefetch_delay") {
-        if (g.opt_prefetch_delay != value) drop_all_plans();
-        g.opt_prefetch_delay = value;
-    }
     else if (k == "mmq_fuse")
         g.opt_mmq_fuse = value;
     else if (k == "spin_wait")
         g.opt_spin_wait = value;
     else if (k == "chain_k")
         g.opt_chain_k = std::min(64, std::max(0, value));
-    else if (k == "mmq_persist")
-        g.opt_mmq_persist = value;
-    else if (k == "mmq_waves")
-        g.opt_mmq_waves = value;
-    else if (k == "mmq_splits")
-        g.opt_mmq_splits = value;
     else if (k == "mmq_t256") {
         if (g.opt_mmq_t256 != value) drop_all_plans();
         g.opt_mmq_t256 = value;
@@ -780,8 +756,6 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         g.opt_mmq_min = value;
     else if (!strcmp(key, "mmq_splitk"))
         g.opt_mmq_splitk = value;
-    else if (!strcmp(key, "mmq_dma"))
-        g.opt_mmq_dma = value;
     else if (!strcmp(key, "mmq_i8"))
         g.opt_mmq_i8 = value;
     else

@@ -25,7 +25,7 @@
 // (s_waitcnt vmcnt(ring loads)), not for the ring (12.5 MB chip-wide: 2.7 us at HBM speed).
 #pragma once
 #include "decode_big8.h"
-#include "mmq_dma.h"
+#include "mmq.h"
 
 struct ColsArgs {
     DecMmvqArgs d;     // d.x: Q8 rows [ncols][nb] (planar), d.dst / d.res: row 0

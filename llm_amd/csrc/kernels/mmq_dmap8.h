@@ -1,17 +1,28 @@
-// mmq_dmap8.h — k_mmq_dma_p with EIGHT waves per workgroup (two per SIMD) on the same 128 x 128 x 64 tile and LDS layout.
+// mmq_dmap8.h — k_mmq_dma_p8: the persistent prompt GEMM on the QUANTIZED blocks (no resident f16 copy: HBM full, option
+// mmq_w16 = 0): 128 x 128 x 64 tile, eight waves per workgroup (two per SIMD), one workgroup per CU walking the
+// (tile x K split) items.  Every global operand byte — the f16 activations, the raw quant nibbles, the block scales — goes
+// global -> LDS by DMA (global_load_lds_dwordx4) into a ring of slots several k-stages ahead; the only waits are hand-placed
+// `s_waitcnt vmcnt(G)` (G = DMA instructions per stage and wave) in front of a raw s_barrier; the weights of the next stage
+// are dequantized slot -> VALU -> padded f16 tile (144-byte rows: conflict-free fragment reads) while the MFMAs of the
+// current one run.  The DMA ring, the dequantization pipeline and the matrix pipe keep running across item boundaries: the
+// fixed ~15 us a one-workgroup-per-tile launch paid per tile (dispatch, first DMA round trip, drain + result stores with the
+// matrix pipe idle; profiles/r02_prefill_shapes.txt) is paid once per launch.
 //
-// Why: with one wave per SIMD (mmq_dma.h: 140 KB of LDS per workgroup, one workgroup per CU) every stall of that wave —
-// the LDS round trip in front of each group of MFMAs, the barrier skew, the scalar work of the DMA issue — idles the
-// SIMD's matrix pipe; a k-stage takes ~1440 clocks for 512 clocks of MFMA (profiles/r02_prefill_shapes.txt: 0.6 us per
-// stage).  The LDS footprint is per workgroup, not per wave: the same ring serves 512 threads.  Each wave then owns a
-// 64 x 32 piece of the tile (2 MFMA accumulator tiles instead of 4: 8 MFMAs per stage and wave), dequantizes half a
-// block per stage, requests a quarter of the DMA traffic — and the SIMD has a second wave to issue from while the
-// first one waits.  Per output element the products are accumulated in the same order as in k_mmq_dma: bit-identical.
+// History (tests/tools/attic/mmq_dma.h, mmq_dmap.h — retired in round 4): k_mmq_dma was this tile with one workgroup per
+// tile and four waves, k_mmq_dma_p its persistent form.  With one wave per SIMD every stall of that wave — the LDS round trip
+// in front of each group of MFMAs, the barrier skew, the scalar work of the DMA issue — idled the SIMD's matrix pipe (a
+// k-stage took ~1440 clocks for 512 clocks of MFMA).  The LDS footprint is per workgroup, not per wave: the same ring serves
+// 512 threads; each wave owns a 64 x 32 piece of the tile (8 MFMAs per stage and wave), dequantizes half a block per stage,
+// requests a quarter of the DMA traffic — and the SIMD has a second wave to issue from while the first one waits.  Per output
+// element the products are accumulated in the same k order as in every other f16 GEMM here: bit-identical for equal K splits.
+//
+// Ring slot: X 128 tokens x 128 B, chunk-XOR-swizzled (the DMA writes lane-linear, so the swizzle is applied to each lane's
+// SOURCE address: physical chunk p of row r holds logical chunk p ^ ((r >> 1) & 7)); Wq [128 rows][2 blocks][16 B] (+ Wq2
+// for Q8_0), Wh [row][blk] u32 (Q5), Wd / Wm [row][2] f16 (one aligned 4-byte DMA per row: needs K/32 even).
 #pragma once
-#include "mmq_dmap.h"
+#include "mmq.h"
 
-// Ring slot of k_mmq_dma_p8, packed per weight type (mmq_dma.h reserves room for every part in every slot): the X tile, then only
-// the parts the type has.  The 4- and 5-bit types then fit FIVE slots next to the two dequantized W tiles in the CU's
+// Ring slot of k_mmq_dma_p8, packed per weight type: the X tile, then only the parts the type has.  The 4- and 5-bit types then fit FIVE slots next to the two dequantized W tiles in the CU's
 // 160 KB — four stages in flight instead of three (1.5 us of latency cover at 0.5 us per stage).  Measured: no change
 // (GEMMs 10.8 vs 10.7 ms per batch) — the waits the counters show (profiles/r02_prefill_mmq_p8_pmc.txt: waves spend 47 % of
 // their cycles waiting, matrix pipes busy 26 %) are not DMA landing.  Q8_0 (two quant planes) stays at four.
@@ -59,15 +70,9 @@ __global__ void __launch_bounds__(512, 1) k_mmq_dma_p8(const MmqArgs a, int n_it
     auto load_item = [&](int w, Item &it) {
         const int y = w / tiles_total, b = w - y * tiles_total;
         int tm, tn;
-        if (a.xcd_by_n) {
-            const int tiles_m = tiles_total / a.tiles_n;
-            tn = b / tiles_m;
-            tm = b - tn * tiles_m;
-        } else {
-            const int t = xcd_tile_id(b, tiles_total);
-            tm = t / a.tiles_n;
-            tn = t - tm * a.tiles_n;
-        }
+        const int t = xcd_tile_id(b, tiles_total);
+        tm = t / a.tiles_n;
+        tn = t - tm * a.tiles_n;
         QWeight w_ = a.w;
         float *dst = a.dst;
         int64_t ldd = a.ldd;

@@ -3,13 +3,13 @@
 // ggml_compute_forward_mul_mat for quantized src0 (crates/models/llama/src/lib.rs:194-352; op builder
 // crates/ggml/src/context.rs:314-324) computes, per 32-wide block, an exact integer dot of the weight codes with the
 // int8-requantized activations and scales it in f32.  v_mfma_i32_32x32x32_i8 has K = 32: ONE instruction = the 32 x 32
-// integer block dots of 32 weight rows x 32 tokens for one block column, exact in i32.  So, unlike k_mmq / k_mmq_dma
+// integer block dots of 32 weight rows x 32 tokens for one block column, exact in i32.  So, unlike the f16 GEMMs
 // (which round d*q of both operands to f16 and accumulate in the f16 pipe: 1.1e-3*scale), this kernel's only
 // difference from ggml's CPU result is the f32 association of the per-block terms — the mat-vec kernels' bound.
 //
 //   tile     128 tokens x 128 weight rows per 256-thread workgroup, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
 //   k stage  2 blocks (64 weights); every operand byte goes HBM -> LDS by DMA into a ring of I8_RING slots, RING - 1
-//            stages ahead (hand-placed counted waits, one raw s_barrier per stage, as in mmq_dma.h)
+//            stages ahead (hand-placed counted waits, one raw s_barrier per stage, as in mmq_dmap8.h)
 //   A (X)    int8 activations [token][32 B per block], 16-byte chunks XOR-swizzled on the DMA source address so that the
 //            fragment reads (32 token rows, 64 B apart) are conflict-free; lanes 0-31 take elements 0-15 of the block,
 //            lanes 32-63 elements 16-31 (any k order works as long as both operands use the same one)

@@ -1,7 +1,7 @@
 // mmq_w16.h — the prompt GEMM on RESIDENT f16 copies of the quantized weights.
 //
 // 288 GB of HBM hold a second copy of a model's 2-D weights: the f16 values w16 = f16(d * (q - zero) [+ m]) that
-// k_mmq_dma dequantizes into LDS in every k-stage of every tile of every batch, computed ONCE (k_dequant_w16, at the
+// k_mmq_dma_p8 dequantizes into LDS in every k-stage of every tile of every batch, computed ONCE (k_dequant_w16, at the
 // first prompt batch of a model: 13.2 GB for LLaMA-7B, 130 GB for 65B next to its 69 GB of Q8_0).  The decode mat-vecs
 // keep streaming the quantized blocks (they are HBM-bound: 4.5 bits per weight is what makes them fast); prompt batches
 // are compute-bound, and what bounded k_mmq_dma_p8 was not the matrix pipe but the dependency chain around the
@@ -11,7 +11,7 @@
 // k_mmq_w16_p8: the persistent eight-wave kernel of mmq_dmap8.h with BOTH operands arriving by LDS-DMA — the W tile is
 // just a second X tile in the ring slot (same 128-byte rows, same XOR swizzle on the source address): no dequantization,
 // no W double buffer, no raw-slot reads, and nothing a stage needs is produced by the stage before it.  Same tile, same
-// k order, same MFMA sequence per output element as k_mmq_dma: bit-identical results.
+// k order, same MFMA sequence per output element as k_mmq_dma_p8: bit-identical results.
 #pragma once
 #include "mmq_dmap8.h"
 
@@ -61,15 +61,9 @@ __global__ void __launch_bounds__(512, 1) k_mmq_w16_p8(const MmqArgs a, int n_it
     auto load_item = [&](int w, Item &it) {
         const int y = w / tiles_total, b = w - y * tiles_total;
         int tm, tn;
-        if (a.xcd_by_n) {
-            const int tiles_m = tiles_total / a.tiles_n;
-            tn = b / tiles_m;
-            tm = b - tn * tiles_m;
-        } else {
-            const int t = xcd_tile_id(b, tiles_total);
-            tm = t / a.tiles_n;
-            tn = t - tm * a.tiles_n;
-        }
+        const int t = xcd_tile_id(b, tiles_total);
+        tm = t / a.tiles_n;
+        tn = t - tm * a.tiles_n;
         const _Float16 *w16 = (const _Float16 *)a.w.w16;
         float *dst = a.dst;
         int64_t ldd = a.ldd, M = a.w.M;

@@ -17,7 +17,7 @@
 //  * LDS image as in k_mmq_w16_p8: 128-byte rows (64 k), 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the SOURCE
 //    address (the DMA writes lane-linear), conflict-free ds_read_b128 fragments.
 //  * Persistent: one workgroup per CU walks (tile x K-split) items; the DMA cursor runs on into the next item.
-// Same f16 values, same k order and the same MFMA per 16-wide k step as k_mmq_w16_p8 / k_mmq_dma: for equal K splits the
+// Same f16 values, same k order and the same MFMA per 16-wide k step as k_mmq_w16_p8 / k_mmq_dma_p8: for equal K splits the
 // results are bit-identical (tests/test_prompt_plan_gpu.py).
 #pragma once
 #include "mmq_w16.h"

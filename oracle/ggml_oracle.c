@@ -579,6 +579,13 @@ static void dequantize_row_q8_K(const block_q8_K *x, float *y, int k) {
 /* ---- Q2_K / Q3_K / Q5_K.  Decoders and dot products restate upstream k_quants.c (scalar branches);
  * the ENCODERS below are simple min/max (abs-max) fits that produce VALID blocks for tests — not upstream's iterative
  * make_qkx / make_q3 searches (oracle/SEMANTICS.md). ---------------------------------------------------------------- */
+/* A second legal summation order of every block dot (orc_set_block_order(1)): the blocks / super-blocks of a row are walked
+ * downwards instead of upwards.  ggml's scalar and SIMD branches differ from each other by re-associations of this size; the
+ * difference between the two orders is the yardstick ("band") the model-level parity checks measure in the same run. */
+static int g_rev = 0;
+EXPORT void orc_set_block_order(int reverse) { g_rev = reverse; }
+#define BLOCK_LOOP(i, nb) for (int ii_ = 0, i = g_rev ? (nb)-1 : 0; ii_ < (nb); ii_++, i += g_rev ? -1 : 1)
+
 /* Q2_K: x = d*(sc&15)*q - dmin*(sc>>4), 16 sub-blocks of 16, q in 0..3.  Element e: n = e/128, j = (e%128)/32, h = (e%32)/16:
  * byte qs[32n + 16h + e%16], bits 2j..2j+1; scale byte scales[8n + 2j + h]. */
 static void quantize_row_q2_K(const float *x, block_q2_K *y, int k) {
@@ -640,7 +647,7 @@ static void dequantize_row_q2_K(const block_q2_K *x, float *y, int k) {
 static float vec_dot_q2_K_q8_K(int n, const block_q2_K *x, const block_q8_K *y) {
     const int nb = n / QK_K;
     float sumf = 0.0f;
-    for (int i = 0; i < nb; ++i) {
+    BLOCK_LOOP(i, nb) {
         const uint8_t *q2 = x[i].qs;
         const int8_t *q8 = y[i].qs;
         const uint8_t *sc = x[i].scales;
@@ -772,7 +779,7 @@ static float vec_dot_q3_K_q8_K(int n, const block_q3_K *x, const block_q8_K *y) 
     int32_t aux32[8];
     memset(sums, 0, sizeof(sums));
     float sumf = 0;
-    for (int i = 0; i < nb; ++i) {
+    BLOCK_LOOP(i, nb) {
         const uint8_t *q3 = x[i].qs, *hm = x[i].hmask;
         const int8_t *q8 = y[i].qs;
         memset(aux32, 0, sizeof(aux32));
@@ -885,7 +892,7 @@ static float vec_dot_q5_K_q8_K(int n, const block_q5_K *x, const block_q8_K *y) 
     int32_t aux32[8];
     memset(sums, 0, sizeof(sums));
     float sumf = 0;
-    for (int i = 0; i < nb; ++i) {
+    BLOCK_LOOP(i, nb) {
         const uint8_t *q4 = x[i].qs, *hm = x[i].qh;
         const int8_t *q8 = y[i].qs;
         memset(aux32, 0, sizeof(aux32));
@@ -935,7 +942,7 @@ static float vec_dot_q4_K_q8_K(int n, const block_q4_K *x, const block_q8_K *y) 
     int32_t aux32[8];
     memset(sums, 0, sizeof(sums));
     float sumf = 0;
-    for (int i = 0; i < nb; ++i) {
+    BLOCK_LOOP(i, nb) {
         const uint8_t *q4 = x[i].qs;
         const int8_t *q8 = y[i].qs;
         memset(aux32, 0, sizeof(aux32));
@@ -978,7 +985,7 @@ static float vec_dot_q6_K_q8_K(int n, const block_q6_K *x, const block_q8_K *y) 
     int32_t aux32[8];
     memset(sums, 0, sizeof(sums));
     float sumf = 0;
-    for (int i = 0; i < nb; ++i) {
+    BLOCK_LOOP(i, nb) {
         const uint8_t *ql = x[i].ql, *qh = x[i].qh;
         const int8_t *q8 = y[i].qs;
         memset(aux32, 0, sizeof(aux32));
@@ -1165,9 +1172,6 @@ EXPORT size_t orc_quantize(int type, const float *src, void *dst, int n, int k, 
 /* Order in which a row's blocks are added into sumf.  0 = ascending (ggml's scalar code).  1 = descending:
  * NOT a ggml mode — a yardstick for how much a legal re-association of the f32 block sum (which ggml's own
  * AVX2 path, 8 lanes + horizontal add, also performs) moves the results of a given model. */
-static int g_rev = 0;
-EXPORT void orc_set_block_order(int reverse) { g_rev = reverse; }
-#define BLOCK_LOOP(i, nb) for (int ii_ = 0, i = g_rev ? (nb)-1 : 0; ii_ < (nb); ii_++, i += g_rev ? -1 : 1)
 
 static float vec_dot_q4_0_q8_0(int n, const block_q4_0 *x, const block_q8_0 *y) {
     const int nb = n / QK;

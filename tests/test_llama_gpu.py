@@ -88,7 +88,7 @@ def test_logits_match_oracle_prompt_and_decode(G, O, wtype):
 @pytest.mark.parametrize("i8", [0, 1])
 def test_prefill_batch_on_mfma_matches_oracle(G, O, wtype, i8):
     """A 48-token prompt evaluated as ONE batch (n_batch=64): every quantized mul_mat runs on an MFMA GEMM — the
-    default f16 one (kernels/mmq_dma.h, mmq.h) or, with option mmq_i8 = 1, the integer one (kernels/mmq_i8.h: ggml's
+    default f16 ones (kernels/mmq_w16_256.h, mmq_w16.h, mmq_dmap8.h; mmq_plain.h for an odd K/32) or, with option mmq_i8 = 1, the integer one (kernels/mmq_i8.h: ggml's
     exact block dots; held to I8_RMS, half the f16 bound).  Besides f32 summation order, that path rounds each dequantized weight and activation to f16
     (2^-11 unit roundoff), ~100x the f32 noise, so rounding-edge flips of downstream int8 activation quants are
     the norm rather than the exception in the 128-wide test model.  Stated tolerance (relative to std(logits)):

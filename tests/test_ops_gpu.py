@@ -63,7 +63,7 @@ def test_mul_mat_q_prefill_mfma_matches_oracle(G, O, wtype, shape, N, i8):
     """N >= 32 tokens on the matrix cores, both prompt GEMMs.
     mmq_i8 = 1 and K/32 even: the INTEGER GEMM (kernels/mmq_i8.h, v_mfma_i32_32x32x32_i8): ggml's exact block dots,
     scaled and accumulated in f32 — the mat-vec bound, 2e-5 * scale.
-    mmq_i8 = 0 (the default: it is the faster one) or K/32 odd: the f16 GEMM (kernels/mmq_dma.h, mmq.h),
+    mmq_i8 = 0 (the default: it is the faster one) or K/32 odd: the f16 GEMM (kernels/mmq_w16*.h, mmq_dmap8.h; mmq_plain.h for an odd K/32),
     which rounds each dequantized weight and activation to f16 (unit roundoff 2^-11 each):
         |got - exact| <= 2 * 2^-11 * sum_k |w||x|   (worst case; stated bound 1.1e-3 * scale), RMS <= 1e-4 * scale."""
     M, K = shape

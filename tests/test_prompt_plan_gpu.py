@@ -132,37 +132,6 @@ def test_prompt_plan_stage_of_a_layer_split(G):
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
-@pytest.mark.parametrize("cfg", ["wide", "splitk"])
-def test_persistent_gemm_is_bit_identical_to_one_workgroup_per_tile(G, wtype, cfg):
-    """k_mmq_dma_p (one workgroup per CU walks the tiles, the DMA ring runs across tile boundaries) against k_mmq_dma (one
-    workgroup per tile): same tile arithmetic, so the same bits — node-by-node executor (atomics for K splits) and plan
-    (partial tiles), batches of 1..3 token tiles, more tiles than CUs in none of them (that is covered at full size by
-    tests/test_fullsize_gpu.py against the oracle)."""
-    from llm_amd import llama, synth
-    if cfg == "splitk" and wtype not in (2, 7):
-        pytest.skip("two formats for the K-split shapes")
-    hp, w = synth.make_llama({"wide": WIDE, "splitk": SPLITK}[cfg], wtype, seed=6)
-    model = llama.Llama(hp, w, context_size=512)
-    toks = np.random.default_rng([wtype, 5]).integers(0, hp["n_vocab"], 330).astype(np.int32)
-    chunks = [toks[0:40], toks[40:170], toks[170:330]]
-    res = {}
-    for persist, waves in ((1, 8), (1, 4), (0, 4)):  # 8 waves per workgroup (mmq_dmap8.h), 4 (mmq_dmap.h), one workgroup per tile
-        G.set_option("mmq_persist", persist)
-        G.set_option("mmq_waves", waves)
-        for plan in (1, 0):
-            res[persist, waves, plan] = _run(G, model, chunks, plan)
-    G.set_option("mmq_persist", 1)
-    G.set_option("mmq_waves", 8)
-    for plan in (1, 0):
-        for variant in ((1, 8), (1, 4)):
-            (a, ka, va), (b, kb, vb) = res[variant + (plan,)], res[0, 4, plan]
-            for la, lb in zip(a, b):
-                assert np.array_equal(la, lb), (cfg, wtype, plan, variant, float(np.max(np.abs(la - lb))))
-            assert np.array_equal(ka, kb) and np.array_equal(va, vb)
-    model.free()
-
-
 @pytest.mark.parametrize("wtype", [2, 7])
 def test_prompt_plan_rows_longer_than_512_positions(G, wtype):
     """Score rows of more than 512 positions take the softmax kernel's multi-pass branch (row not held in registers), the

@@ -32,9 +32,8 @@ for name, M, K, sp in SHAPES:
         x = ctx.tensor_from(X, G.TYPE_F32, (K, N)).set_name("x")
         y = ctx.op_mul_mat(w, x)
         g = ctx.graph().build_forward_expand(y)
-        line = f"{name:9s} M={M:6d} K={K:6d} N={N} splits={sp}:"
+        line = f"{name:9s} M={M:6d} K={K:6d} N={N} splits(rule)={sp}:"
         for label, opts in VARIANTS:
-            G.set_option("mmq_splits", sp)
             for k, v in opts.items():
                 G.set_option(k, v)
             best = 1e9
@@ -47,6 +46,5 @@ for name, M, K, sp in SHAPES:
                     best = min(best, ms)
             for k in opts:
                 G.set_option(k, RESET[k])
-            G.set_option("mmq_splits", 0)
             line += f"\n      {label:15s} {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF"
         print(line, flush=True)
