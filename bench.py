@@ -387,6 +387,16 @@ def run_single(args):
     rs = max(args.roofline_steps, 1)
     kinds = {"qkv": 0, "wo": 1, "gate_up": 2, "down": 3, "lm_head": 4}
     per_kind = {}
+    if stat("plan_tokens") == h0["plan_tokens"]:  # e.g. GGML_HIP_PLAN_K=0: the node-by-node executor ran, nothing to replay
+        print(json.dumps({"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}", "value": round(tok_s, 2),
+                          "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": DTYPES[args.wtype], "parity_check": parity, "data": "synthetic",
+                          "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode on the "
+                                                 "node-by-node executor (no decode plan matched or the plan option is off)"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+        sess.free()
+        return
     for name, k in kinds.items():
         kms, kn, kb = ggml.bench_plan_class(ggml.KKIND_BASE + k, rs)
         per_kind[name] = {"launches": kn, "bytes_per_launch": int(kb / max(kn, 1)),
@@ -407,8 +417,12 @@ def run_single(args):
             traffic_from = ("profiles/" + tp + ": a COMMITTED figure from separate rocprofv3 --pmc passes of this kernel "
                             "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run")
             break
-    roofline = {"bound": "hbm", "kernel": "k_mmvq_big<Q4_0, EPI_GATE, XSRC_NORM> (w1|w3 mat-vec, rms_norm + Q8 staging and "
-                                          "silu(w1 x)*(w3 x) epilogue fused; 32 launches per token)",
+    is_k = args.wtype.endswith("_k")
+    kernel_label = (f"k_mmvq_k / k_mmvq_k2<{args.wtype.upper()}, 1 column> (K plan: w1 and w3 as one launch each, Q8_K activations "
+                    f"staged in LDS; {2 * nl} launches per token)") if is_k else (
+                    f"k_mmvq_big<{args.wtype.upper()}, EPI_GATE, XSRC_NORM> (w1|w3 mat-vec, rms_norm + Q8 staging and "
+                    f"silu(w1 x)*(w3 x) epilogue fused; {nl} launches per token)")
+    roofline = {"bound": "hbm", "kernel": kernel_label,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_from": traffic_from,
                 "avg_launch_us": dom["us_per_launch"], "algo_bytes_per_launch": dom["bytes_per_launch"],
@@ -444,9 +458,12 @@ def run_single(args):
                       "n_past_at_start": args.prompt + args.warmup, "parallelism": "1 GPU",
                       "weights_in_hbm_before_timing": True, "host_split_per_token": host_split,
                       "decode_launches": {"qkv_and_attention_in_one_launch_tokens": int(fused_tokens), "of_timed_tokens": int(args.steps),
-                                          "per_layer": "k_qkv_attn (wq|wk|wv mat-vec on G - n_head workgroups + one attention workgroup per head "
+                                          "per_layer": "K plan, 13 launches: norm+Q8_K, wq, wk, wv, rope+K/V store, k_attn_decode, Q8_K, wo+residual, "
+                                                       "norm+Q8_K, w1, w3, silu*mul+Q8_K, w2+residual" if is_k else
+                                                       "k_qkv_attn (wq|wk|wv mat-vec on G - n_head workgroups + one attention workgroup per head "
                                                        "in the same launch, rows handed over as epoch-tagged 8-byte granules) -> wo -> w1|w3 -> w2"
                                                        if fused_tokens else "wq|wk|wv -> k_attn_decode -> wo -> w1|w3 -> w2",
+                                          "k_plan_tokens": stat("kplan_tokens") if is_k else None,
                                           "note": "roofline.per_kind.qkv is the fused launch when it ran: its bytes include the K/V read of the "
                                                   "attention, its time the hand-off wait and the attention tail"},
                       "long_context": long_ctx,

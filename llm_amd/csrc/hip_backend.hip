@@ -50,6 +50,7 @@
 #include "kernels/decode_big8.h"
 #include "kernels/mmq_cols.h"
 #include "kernels/decode_attn_split.h"
+#include "kernels/kquant_plan.h"
 #include "kernels/prompt.h"
 #include "kernels/prompt_attn.h"
 
@@ -734,6 +735,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_plan_prompt != value) drop_all_plans();
         g.opt_plan_prompt = value;
     }
+    else if (k == "plan_k") {
+        if (g.opt_plan_k != value) drop_all_plans();
+        g.opt_plan_k = value;
+    }
     else if (k == "plan_multi") {
         if (g.opt_plan_multi != value) drop_all_plans();
         g.opt_plan_multi = value;
@@ -797,7 +802,7 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     HIP_CHECK(hipEventCreate(&b));
     if (g.opt_graph) {
         HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-        plan_launch_all(p, 1u << kclass, &st, kind_mask);
+        plan_launch_decode(p, 1u << kclass, &st, kind_mask);
         HIP_CHECK(hipStreamEndCapture(g.stream, &gr));
         HIP_CHECK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
         HIP_CHECK(hipGraphLaunch(ex, g.stream));  // warm
@@ -805,9 +810,9 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
         for (int i = 0; i < replays; i++) HIP_CHECK(hipGraphLaunch(ex, g.stream));
         HIP_CHECK(hipEventRecord(b, g.stream));
     } else {  // GGML_HIP_GRAPH=0 (e.g. under rocprofv3, whose kernel tracing crashes on graph launches here)
-        plan_launch_all(p, 1u << kclass, &st, kind_mask);
+        plan_launch_decode(p, 1u << kclass, &st, kind_mask);
         HIP_CHECK(hipEventRecord(a, g.stream));
-        for (int i = 0; i < replays; i++) plan_launch_all(p, 1u << kclass, nullptr, kind_mask);
+        for (int i = 0; i < replays; i++) plan_launch_decode(p, 1u << kclass, nullptr, kind_mask);
         HIP_CHECK(hipEventRecord(b, g.stream));
     }
     HIP_CHECK(hipStreamSynchronize(g.stream));

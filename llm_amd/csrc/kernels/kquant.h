@@ -133,7 +133,33 @@ struct MmvqKArgs {
     KAct x;
     float *dst;
     int64_t ldd;  // dst column stride in floats
+    const float *res;  // nullable: dst = row sum + res[row] (the residual add that follows wo / w2; one column only)
+    // up to three matrices of ONE type sharing the activations in one launch (the K plan's wq|wk|wv and w1|w3): rows
+    // [0, w.M) belong to w / dst, [w.M, w.M + wb.M) to wb / dst_b, the rest to wc / dst_c.  nseg <= 1: single matrix.
+    int nseg;
+    KWeight wb, wc;
+    float *dst_b, *dst_c;
 };
+// global row of a multi-matrix launch -> (matrix, row inside it, its dst); wave-uniform
+__device__ __forceinline__ void mmvq_k_select(const MmvqKArgs &a, int64_t row, KWeight &w, int64_t &lrow, float *&dst) {
+    w = a.w;
+    lrow = row;
+    dst = a.dst;
+    if (a.nseg > 1 && row >= a.w.M) {
+        if (a.nseg > 2 && row >= a.w.M + a.wb.M) {
+            w = a.wc;
+            lrow = row - a.w.M - a.wb.M;
+            dst = a.dst_c;
+        } else {
+            w = a.wb;
+            lrow = row - a.w.M;
+            dst = a.dst_b;
+        }
+    }
+}
+__device__ __forceinline__ int64_t mmvq_k_rows(const MmvqKArgs &a) {
+    return a.w.M + (a.nseg > 1 ? a.wb.M : 0) + (a.nseg > 2 ? a.wc.M : 0);
+}
 
 template <int KT>
 struct KStep {  // what one lane holds of one step: its chunk + the super-block's scales
@@ -170,24 +196,29 @@ __global__ void __launch_bounds__(256) k_mmvq_k(const MmvqKArgs a) {
     const int c = lane & 7, sbl = lane >> 3;
     const int nsteps = (nsb + 7) >> 3;
     const int64_t row0 = (int64_t)blockIdx.x * 4 + wave, rstride = (int64_t)gridDim.x * 4;
-    auto load = [&](KStep<KT> &st, int64_t row, int s) {
+    const int64_t Mt = mmvq_k_rows(a);
+    auto load = [&](KStep<KT> &st, int64_t grow, int s) {
+        KWeight w;
+        int64_t row;
+        float *dst_;
+        mmvq_k_select(a, grow, w, row, dst_);
         int sb = s * 8 + sbl;
         sb = sb < nsb ? sb : nsb - 1;  // lanes past the row end re-read the last super-block and are masked below
         const int64_t g = row * nsb + sb;
-        st.q = __builtin_nontemporal_load((const u32x4 *)(a.w.qs + g * 128 + c * 16));
-        st.sc = *(const u32x4 *)(a.w.sc + g * 16);
+        st.q = __builtin_nontemporal_load((const u32x4 *)(w.qs + g * 128 + c * 16));
+        st.sc = *(const u32x4 *)(w.sc + g * 16);
         if constexpr (KT == KT_Q4_K) {
-            st.dm = *(const uint32_t *)(a.w.d + g * 2);
+            st.dm = *(const uint32_t *)(w.d + g * 2);
         } else {
-            const u32x2 h = __builtin_nontemporal_load((const u32x2 *)(a.w.aux + (g * 8 + c) * 2));
+            const u32x2 h = __builtin_nontemporal_load((const u32x2 *)(w.aux + (g * 8 + c) * 2));
             st.hA = h[0];
             st.hB = h[1];
-            st.dm = (uint32_t) * (const uint16_t *)(a.w.d + g);
+            st.dm = (uint32_t) * (const uint16_t *)(w.d + g);
         }
     };
     KStep<KT> cur, nxt;
-    if (row0 < a.w.M) load(cur, row0, 0);
-    for (int64_t row = row0; row < a.w.M; row += rstride) {
+    if (row0 < Mt) load(cur, row0, 0);
+    for (int64_t row = row0; row < Mt; row += rstride) {
         float acc[NCOLS];
 #pragma unroll
         for (int n = 0; n < NCOLS; n++) acc[n] = 0.0f;
@@ -195,7 +226,7 @@ __global__ void __launch_bounds__(256) k_mmvq_k(const MmvqKArgs a) {
             // request the next step (of this row, or the first of the wave's next row)
             const bool last = s + 1 == nsteps;
             const int64_t nrow = last ? row + rstride : row;
-            if (nrow < a.w.M) load(nxt, nrow, last ? 0 : s + 1);
+            if (nrow < Mt) load(nxt, nrow, last ? 0 : s + 1);
             const int sb = s * 8 + sbl;
             if (sb < nsb) {
                 if constexpr (KT == KT_Q4_K) {
@@ -243,7 +274,13 @@ __global__ void __launch_bounds__(256) k_mmvq_k(const MmvqKArgs a) {
 #pragma unroll
         for (int n = 0; n < NCOLS; n++) {
             const float v = wave_sum_f32(acc[n]);
-            if (lane == 0) a.dst[(int64_t)n * a.ldd + row] = v;
+            if (lane == 0) {
+                KWeight w_;
+                int64_t lrow;
+                float *dst_;
+                mmvq_k_select(a, row, w_, lrow, dst_);
+                dst_[(int64_t)n * a.ldd + lrow] = a.res ? v + a.res[lrow] : v;
+            }
         }
     }
 }

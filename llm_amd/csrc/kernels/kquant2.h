@@ -120,14 +120,19 @@ __global__ void __launch_bounds__(256) k_mmvq_k2(const MmvqKArgs a) {
     __syncthreads();
     const int g = lane & 15, sbl = lane >> 4;
     const int nsteps = (nsb + 3) >> 2;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.w.M; row += (int64_t)gridDim.x * 4) {
+    const int64_t Mt = mmvq_k_rows(a);
+    for (int64_t grow = (int64_t)blockIdx.x * 4 + wave; grow < Mt; grow += (int64_t)gridDim.x * 4) {
+        KWeight w;
+        int64_t row;
+        float *dst;
+        mmvq_k_select(a, grow, w, row, dst);
         float acc[NCOLS];
 #pragma unroll
         for (int n = 0; n < NCOLS; n++) acc[n] = 0.0f;
         for (int s = 0; s < nsteps; s++) {
             const int sb = s * 4 + sbl;
             if (sb < nsb) {
-                const KGroup<KT> r = k2_load<KT>(a.w, row * nsb + sb, g);
+                const KGroup<KT> r = k2_load<KT>(w, row * nsb + sb, g);
 #pragma unroll
                 for (int n = 0; n < NCOLS; n++) {
                     const i32x4 x = *(const i32x4 *)(s_q + (size_t)n * K + sb * 256 + 16 * g);
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(256) k_mmvq_k2(const MmvqKArgs a) {
 #pragma unroll
         for (int n = 0; n < NCOLS; n++) {
             const float v = wave_sum_f32(acc[n]);
-            if (lane == 0) a.dst[(int64_t)n * a.ldd + row] = v;
+            if (lane == 0) dst[(int64_t)n * a.ldd + row] = a.res ? v + a.res[row] : v;
         }
     }
 }

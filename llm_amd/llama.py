@@ -133,12 +133,13 @@ class Llama:
             b = name.encode()
             self._names.append(b)
             descs[i].name = b
-            descs[i].type = ggml.TYPE_F32 if ne1 is None else hp["wtype"]
+            wt = hp.get("wtypes", {}).get(name, hp["wtype"])  # per-tensor types of a mixed file (*_K_M: some tensors Q6_K)
+            descs[i].type = ggml.TYPE_F32 if ne1 is None else wt
             descs[i].n_dims = 1 if ne1 is None else 2
             descs[i].ne[0] = ne0
             descs[i].ne[1] = 1 if ne1 is None else ne1
             arr = weights[name]
-            exp = ne0 * 4 if ne1 is None else ggml.row_bytes(hp["wtype"], ne0) * ne1
+            exp = ne0 * 4 if ne1 is None else ggml.row_bytes(wt, ne0) * ne1
             assert arr.nbytes == exp, (name, arr.nbytes, exp)
             descs[i].data = arr.ctypes.data
         h = _HP(hp["n_vocab"], hp["n_embd"], hp.get("n_mult", 256), hp["n_head"], hp["n_head_kv"], hp["n_layer"],

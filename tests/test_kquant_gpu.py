@@ -128,8 +128,8 @@ TINY_K = dict(n_vocab=256, n_embd=256, n_head=4, n_head_kv=4, n_layer=2, n_rot=6
 @pytest.mark.parametrize("wtype", KTYPES)
 def test_llama_with_k_quant_weights_matches_oracle(G, O, wtype):
     """A two-layer LLaMA whose 2-D weights are all of one K type through the session API: prompt chunks and decode
-    steps against the oracle on the same K/V state.  K-quant graphs take the generic executor (the fused decode plan
-    matches the 32-wide block types only): the statistic says so."""
+    steps against the oracle on the same K/V state.  The prompt chunks take the generic executor (the statistic says so), the
+    single-token steps the K plan (tests/test_kquant_plan_gpu.py)."""
     from llm_amd import llama, synth
     rng = np.random.default_rng([wtype, 321])
     hp = dict(TINY_K)
