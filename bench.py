@@ -14,6 +14,7 @@ crosses each boundary by RCCL send/recv; N independent sequences are kept in fli
 work per step is constant ("weak"): value = tokens of all sequences / time.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -75,43 +76,88 @@ def weight_bytes_per_token(hp, wtype_bytes, blck=32):
     return params // blck * wtype_bytes, params
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), None = unlimited or unknown: a box that
+    shows 256 CPUs but is capped at 32 explains a team-size calibration that peaks at 32 threads."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, hp, w, budget_s):
     """ggml's CPU path as the reference's build selects it (crates/ggml/sys/build.rs:46-62: -mavx2 -mfma -mf16c), restated
     with the AVX2 intrinsics themselves (oracle mode 3: _mm256_maddubs_epi16 / _mm256_madd_epi16 block dots, 8-lane fmadd,
     _mm256_round_ps activation quantizer, F16C attention dots; bit-identical to the order restatement the CPU tests pin),
     OpenMP over rows where ggml uses its thread pool, timed on this host's cores.  Falls back to the scalar restatement
     (mode 0, kind "port") on a host without AVX2."""
+    from llm_amd import synth
     from oracle import oracle
     mode = 3 if oracle.have_avx2() else 0
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     ncpu = len(os.sched_getaffinity(0))
-    orc = oracle.Llama(hp, w, 256)
     tok = np.array([1], np.int32)
+    L = oracle.lib()
+    L.orc_first_touch_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    L.orc_pin_threads.restype = ctypes.c_int
+    shapes = synth.tensor_shapes(hp)
+
+    def placed(thr):
+        """The model with its OpenMP team pinned (spread over the host's CPUs) and every matrix copied so that the thread that
+        will read a row is the one that first touched its pages (NUMA first-touch; on a two-socket host the un-placed copy made
+        the team SLOWER beyond 16 threads in round 3).  Untimed: ggml's mmap'd weights settle the same way after a few tokens."""
+        L.orc_set_num_threads(thr)
+        L.orc_pin_threads()
+        w2 = {}
+        for name, a in w.items():
+            ne1 = shapes[name][1]
+            if ne1 is None:
+                w2[name] = a
+                continue
+            c = np.empty_like(a)  # untouched pages
+            L.orc_first_touch_copy(c.ctypes.data, a.ctypes.data, ne1, a.nbytes // ne1)
+            w2[name] = c
+        return oracle.Llama(hp, w2, 256)
+
     best, tried = None, {}
     spent = 0.0
-    # calibrate the team size on one token each (containers often expose more cpus than they may use)
+    # calibrate the team size: one warm-up token (page faults of the K/V cache, thread start) + one timed token each
     for thr in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu} | {min(ncpu, 8)}):
-        oracle.lib().orc_set_num_threads(thr)
+        o = placed(thr)
+        o.evaluate(tok, mode=mode)
         t = time.perf_counter()
-        orc.evaluate(tok, mode=mode)
+        o.evaluate(tok, mode=mode)
         dt = time.perf_counter() - t
-        spent += dt
+        spent += 2 * dt
         tried[thr] = round(dt, 3)
         if best is None or dt < best[1]:
             best = (thr, dt)
-        if spent > 0.4 * budget_s:
+        del o
+        if spent > 0.5 * budget_s:
             break
     thr, dt1 = best
-    oracle.lib().orc_set_num_threads(thr)
-    n = int(max(1, min(40, (budget_s - spent) / max(dt1, 1e-3))))
+    orc = placed(thr)
+    orc.evaluate(tok, mode=mode)
+    n = int(max(1, min(60, (budget_s - spent) / max(dt1, 1e-3))))
     t = time.perf_counter()
     for _ in range(n):
         orc.evaluate(tok, mode=mode)
     el = time.perf_counter() - t
+    L.orc_unpin_threads()
+    L.orc_set_num_threads(min(ncpu, 16))
     return {"value": round(n / el, 3), "unit": "tokens/s", "cores": thr, "kind": "port-avx2" if mode == 3 else "port",
             "sample": f"{n} single-token decode steps of the same {args.model} {args.wtype} weights at short context "
-                      f"(oracle mode {mode}, OpenMP, {thr} threads = the fastest of the calibrated team sizes)",
+                      f"(oracle mode {mode}, OpenMP, {thr} pinned threads = the fastest of the calibrated team sizes; "
+                      "weights first-touched by the threads that read them)",
             "calibration_s_per_token": {str(k): v for k, v in tried.items()}, "host_cpus": ncpu,
+            "host_cpu_quota": cpu_quota(),
             "note": ("ggml's AVX2 code path restated with the same intrinsics (block dots by maddubs/madd, fmadd lanes, F16C), "
                      "bit-identical to oracle mode 2; not ggml's binary (its C sources are an empty submodule in the reference "
                      "tree), so thread pool and cache blocking are this port's") if mode == 3 else
@@ -527,9 +573,11 @@ def run_prefill(args):
         step()
     L.ggml_hip_synchronize()
     elapsed = time.perf_counter() - t0
+    c0 = mmq_counts(L)
     L.ggml_hip_timing_begin()
     step()
     L.ggml_hip_timing_end()
+    label, counts = mmq_label(c0, mmq_counts(L))
     cls = {}
     for name, k in (("mmq_mfma", ggml.KCLASS_MMQ_MFMA), ("mmvq", ggml.KCLASS_MMVQ), ("attn", ggml.KCLASS_ATTN),
                     ("other", ggml.KCLASS_OTHER)):
@@ -537,7 +585,8 @@ def run_prefill(args):
         cls[name] = (ms, launches, work)
     ms, launches, flops = cls["mmq_mfma"]
     achieved = flops / 1e12 / (ms / 1e3) if ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "k_mmq_dma_p8 (persistent quantized GEMM, in-LDS dequant to f16, v_mfma_f32_32x32x16_f16)",
+    roofline = {"bound": "mfma", "kernel": label + " — wq|wk|wv, wo, w1|w3, w2 per layer + lm_head",
+                "kernel_launch_counts": {k: v for k, v in counts.items() if v},
                 "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches_per_step": launches,
@@ -549,7 +598,8 @@ def run_prefill(args):
            "value": round(n * args.steps / elapsed, 1), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": "f16 MFMA, f32 accumulate (weights dequantized in LDS; activations Q8-requantized then f16)",
+           "dtype": "f16 x f16 MFMA, f32 accumulate (weights f16(d*q) from the resident copy or dequantized in LDS; activations "
+                    "Q8-requantized as ggml does, then f16(d*q))",
            "data": "synthetic",
            "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} {n}-token prefill batch "
                                   f"(BASELINE configs[2]) at n_past=1, ctx 2048, f16 KV", "parallelism": "1 GPU",

@@ -339,3 +339,75 @@ def _continue_decode(pipe, n_seq, steps):
     if rank == world - 1:
         pipe._last_tokens = [out[s][-1] for s in range(n_seq)]
     return out
+
+
+def selftest():
+    """`python -m llm_amd.pipeline --selftest` (under torchrun for more than one rank): first contact with the node's GPUs made
+    boring — before anything is timed, every rank prints what it drives, forms the RCCL communicator INSIDE the library exactly
+    as the bench does (unique id over gloo, ggml_hip_comm_init), reports `comm_ranks_seen_by_rccl`, and moves a known pattern
+    once around the ring with ggml_hip_comm_sendrecv on the backend stream (rank r -> r + 1, 32 KiB = the 65B residual), checking
+    every byte.  Exit code 0 only if every rank saw world ranks and its payload arrived intact."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    n_dev = torch.cuda.device_count()
+    os.environ["GGML_HIP_DEVICE"] = str(local_rank % max(n_dev, 1))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from . import ggml
+    L = ggml.lib()
+    info = {"rank": rank, "world": world, "visible_gpus": n_dev, "device": int(os.environ["GGML_HIP_DEVICE"]),
+            "library": L.ggml_hip_version().decode()}
+    idb = torch.zeros(ggml.COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        buf = (ctypes.c_ubyte * ggml.COMM_ID_BYTES)()
+        L.ggml_hip_comm_unique_id(buf)
+        idb = torch.tensor(list(buf), dtype=torch.uint8)
+    dist.broadcast(idb, src=0)
+    raw = (ctypes.c_ubyte * ggml.COMM_ID_BYTES)(*idb.tolist())
+    seen = L.ggml_hip_comm_init(rank, world, raw)
+    info["comm_ranks_seen_by_rccl"] = int(seen)
+    ok = seen == world
+    if ok:
+        n = 32 * 1024
+        src = np.frombuffer(np.random.default_rng(1000 + rank).bytes(n), dtype=np.uint8).copy()
+        want = np.frombuffer(np.random.default_rng(1000 + (rank - 1) % world).bytes(n), dtype=np.uint8)
+        # device buffers from torch (same device as the library's backend); the hop itself runs on the library's stream
+        dev = torch.device("cuda", int(os.environ["GGML_HIP_DEVICE"]))
+        t_src = torch.from_numpy(src).to(dev)
+        t_dst = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        d_src, d_dst = ctypes.c_void_p(t_src.data_ptr()), ctypes.c_void_p(t_dst.data_ptr())
+        t0 = time.perf_counter()
+        L.ggml_hip_comm_sendrecv(d_src, (rank + 1) % world, d_dst, (rank - 1) % world, n)
+        L.ggml_hip_synchronize()
+        info["ring_hop_first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            L.ggml_hip_comm_sendrecv(d_src, (rank + 1) % world, d_dst, (rank - 1) % world, n)
+        L.ggml_hip_synchronize()
+        info["ring_hop_us"] = round((time.perf_counter() - t0) / 20 * 1e6, 1)
+        got = t_dst.cpu().numpy()
+        ok = bool(np.array_equal(got, want))
+        info["payload_intact"] = ok
+        L.ggml_hip_comm_destroy()
+    allok = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(allok, op=dist.ReduceOp.MIN)
+    infos = [None] * world
+    dist.all_gather_object(infos, info)
+    if rank == 0:
+        print(json.dumps({"selftest": "passed" if int(allok.item()) else "FAILED", "ranks": infos}), flush=True)
+    dist.destroy_process_group()
+    return 0 if int(allok.item()) else 1
+
+
+if __name__ == "__main__":
+    import sys
+    if "--selftest" in sys.argv:
+        sys.exit(selftest())
+    print("usage: [torchrun --nproc-per-node G] python -m llm_amd.pipeline --selftest", file=sys.stderr)
+    sys.exit(2)

@@ -43,8 +43,12 @@
  *
  * Build: make -C oracle   (gcc -O3 -mavx2 -mfma -mf16c -fopenmp; flags of sys/build.rs:46-62)
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* sched_setaffinity: the CPU-baseline leg pins its OpenMP team (orc_pin_threads) */
+#endif
 #include <float.h>
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1954,6 +1958,48 @@ EXPORT void orc_llama_eval(const orc_llama *m, const int32_t *tokens, int N, int
     free(inpL); free(cur); free(q); free(k); free(v); free(kq); free(kqv); free(att); free(inpFF); free(t1); free(t3);
 }
 
+/* bench.py's cpu_baseline leg only: a copy of a weight matrix whose pages are FIRST TOUCHED by the threads that will read them
+ * (the static row partition of orc_mul_mat's row loop, same team size), so that on a multi-socket host every thread streams
+ * its rows from its own NUMA node — what ggml's mmap'd weights settle into after the first tokens.  dst: untouched memory. */
+EXPORT void orc_first_touch_copy(void *dst, const void *src, int64_t rows, int64_t row_bytes) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < rows; m++) memcpy((uint8_t *)dst + (size_t)m * (size_t)row_bytes, (const uint8_t *)src + (size_t)m * (size_t)row_bytes, (size_t)row_bytes);
+}
+/* bench.py's cpu_baseline leg only: pins the threads of the current OpenMP team to distinct CPUs spread evenly over the CPUs
+ * the process may use (both sockets of a two-socket host), so that the first-touch placement above stays valid for the timed
+ * tokens; orc_unpin_threads gives every team thread (the caller included) its original mask back.  Returns the CPUs found. */
+static cpu_set_t g_orig_mask;
+static int g_orig_saved = 0;
+EXPORT int orc_pin_threads(void) {
+    if (!g_orig_saved) {
+        CPU_ZERO(&g_orig_mask);
+        if (sched_getaffinity(0, sizeof g_orig_mask, &g_orig_mask) != 0) return 0;
+        g_orig_saved = 1;
+    }
+    static int cpus[CPU_SETSIZE];
+    int n = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &g_orig_mask)) cpus[n++] = c;
+    if (n == 0) return 0;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int t = 0, T = 1;
+#endif
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cpus[(int)((int64_t)t * n / T)], &one);
+        (void)sched_setaffinity(0, sizeof one, &one);
+    }
+    return n;
+}
+EXPORT void orc_unpin_threads(void) {
+    if (!g_orig_saved) return;
+#pragma omp parallel
+    { (void)sched_setaffinity(0, sizeof g_orig_mask, &g_orig_mask); }
+}
 EXPORT int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
