@@ -133,27 +133,31 @@ struct MmvqKArgs {
     KAct x;
     float *dst;
     int64_t ldd;  // dst column stride in floats
-    const float *res;  // nullable: dst = row sum + res[row] (the residual add that follows wo / w2; one column only)
+    const float *res;  // nullable: dst = row sum + res (same layout as dst: the residual add that follows wo / w2; single matrix)
     // up to three matrices of ONE type sharing the activations in one launch (the K plan's wq|wk|wv and w1|w3): rows
     // [0, w.M) belong to w / dst, [w.M, w.M + wb.M) to wb / dst_b, the rest to wc / dst_c.  nseg <= 1: single matrix.
     int nseg;
     KWeight wb, wc;
     float *dst_b, *dst_c;
+    int64_t ldd_b, ldd_c;
 };
-// global row of a multi-matrix launch -> (matrix, row inside it, its dst); wave-uniform
-__device__ __forceinline__ void mmvq_k_select(const MmvqKArgs &a, int64_t row, KWeight &w, int64_t &lrow, float *&dst) {
+// global row of a multi-matrix launch -> (matrix, row inside it, its dst and column stride); wave-uniform
+__device__ __forceinline__ void mmvq_k_select(const MmvqKArgs &a, int64_t row, KWeight &w, int64_t &lrow, float *&dst, int64_t &ldd) {
     w = a.w;
     lrow = row;
     dst = a.dst;
+    ldd = a.ldd;
     if (a.nseg > 1 && row >= a.w.M) {
         if (a.nseg > 2 && row >= a.w.M + a.wb.M) {
             w = a.wc;
             lrow = row - a.w.M - a.wb.M;
             dst = a.dst_c;
+            ldd = a.ldd_c;
         } else {
             w = a.wb;
             lrow = row - a.w.M;
             dst = a.dst_b;
+            ldd = a.ldd_b;
         }
     }
 }
@@ -199,9 +203,9 @@ __global__ void __launch_bounds__(256) k_mmvq_k(const MmvqKArgs a) {
     const int64_t Mt = mmvq_k_rows(a);
     auto load = [&](KStep<KT> &st, int64_t grow, int s) {
         KWeight w;
-        int64_t row;
+        int64_t row, ldd_;
         float *dst_;
-        mmvq_k_select(a, grow, w, row, dst_);
+        mmvq_k_select(a, grow, w, row, dst_, ldd_);
         int sb = s * 8 + sbl;
         sb = sb < nsb ? sb : nsb - 1;  // lanes past the row end re-read the last super-block and are masked below
         const int64_t g = row * nsb + sb;
@@ -276,10 +280,10 @@ __global__ void __launch_bounds__(256) k_mmvq_k(const MmvqKArgs a) {
             const float v = wave_sum_f32(acc[n]);
             if (lane == 0) {
                 KWeight w_;
-                int64_t lrow;
+                int64_t lrow, ldd_;
                 float *dst_;
-                mmvq_k_select(a, row, w_, lrow, dst_);
-                dst_[(int64_t)n * a.ldd + lrow] = a.res ? v + a.res[lrow] : v;
+                mmvq_k_select(a, row, w_, lrow, dst_, ldd_);
+                dst_[(int64_t)n * ldd_ + lrow] = a.res ? v + a.res[(int64_t)n * ldd_ + lrow] : v;
             }
         }
     }

@@ -123,9 +123,9 @@ __global__ void __launch_bounds__(256) k_mmvq_k2(const MmvqKArgs a) {
     const int64_t Mt = mmvq_k_rows(a);
     for (int64_t grow = (int64_t)blockIdx.x * 4 + wave; grow < Mt; grow += (int64_t)gridDim.x * 4) {
         KWeight w;
-        int64_t row;
+        int64_t row, ldd;
         float *dst;
-        mmvq_k_select(a, grow, w, row, dst);
+        mmvq_k_select(a, grow, w, row, dst, ldd);
         float acc[NCOLS];
 #pragma unroll
         for (int n = 0; n < NCOLS; n++) acc[n] = 0.0f;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_mmvq_k2(const MmvqKArgs a) {
 #pragma unroll
         for (int n = 0; n < NCOLS; n++) {
             const float v = wave_sum_f32(acc[n]);
-            if (lane == 0) dst[(int64_t)n * a.ldd + row] = a.res ? v + a.res[row] : v;
+            if (lane == 0) dst[(int64_t)n * ldd + row] = a.res ? v + a.res[(int64_t)n * ldd + row] : v;
         }
     }
 }

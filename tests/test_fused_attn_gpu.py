@@ -124,3 +124,67 @@ def test_fused_launch_is_the_default_at_7b_width_and_matches_the_pair(G, O):
     for (ta, la), (tb, lb) in zip(res[0][0], res[1][0]):
         assert ta == tb and np.array_equal(la, lb)
     assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
+
+
+LONG_SHAPES = {
+    "tiny": (SHAPES["tiny"], 1024),
+    "gqa": (SHAPES["gqa"], 1024),
+    "d128gqa": (SHAPES["d128gqa"], 2048),
+}
+
+
+@pytest.mark.parametrize("shape", ["tiny", "gqa", "d128gqa"])
+@pytest.mark.parametrize("wtype", [2, 7])
+def test_split_attention_as_one_launch_is_bit_identical_to_its_three_launches(G, shape, wtype):
+    """Long contexts (from 512 positions on): scores / softmax + V.P / combine of the position-split decode attention as ONE
+    launch (k_attn_split_one, kernels/decode_attn_split.h: scores and partial outputs handed over as tagged granules between the
+    workgroups of a head, the last workgroup to arrive combines) against the three launches it replaces (option attn_one = 0):
+    same float operations in the same order, so logits and K/V must be BIT-IDENTICAL — at context lengths on and off the 64-position
+    range boundaries, right below the context size, and through a hipGraph replay, an eager run and the device-sampled chain."""
+    from llm_amd import llama, synth
+    hp0, ctx = LONG_SHAPES[shape]
+    hp, w = synth.make_llama(hp0, wtype, seed=21)
+    model = llama.Llama(hp, w, context_size=ctx)
+    rng = np.random.default_rng([wtype, len(shape)])
+    toks = rng.integers(0, hp["n_vocab"], ctx).astype(np.int32)
+    starts = [513, 577, 700, ctx - 70, ctx - 9]  # decode 8 tokens from each (the last run ends on the final position)
+
+    def run(one, graph=1):
+        G.set_option("attn_one", one)
+        G.set_option("graph", graph)
+        outs = []
+        try:
+            s = model.start_session(n_batch=512)
+            pos = 0
+            for st in starts:
+                s.feed_prompt(toks[pos:st])
+                b0 = _stat(G, "attn_split_tokens")
+                for i in range(8):
+                    outs.append(s.evaluate(toks[st + i:st + i + 1])[-1].copy())
+                assert _stat(G, "attn_split_tokens") - b0 == 8
+                pos = st + 8
+            k, v = s.get_kv()
+            s.free()
+        finally:
+            G.set_option("attn_one", 1)
+            G.set_option("graph", 1)
+        return outs, k, v
+
+    a, ka, va = run(1)
+    b, kb, vb = run(0)
+    c, kc, vc = run(1, graph=0)
+    assert _stat(G, "fused_attn_timeouts") == 0
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb) and np.array_equal(ka, kc) and np.array_equal(va, vc)
+    # the device-sampled greedy chain crosses the same launches
+    ids = {}
+    for one in (1, 0):
+        G.set_option("attn_one", one)
+        s = model.start_session(n_batch=512)
+        s.feed_prompt(toks[:600])
+        ids[one] = s.infer_tokens_device(12)
+        s.free()
+    G.set_option("attn_one", 1)
+    assert list(ids[1]) == list(ids[0])
+    model.free()
