@@ -456,7 +456,7 @@ def run_single(args):
     achieved = dom["GBps"]
     wb, nparams = weight_bytes_per_token(hp, ggml.BLOCK_BYTES[hp["wtype"]], ggml.BLOCK_ELEMS[hp["wtype"]])
     traffic, traffic_from = None, None
-    for tp in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tp in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tp)
         if os.path.exists(tpath) and args.model == "7b" and args.wtype == "q4_0":
             traffic = json.load(open(tpath))["gate_up"]["hbm_bytes_per_launch"]
