@@ -18,9 +18,12 @@
 #pragma once
 #include "decode.h"
 
-#define ATTN_SPLIT_MIN 512  // positions (n_past + 1) from which the split path is used (7B Q4_0 on MI355X: the split
-                            // token costs 1.69 ms from 200 to 1000 positions and 1.80 at 1900; the single launch 1.54 at
-                            // 200, 1.62 at 330, 1.70-1.74 at 460-700, 1.83 at 1000, 2.12 at 1900)
+#define ATTN_SPLIT_MIN 512        // positions (n_past + 1) from which the split path replaces k_attn_decode (round 2; the K plan)
+#define ATTN_SPLIT_MIN_FUSED 768  // ... from which it replaces k_qkv_attn.  LLaMA-7B Q4_0 on one MI355X, ms per token
+                            // (tests/tools/ctx_sweep.py, profiles/r04_ctx_sweep.txt): k_qkv_attn (one workgroup per head, register
+                            // window of 512 positions, later ones streamed) 1.35 up to 480 positions, 1.50 at 560, 1.53 at 700,
+                            // 1.64 at 900; wq|wk|wv + k_attn_split_one 1.60-1.65 from 300 to 1900 positions: they cross near 850.
+                            // (Round 2, k_attn_decode against three split launches: 512, see the top of this file.)
 
 struct AttnSplitArgs {
     const float *q;

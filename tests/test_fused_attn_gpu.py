@@ -152,6 +152,7 @@ def test_split_attention_as_one_launch_is_bit_identical_to_its_three_launches(G,
     def run(one, graph=1):
         G.set_option("attn_one", one)
         G.set_option("graph", graph)
+        G.set_option("attn_split", 512)  # the split path from 512 positions on (default: 768), so that the range edges below are met
         outs = []
         try:
             s = model.start_session(n_batch=512)
@@ -168,6 +169,7 @@ def test_split_attention_as_one_launch_is_bit_identical_to_its_three_launches(G,
         finally:
             G.set_option("attn_one", 1)
             G.set_option("graph", 1)
+            G.set_option("attn_split", 1)
         return outs, k, v
 
     a, ka, va = run(1)
@@ -179,6 +181,7 @@ def test_split_attention_as_one_launch_is_bit_identical_to_its_three_launches(G,
     assert np.array_equal(ka, kb) and np.array_equal(va, vb) and np.array_equal(ka, kc) and np.array_equal(va, vc)
     # the device-sampled greedy chain crosses the same launches
     ids = {}
+    G.set_option("attn_split", 512)
     for one in (1, 0):
         G.set_option("attn_one", one)
         s = model.start_session(n_batch=512)
@@ -186,5 +189,6 @@ def test_split_attention_as_one_launch_is_bit_identical_to_its_three_launches(G,
         ids[one] = s.infer_tokens_device(12)
         s.free()
     G.set_option("attn_one", 1)
+    G.set_option("attn_split", 1)
     assert list(ids[1]) == list(ids[0])
     model.free()

@@ -246,7 +246,7 @@ def test_k_plan_takes_prompt_chunks_of_up_to_8_tokens(G, O, wtype):
 
 
 def test_k_plan_at_long_context_uses_the_split_attention(G, O):
-    """From 512 positions on the K plan's attention is the position-split one-launch kernel (k_attn_split_one): against the
+    """On long contexts (option attn_split: from 768 positions by default, 512 here) the K plan's attention is the position-split one-launch kernel (k_attn_split_one): against the
     node-by-node executor and the oracle at ~600 and ~1000 positions of a 1024-position context."""
     from llm_amd import llama
     hp, w = _model(O, TINY_K, 12, 57)
@@ -256,6 +256,7 @@ def test_k_plan_at_long_context_uses_the_split_attention(G, O):
     res = {}
     for plan_k in (1, 0):
         G.set_option("plan_k", plan_k)
+        G.set_option("attn_split", 512)  # the split path from 512 positions on (default: 768)
         try:
             s = model.start_session(n_batch=512)
             outs = []
@@ -268,6 +269,7 @@ def test_k_plan_at_long_context_uses_the_split_attention(G, O):
             s.free()
         finally:
             G.set_option("plan_k", 1)
+            G.set_option("attn_split", 1)
         res[plan_k] = (outs, split)
     assert res[1][1] == 10 and res[0][1] == 0
     assert _stat(G, "fused_attn_timeouts") == 0

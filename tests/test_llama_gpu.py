@@ -399,8 +399,8 @@ def test_snapshot_restores_a_session_bit_exactly(G, O, kv):
 
 @pytest.mark.parametrize("wtype", [2, 7])
 def test_long_context_split_attention_matches_single_launch_and_oracle(G, O, wtype):
-    """From 512 positions on the decode plan splits every head's attention over positions (three launches,
-    kernels/decode_attn_split.h).  Same rounding points as the single launch (row max, f16 exp, exact f64 sum, f16
+    """On long contexts (from 768 positions; 790 here) the decode plan splits every head's attention over positions
+    (kernels/decode_attn_split.h).  Same rounding points as the single launch (row max, f16 exp, exact f64 sum, f16
     probabilities); only the f32 association of the V.P sum differs."""
     from llm_amd import llama, synth
     hp, w = synth.make_llama(synth.TINY, wtype, seed=7)
@@ -630,6 +630,7 @@ def test_gqa_split_attention_and_layer_split(G, O):
     model = llama.Llama(hp, w, context_size=1024)
     toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 600).astype(np.int32)
     nxt = np.random.default_rng(10).integers(0, hp["n_vocab"], 4).astype(np.int32)
+    G.set_option("attn_split", 512)  # 600 positions: below the default switch (768)
     s = model.start_session(n_batch=8)
     s.feed_prompt(toks)
     orc = O.Llama(hp, w, 1024)
@@ -643,6 +644,7 @@ def test_gqa_split_attention_and_layer_split(G, O):
         ref = orc.evaluate(np.array([t], np.int32), mode=O.ref_mode())[-1]
         assert float(np.max(np.abs(got - ref)) / ref.std()) <= EDGE
     assert _stat(G, "attn_split_tokens") - before == len(nxt)
+    G.set_option("attn_split", 1)
     s.free()
     model.free()
     # two stages
