@@ -702,6 +702,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         }
         if (g.timeline) HIP_CHECK(hipMemsetAsync(g.timeline, 0, g.timeline_bytes, g.stream));
     }
+    else if (k == "fuse_heads") {
+        if (g.opt_fuse_heads != value) drop_all_plans();
+        g.opt_fuse_heads = value;
+    }
     else if (k == "attn_one") {
         if (g.opt_attn_one != value) drop_all_plans();
         g.opt_attn_one = value;

@@ -19,6 +19,7 @@
 #include "decode.h"
 
 #define ATTN_SPLIT_MIN 512        // positions (n_past + 1) from which the split path replaces k_attn_decode (round 2; the K plan)
+#define FUSE_HEADS_MIN 576        // positions from which k_qkv_attn takes 2 / 4 attention workgroups per head (window 512 + one 64-slab streamed)
 #define ATTN_SPLIT_MIN_FUSED 768  // ... from which it replaces k_qkv_attn.  LLaMA-7B Q4_0 on one MI355X, ms per token
                             // (tests/tools/ctx_sweep.py, profiles/r04_ctx_sweep.txt): k_qkv_attn (one workgroup per head, register
                             // window of 512 positions, later ones streamed) 1.35 up to 480 positions, 1.50 at 560, 1.53 at 700,

@@ -20,6 +20,7 @@
 // difference, f64 sum, f16 probabilities, f32 V.P, Q8 re-quantization for wo.
 #pragma once
 #include "decode_big.h"
+#include "decode_attn_split.h"  // attn_one_wait and the hand-off protocol of k_attn_split_one
 
 struct FusedAttnArgs {
     const __half *mem_k, *mem_v;  // + layer offset, layouts of DecMmvqArgs
@@ -35,6 +36,10 @@ struct FusedAttnArgs {
     int *sumq;
     long long *ts;  // optional timeline slot (as k_attn_decode)
     unsigned *err;  // raised when a wait gave up
+    // S > 1: S attention workgroups per head, workgroup s takes positions [512 s, 512 (s + 1)) (attn_consumer_split below)
+    int S, layer;
+    unsigned long long *mx_g, *sum_g, *part_g;  // hand-off granules of k_attn_split_one (decode_attn_split.h): [n_head][S], [..][S][2], [..][S][D]
+    unsigned *cnt;                              // [n_head] arrival counters
 };
 
 __device__ __forceinline__ f16x2 u32_as_h2(unsigned u) { return __builtin_bit_cast(f16x2, u); }
@@ -261,13 +266,247 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Contexts beyond the 512-position register window: S attention workgroups per head instead of one (S = 2 up to 1024
+// positions, 4 up to 2048), still inside the wq|wk|wv launch.  Workgroup (h, s) owns positions [512 s, 512 (s + 1)): it
+// requests exactly those K / V rows at entry (they stream under the weights), waits for the token's Q (and, if the token's own
+// position falls into its range, K / V) granules, and then runs k_attn_split_one's protocol with its S - 1 peers
+// (decode_attn_split.h): range maximum -> row maximum, range sum of the f16-rounded exps -> row sum (exact in any order), partial
+// V.P -> the last workgroup of the head to arrive adds the partials (s ascending) and re-quantizes for wo.  ggml's rounding points
+// are kept; only the f32 association of the V.P sum differs from the one-workgroup form (as for every split of a head).
+// ---------------------------------------------------------------------------------------------------
+template <bool F16_D>
+__device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, const int h, const int s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t C = f.C, Egqa = f.Egqa;
+    const int D = f.D, S = f.S;
+    constexpr int WIN = 512;
+    float *s_s = (float *)smem;               // WIN scores, then exps, of the range
+    float *s_o = s_s + WIN;                   // D floats (unused here, keeps the layout of attn_consumer's dynamic LDS in mind)
+    _Float16 *s_p = (_Float16 *)(s_o + 128);  // WIN probabilities
+    __shared__ float s_red[16];
+    __shared__ double s_redd[16];
+    __shared__ float s_mx;
+    __shared__ double s_tot;
+    __shared__ int s_last;
+    __shared__ __attribute__((aligned(16))) unsigned s_new[3 * 64];
+    const int hk = h / f.n_rep;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_past = f.prm->n_past;
+    const unsigned epoch = *f.epoch;
+    const unsigned tag = (epoch * 64u + (unsigned)(f.layer & 63)) | 0x80000000u;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int NPRE = 8;
+    const int T = n_past + 1;
+    const int t0 = s * WIN;
+    const int n = T > t0 ? (T - t0 < WIN ? T - t0 : WIN) : 0;  // positions of this range (0: the context ends before it)
+    const int n8 = (n + 7) & ~7;
+    const bool own = n_past >= t0 && n_past < t0 + WIN;        // the token's own position lies in this range
+    const int g = tid >> 4, gl = tid & 15;
+    const int d0 = gl * 8;
+    const bool act = d0 < D;
+    const __half *kbase = f.mem_k + (int64_t)hk * D + d0;
+    f16x8 kv[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int t = t0 + g + 64 * u;
+        kv[u] = zero8;
+        if (act && t < n_past) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+    }
+    const int cv = wave * 8 + (lane >> 3), pj = (lane & 7) * 8;
+    const bool vact = cv < D;
+    const __half *vbase = f.mem_v + ((int64_t)hk * D + cv) * C + t0 + pj;
+    f16x8 vv[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        vv[u] = zero8;
+        if (vact && 64 * u + pj < n8) vv[u] = *(const f16x8 *)(vbase + 64 * u);  // t0 + n8 <= C: the chunk lies inside the cache
+    }
+    // ---- Q first: the mat-vec workgroups take their units in ascending order, so the token's Q rows are published in the first
+    //      third of the launch, its K and V rows at the end.  Everything that needs only Q happens NOW, under the weight stream:
+    //      the scores of the cached positions and the exchange of their range maxima.
+    auto wait_rows = [&](int which /* 0 Q, 1 K, 2 V */) {  // one wave: the D/2 granules of this head's row -> s_new[which * 64 ..]
+        const int half_d = D >> 1;
+        const int base = which == 0 ? h * half_d : which == 1 ? f.k_pair0 + hk * half_d : f.v_pair0 + hk * half_d;
+        const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
+        const long long c0 = (long long)wall_clock64();
+        unsigned long long x;
+        for (;;) {
+            x = gran_load(gp);
+            const bool ok = (unsigned)(x >> 32) == epoch;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((long long)wall_clock64() - c0 > 5000000) {
+                if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        s_new[which * 64 + lane] = (unsigned)x;
+    };
+    if (wave == 0) wait_rows(0);
+    for (int i = tid; i < WIN; i += 1024) s_p[i] = (_Float16)0.0f;
+    __syncthreads();
+    f16x2 qh2[4];
+    if (act) {
+        const u32x4 q4 = *(const u32x4 *)(s_new + (d0 >> 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++) qh2[j] = u32_as_h2(q4[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) qh2[j] = f16x2{(_Float16)0.0f, (_Float16)0.0f};
+    }
+    // scores of the range's CACHED positions (t < n_past) -> LDS; their maximum -> peers
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        if (64 * u >= n) break;  // uniform
+        const int tl = g + 64 * u;
+        float sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sc = __builtin_amdgcn_fdot2(f16x2{kv[u][2 * j], kv[u][2 * j + 1]}, qh2[j], sc, false);
+        sc = g16_sum_f32(sc);
+        if (t0 + tl < n_past) {
+            sc *= f.scale;
+            if (gl == 0) s_s[tl] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    }
+    mx = wave_max_f32(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    if (wave == 0) {
+        float m = lane < 16 ? s_red[lane] : -INFINITY;
+        m = wave_max_f32(m);
+        if (lane == 0) gran_store(f.mx_g + (int64_t)h * S + s, tag, __float_as_uint(m));  // -inf: no cached position here
+        float pm = -INFINITY;
+        if (lane < S) pm = __uint_as_float((unsigned)attn_one_wait(f.mx_g + (int64_t)h * S + lane, tag, f.err));
+        pm = wave_max_f32(pm);
+        if (lane == 0) s_mx = pm;
+    } else if (wave == 1) {
+        // ---- the token's K row: EVERY workgroup of the head takes it and scores the new position itself, so the row maximum
+        //      needs no second exchange behind the mat-vec; its V row only where the position lives
+        wait_rows(1);
+    } else if (wave == 2 && own) {
+        wait_rows(2);
+    }
+    __syncthreads();
+    {
+        f16x8 knew = zero8;
+        if (act) {
+            const u32x4 k4 = *(const u32x4 *)(s_new + 64 + (d0 >> 1));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f16x2 kk = u32_as_h2(k4[j]);
+                knew[2 * j] = kk[0];
+                knew[2 * j + 1] = kk[1];
+            }
+        }
+        float sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sc = __builtin_amdgcn_fdot2(f16x2{knew[2 * j], knew[2 * j + 1]}, qh2[j], sc, false);
+        sc = g16_sum_f32(sc) * f.scale;  // every 16-lane group holds the same value
+        mx = fmaxf(s_mx, sc);
+        if (own && tid == 0) s_s[n_past - t0] = sc;
+    }
+    __syncthreads();
+    // ---- f16-rounded exps of the range, range sum -> peers, row sum (exact in any order)
+    double sum = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        const float e = round_f16(expf(round_f16(s_s[i] - mx)));
+        s_s[i] = e;
+        sum += (double)e;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) s_redd[wave] = sum;
+    __syncthreads();
+    if (wave == 0) {
+        if (lane == 0) {
+            double loc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) loc += s_redd[i];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(loc);
+            gran_store(f.sum_g + ((int64_t)h * S + s) * 2, tag, (unsigned)(bits >> 32));
+            gran_store(f.sum_g + ((int64_t)h * S + s) * 2 + 1, tag, (unsigned)bits);
+        }
+        double part = 0.0;
+        if (lane < S) {
+            const unsigned hi = (unsigned)attn_one_wait(f.sum_g + ((int64_t)h * S + lane) * 2, tag, f.err);
+            const unsigned lo = (unsigned)attn_one_wait(f.sum_g + ((int64_t)h * S + lane) * 2 + 1, tag, f.err);
+            part = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+        part = wave_sum_f64(part);
+        if (lane == 0) s_tot = part;
+    }
+    __syncthreads();
+    const float inv = (float)(1.0 / s_tot);
+    for (int i = tid; i < n; i += 1024) s_p[i] = (_Float16)(s_s[i] * inv);
+    __syncthreads();
+    // ---- partial V.P of the range
+    {
+        const unsigned vpair = (vact && own) ? s_new[128 + (cv >> 1)] : 0u;
+        const _Float16 vnew = u32_as_h2(vpair)[cv & 1];
+        const int np = n_past - t0;  // the token's position inside the range (if own)
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            if (64 * u >= n8) break;  // uniform
+            const int pos = 64 * u + pj;
+            if (pos < n8) {
+                f16x8 vr = vv[u];
+                if (own && (pos >> 3) == (np >> 3)) {
+                    const int e = np - pos;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
+                }
+                const f16x8 pp = *(const f16x8 *)(s_p + pos);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc = __builtin_amdgcn_fdot2(f16x2{vr[2 * j], vr[2 * j + 1]}, f16x2{pp[2 * j], pp[2 * j + 1]}, acc, false);
+            }
+        }
+        acc = g8_sum_f32(acc);
+        if ((lane & 7) == 0 && vact) gran_store(f.part_g + ((int64_t)h * S + s) * D + cv, tag, __float_as_uint(acc));
+    }
+    // ---- the last workgroup of the head to arrive adds the partials and re-quantizes for wo
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(f.cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (unsigned)(S - 1);
+        if (s_last) __hip_atomic_store(f.cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int nblk = D / 32, l = tid & 31, b = tid >> 5;
+    if (b >= nblk) return;
+    float v = 0.0f;
+    for (int s2 = 0; s2 < S; s2++)
+        v += __uint_as_float((unsigned)attn_one_wait(f.part_g + ((int64_t)h * S + s2) * D + b * 32 + l, tag, f.err));
+    float amax = fabsf(v);
+    amax = g32_max_f32(amax);
+    const float d = amax / 127.0f;
+    const float id = act_id(amax, d, aq_scalar());
+    const int qv = act_q(v * id, aq_scalar());
+    int sq = qv;
+    sq = g32_sum_i32(sq);
+    const int64_t gb = (int64_t)h * nblk + b;
+    (l < 16 ? f.lo : f.hi)[gb * 16 + (l & 15)] = (int8_t)qv;
+    if (l == 0) {
+        f.dq[gb] = F16_D ? round_f16(d) : d;
+        f.sumq[gb] = sq;
+    }
+}
+
 template <int QT, bool INSTR = false>
 __global__ void __launch_bounds__(1024) k_qkv_attn(const BigArgs ba, const FusedAttnArgs fa) {
     constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
-    const int H = fa.n_head;
-    if ((int)blockIdx.x < H) {
-        attn_consumer<F16_D>(fa, (int)blockIdx.x);
+    const int H = fa.n_head, A = H * (fa.S > 1 ? fa.S : 1);  // attention workgroups (dispatched first)
+    if ((int)blockIdx.x < A) {
+        if (fa.S > 1)
+            attn_consumer_split<F16_D>(fa, (int)blockIdx.x % H, (int)blockIdx.x / H);
+        else
+            attn_consumer<F16_D>(fa, (int)blockIdx.x);
         return;
     }
-    big_body<QT, EPI_QKV, XSRC_NORM, INSTR>(ba, (int)blockIdx.x - H, (int)gridDim.x - H);
+    big_body<QT, EPI_QKV, XSRC_NORM, INSTR>(ba, (int)blockIdx.x - A, (int)gridDim.x - A);
 }

@@ -192,3 +192,87 @@ def test_split_attention_as_one_launch_is_bit_identical_to_its_three_launches(G,
     G.set_option("attn_split", 1)
     assert list(ids[1]) == list(ids[0])
     model.free()
+
+
+WIDE_SHAPES = {  # wide enough for the mat-vec to keep a quarter of the chip next to 2 / 4 attention workgroups per head
+    "mha": dict(n_vocab=256, n_embd=2048, n_head=16, n_head_kv=16, n_layer=2, n_rot=128, n_ff=512, n_mult=32),
+    "gqa": dict(n_vocab=256, n_embd=2048, n_head=16, n_head_kv=4, n_layer=2, n_rot=128, n_ff=512, n_mult=32),
+}
+
+
+@pytest.mark.parametrize("shape", ["mha", "gqa"])
+def test_several_attention_workgroups_per_head_inside_the_qkv_launch(G, O, shape):
+    """Beyond k_qkv_attn's 512-position register window the launch takes 2 (up to 1024 positions) or 4 (up to 2048) attention
+    workgroups per head (one per 512 positions), which hand range maxima, range sums and partial outputs to each other
+    (attn_consumer_split, kernels/decode_fused.h; option fuse_heads).  Against the plan with the separate split attention
+    (fuse_heads = 0: same rounding points, another f32 association of V.P) and against the oracle on the session's own K/V, at
+    context lengths around the range edges (512, 1024, 1536) and right below the context size; graph replay and eager."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(WIDE_SHAPES[shape], 2, seed=33)
+    ctx = 2048
+    model = llama.Llama(hp, w, context_size=ctx)
+    toks = np.random.default_rng(len(shape)).integers(0, hp["n_vocab"], ctx).astype(np.int32)
+    starts = [580, 1020, 1532, ctx - 6]  # 5 tokens each: 2 workgroups per head; 2 -> 3 (T crosses 1024); 3 -> 4 (T crosses 1536); the last positions (4)
+
+    def run(heads, graph=1):
+        G.set_option("fuse_heads", heads)
+        G.set_option("graph", graph)
+        G.set_option("attn_split", 1 if heads else 512)  # the comparison path: the separate split attention from 512 positions on
+        outs, kinds = [], []
+        try:
+            s = model.start_session(n_batch=512)
+            pos = 0
+            for st in starts:
+                s.feed_prompt(toks[pos:st])
+                f0, p0 = _stat(G, "fused_heads_tokens"), _stat(G, "attn_split_tokens")
+                for i in range(5):
+                    outs.append(s.evaluate(toks[st + i:st + i + 1])[-1].copy())
+                kinds.append((_stat(G, "fused_heads_tokens") - f0, _stat(G, "attn_split_tokens") - p0))
+                pos = st + 5
+            k, v = s.get_kv()
+            s.free()
+        finally:
+            G.set_option("fuse_heads", 1)
+            G.set_option("graph", 1)
+            G.set_option("attn_split", 1)
+        return outs, kinds, k, v
+
+    a, kinds_a, ka, va = run(1)
+    b, kinds_b, kb, vb = run(0)
+    c, kinds_c, kc, vc = run(1, graph=0)
+    assert kinds_a == [(5, 0)] * 4 and kinds_b == [(0, 5)] * 4, (kinds_a, kinds_b)
+    assert _stat(G, "fused_attn_timeouts") == 0
+    for x, z in zip(a, c):
+        assert np.array_equal(x, z)  # eager == graph replay
+    worst = max(float(np.max(np.abs(x - y))) / float(y.std()) for x, y in zip(a, b))
+    print(f"{shape}: 2 / 4 attention workgroups per head vs the separate split attention, worst |dlogit|/std = {worst:.2e}")
+    assert worst <= 4e-2
+    # the oracle on the device's own K/V (teacher-forced), at the first token of every start — for both paths: 2048-wide rows put
+    # more activations next to an int8 rounding edge than the 128-wide test models (one flip: ~3e-2 here), so the yardstick for
+    # the new path is what the established one (separate split attention) does on the same inputs
+    orc = O.Llama(hp, w, ctx)
+    worst_o = {}
+    for heads in (1, 0):
+        G.set_option("fuse_heads", heads)
+        G.set_option("attn_split", 1 if heads else 512)
+        try:
+            s = model.start_session(n_batch=512)
+            pos, wo = 0, 0.0
+            for st in starts:
+                s.feed_prompt(toks[pos:st])
+                k, v = s.get_kv()
+                orc.memory_k[:] = k[:orc.memory_k.size]
+                orc.memory_v[:] = v[:orc.memory_v.size]
+                orc.n_past = st
+                got = s.evaluate(toks[st:st + 1])[-1]
+                ref = orc.evaluate(toks[st:st + 1], mode=O.ref_mode())[-1]
+                wo = max(wo, float(np.max(np.abs(got - ref))) / float(ref.std()))
+                pos = st + 1
+            s.free()
+        finally:
+            G.set_option("fuse_heads", 1)
+            G.set_option("attn_split", 1)
+        worst_o[heads] = wo
+    print(f"{shape}: vs oracle worst |dlogit|/std = {worst_o[1]:.2e} (separate split attention: {worst_o[0]:.2e})")
+    assert worst_o[1] <= max(4e-2, 2.0 * worst_o[0]) and worst_o[1] <= 1e-1
+    model.free()
