@@ -1,0 +1,590 @@
+// attic: k_qkv_attn with the cached positions' scores / maximum / exps / sums computed before the token's K and V rows arrive (speculative softmax, both
+// attention consumers).  Needs the Q pairs handed over inside the mat-vec loop (big_body) to pay; measured in round 4 (profiles/r04_negative_results.txt,
+// items 4-5): the in-loop hand-over costs the mat-vec more than the attention gains.  Not compiled.
+// decode_fused.h — wq|wk|wv and the attention of a decode token in ONE launch (k_qkv_attn).
+//
+// The two launches it replaces are a dependent pair: k_mmvq_big<EPI_QKV> streams 28 MB on all CUs, then k_attn_decode runs a
+// latency chain on n_head CUs with HBM idle — its K/V round trip, a kernel boundary and a cold start for ~100 KB of work per
+// head (7.3-8.4 us of a 39 us layer at 7B).  Here the n_head attention workgroups are part of the mat-vec's launch:
+//   * workgroups 0 .. n_head-1 (dispatched first): one head each.  They request the first 256 positions of the head's K and V
+//     at kernel entry — that traffic overlaps the weight stream instead of following it — and then wait for the token's own
+//     Q / K / V rows of their head;
+//   * the other G - n_head workgroups run the mat-vec (big_body) over all row pairs, dealt exactly as in k_mmvq_big, and
+//     publish every finished pair as an 8-byte {epoch, f16 x 2} granule besides storing K / V into the cache.  Q travels as
+//     f16 because that is what ggml's F16 mat-mul makes of its src1 (k_attn_decode rounds the f32 Q the same way); the K / V
+//     halves are the very halves the cache gets, so this token's row of the scores / of V.P comes from the granules and the
+//     cache row that is being written concurrently is never read.
+// The hand-off is Guideline 16's form R2 (the data is the flag: one aligned 8-byte agent-scope store per pair, agent-scope
+// polling loads, no fence, no counter); it does not depend on which XCD or in which order workgroups run: producers never
+// wait, consumers wait only for producers, and all G workgroups fit the chip at once (one 1024-thread workgroup per CU).  The
+// tag is a device word bumped once per token (k_rope_table), so a replayed hipGraph never sees its own previous granules as
+// current.  Every spin is bounded (FusedAttnArgs::err is raised, the token's logits are then garbage but nothing hangs).
+// Arithmetic = k_attn_decode's, hence ggml's: f32 dot of f16 K with f16 Q, scale, row max, f16-rounded exp of the f16-rounded
+// difference, f64 sum, f16 probabilities, f32 V.P, Q8 re-quantization for wo.
+#pragma once
+#include "decode_big.h"
+#include "decode_attn_split.h"  // attn_one_wait and the hand-off protocol of k_attn_split_one
+
+struct FusedAttnArgs {
+    const __half *mem_k, *mem_v;  // + layer offset, layouts of DecMmvqArgs
+    const DecParams *prm;
+    const unsigned *epoch;
+    const unsigned long long *gran;  // this layer's granules: one per row pair of wq|wk|wv
+    int k_pair0, v_pair0;            // index of the first K / V pair (= rows of wq / 2, rows of wq|wk / 2)
+    float scale;
+    int D, n_rep, n_head;
+    int64_t Egqa, C, Clds;
+    int8_t *lo, *hi;  // the head's D outputs re-quantized for wo
+    float *dq;
+    int *sumq;
+    long long *ts;  // optional timeline slot (as k_attn_decode)
+    unsigned *err;  // raised when a wait gave up
+    // S > 1: S attention workgroups per head, workgroup s takes positions [512 s, 512 (s + 1)) (attn_consumer_split below)
+    int S, layer;
+    unsigned long long *mx_g, *sum_g, *part_g;  // hand-off granules of k_attn_split_one (decode_attn_split.h): [n_head][S], [..][S][2], [..][S][D]
+    unsigned *cnt;                              // [n_head] arrival counters
+};
+
+__device__ __forceinline__ f16x2 u32_as_h2(unsigned u) { return __builtin_bit_cast(f16x2, u); }
+
+template <bool F16_D>
+__device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int h) {
+    const long long t_entry = f.ts ? (long long)wall_clock64() : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t Clds = f.Clds, C = f.C, Egqa = f.Egqa;
+    const int D = f.D;
+    float *s_s = (float *)smem;             // Clds scores
+    float *s_o = s_s + Clds;                // D outputs
+    _Float16 *s_p = (_Float16 *)(s_o + D);  // Clds probabilities as f16
+    __shared__ float s_red[16];
+    __shared__ double s_redd[16];
+    __shared__ __attribute__((aligned(16))) unsigned s_new[3 * 64];  // this token's Q | K | V of the head, f16 pairs (D <= 128)
+    const int hk = h / f.n_rep;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_past = f.prm->n_past;
+    const unsigned epoch = *f.epoch;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- the head's cache: up to 512 positions (the split-attention threshold) go into registers now, while the mat-vec
+    //      workgroups stream — exactly the rows the context has (the position is known after one scalar round trip; the
+    //      requests have microseconds of slack), so a short context costs the weight stream next to nothing
+    constexpr int NPRE = 8;
+    const int T = n_past + 1;
+    const int T8 = (T + 7) & ~7;
+    const int g = tid >> 4, gl = tid & 15;
+    const int d0 = gl * 8;
+    const bool act = d0 < D;
+    const __half *kbase = f.mem_k + (int64_t)hk * D + d0;
+    f16x8 kv[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int t = g + 64 * u;
+        kv[u] = zero8;
+        if (act && t < n_past) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+    }
+    const int cv = wave * 8 + (lane >> 3), pj = (lane & 7) * 8;
+    const bool vact = cv < D;
+    const __half *vbase = f.mem_v + ((int64_t)hk * D + cv) * C + pj;
+    f16x8 vv[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        vv[u] = zero8;
+        if (vact && 64 * u + pj < T8) vv[u] = *(const f16x8 *)(vbase + 64 * u);  // T8 <= C: the chunk lies inside the cache
+    }
+
+    // ---- this token's rows of the head arrive as granules.  The mat-vec workgroups hand a Q pair over the moment it is summed
+    //      (big_body, EPI_QKV) and take their units in ascending order, so Q is complete about half-way through the launch, K and
+    //      V at its end: everything that needs only Q — the scores of the cached positions, their maximum, their f16-rounded exps
+    //      against that maximum and the f64 sum — happens under the rest of the weight stream.  Behind the last producer only the
+    //      new position's score is left; unless it raises the maximum (then the exps are redone against it) the speculative
+    //      exps ARE ggml's: same maximum, same rounding points, an exact sum.
+    __shared__ float s_mx_old;
+    __shared__ double s_sum_old;
+    auto wait_rows = [&](int which /* 0 Q, 1 K, 2 V */) {  // one wave: the D/2 granules of the head's row -> s_new[which * 64 ..]
+        const int half_d = D >> 1;
+        const int base = which == 0 ? h * half_d : which == 1 ? f.k_pair0 + hk * half_d : f.v_pair0 + hk * half_d;
+        const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
+        const long long c0 = (long long)wall_clock64();
+        unsigned long long x;
+        for (;;) {
+            x = gran_load(gp);
+            const bool ok = (unsigned)(x >> 32) == epoch;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((long long)wall_clock64() - c0 > 5000000) {  // 50 ms at 100 MHz: a producer never arrived
+                if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        s_new[which * 64 + lane] = (unsigned)x;
+    };
+    if (wave == 0) wait_rows(0);
+    __syncthreads();
+    f16x2 qh2[4];
+    if (act) {
+        const u32x4 q4 = *(const u32x4 *)(s_new + (d0 >> 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++) qh2[j] = u32_as_h2(q4[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) qh2[j] = f16x2{(_Float16)0.0f, (_Float16)0.0f};
+    }
+    // ---- scores of the cached positions (t < n_past) ----
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        if (64 * u >= n_past) break;  // the slab starts beyond the cached positions (uniform over the workgroup)
+        const int t = g + 64 * u;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) s = __builtin_amdgcn_fdot2(f16x2{kv[u][2 * j], kv[u][2 * j + 1]}, qh2[j], s, false);
+        s = g16_sum_f32(s);
+        if (gl == 0 && t < n_past) s_s[t] = s * f.scale;
+    }
+#pragma unroll 1
+    for (int t0 = 64 * NPRE; t0 < n_past; t0 += 64) {  // contexts beyond the register window (option attn_split raised): from the cache
+        const int t = t0 + g;
+        f16x8 kr = zero8;
+        if (act && t < n_past) kr = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) s = __builtin_amdgcn_fdot2(f16x2{kr[2 * j], kr[2 * j + 1]}, qh2[j], s, false);
+        s = g16_sum_f32(s);
+        if (gl == 0 && t < n_past) s_s[t] = s * f.scale;
+    }
+    __syncthreads();
+    const long long t_scores = f.ts ? (long long)wall_clock64() : 0;
+    // ---- their maximum, f16-rounded exps (parked in s_p: an f16 value is stored exactly) and f64 sum ----
+    if (n_past <= 256) {  // one wave does it alone (4 per lane, DPP reductions): no exchange through LDS, no barrier between the passes
+        if (wave == 0) {
+            float sv[4];
+            float mx1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = lane + 64 * i;
+                sv[i] = t < n_past ? s_s[t] : -INFINITY;
+                mx1 = fmaxf(mx1, sv[i]);
+            }
+            mx1 = wave_max_f32(mx1);
+            double sum1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = lane + 64 * i;
+                if (t < n_past) {
+                    const float e = round_f16(expf(round_f16(sv[i] - mx1)));
+                    s_p[t] = (_Float16)e;
+                    sum1 += (double)e;
+                }
+            }
+            sum1 = wave_sum_f64(sum1);
+            if (lane == 0) {
+                s_mx_old = mx1;
+                s_sum_old = sum1;
+            }
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int t = tid; t < n_past; t += 1024) mx = fmaxf(mx, s_s[t]);
+        mx = wave_max_f32(mx);
+        if (lane == 0) s_red[wave] = mx;
+        __syncthreads();
+        mx = s_red[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) mx = fmaxf(mx, s_red[i]);
+        double sum = 0.0;
+        for (int t = tid; t < n_past; t += 1024) {
+            const float e = round_f16(expf(round_f16(s_s[t] - mx)));
+            s_p[t] = (_Float16)e;
+            sum += (double)e;
+        }
+        sum = wave_sum_f64(sum);
+        if (lane == 0) s_redd[wave] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) tot += s_redd[i];
+            s_mx_old = mx;
+            s_sum_old = tot;
+        }
+    }
+    // ---- the token's K and V rows (published last) ----
+    if (wave == 1) wait_rows(1);
+    if (wave == 2) wait_rows(2);
+    __syncthreads();
+    const long long t_loaded = f.ts ? (long long)wall_clock64() : 0;
+    {
+        f16x8 knew = zero8;
+        if (act) {
+            const u32x4 k4 = *(const u32x4 *)(s_new + 64 + (d0 >> 1));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f16x2 kk = u32_as_h2(k4[j]);
+                knew[2 * j] = kk[0];
+                knew[2 * j + 1] = kk[1];
+            }
+        }
+        float sn = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sn = __builtin_amdgcn_fdot2(f16x2{knew[2 * j], knew[2 * j + 1]}, qh2[j], sn, false);
+        sn = g16_sum_f32(sn) * f.scale;  // the new position's score: every 16-lane group holds the same value
+        const float mxo = s_mx_old;
+        if (sn <= mxo) {  // (uniform) the maximum stands: the parked exps are final
+            const float en = round_f16(expf(round_f16(sn - mxo)));
+            const float inv = (float)(1.0 / (s_sum_old + (double)en));
+            for (int t = tid; t < T8; t += 1024)
+                s_p[t] = t < n_past ? (_Float16)((float)s_p[t] * inv) : t == n_past ? (_Float16)(en * inv) : (_Float16)0.0f;
+        } else {  // the new position raises the maximum: the exps against it (ggml's order of events), as before
+            if (tid == 0) s_s[n_past] = sn;
+            __syncthreads();
+            const float mx = sn;
+            double sum = 0.0;
+            for (int t = tid; t < T; t += 1024) {
+                const float e = round_f16(expf(round_f16(s_s[t] - mx)));
+                s_s[t] = e;
+                sum += (double)e;
+            }
+            sum = wave_sum_f64(sum);
+            if (lane == 0) s_redd[wave] = sum;
+            __syncthreads();
+            double tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) tot += s_redd[i];
+            const float inv = (float)(1.0 / tot);
+            for (int t = tid; t < T8; t += 1024) s_p[t] = t < T ? (_Float16)(s_s[t] * inv) : (_Float16)0.0f;
+        }
+    }
+    __syncthreads();
+    const long long t_softmax = f.ts ? (long long)wall_clock64() : 0;
+    // ---- V.P ----
+    {
+        // this token's V of channel cv: element cv of the V granules
+        const unsigned vpair = vact ? s_new[128 + (cv >> 1)] : 0u;
+        const _Float16 vnew = u32_as_h2(vpair)[cv & 1];
+        float acc = 0.0f;
+        auto chunk = [&](f16x8 vr, const int pos) {  // 8 positions of channel cv against their probabilities
+            if ((pos >> 6) == (n_past >> 6)) {  // the 64-slab of the token's own position (uniform)
+                const int e = n_past - pos;
+#pragma unroll
+                for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
+            }
+            const f16x8 pp = *(const f16x8 *)(s_p + pos);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc = __builtin_amdgcn_fdot2(f16x2{vr[2 * j], vr[2 * j + 1]}, f16x2{pp[2 * j], pp[2 * j + 1]}, acc, false);
+        };
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            if (64 * u >= T8) break;  // uniform
+            if (64 * u + pj < T8) chunk(vv[u], 64 * u + pj);
+        }
+#pragma unroll 1
+        for (int p0 = 64 * NPRE; p0 < T8; p0 += 64)
+            if (p0 + pj < T8) chunk(vact ? *(const f16x8 *)(vbase + p0) : zero8, p0 + pj);
+        acc = g8_sum_f32(acc);
+        if ((lane & 7) == 0 && vact) s_o[cv] = acc;
+    }
+    __syncthreads();
+    const long long t_vp = f.ts ? (long long)wall_clock64() : 0;
+    // ---- the head's D outputs as Q8 blocks for wo ----
+    const int nblk = D / 32, l = tid & 31, b = tid >> 5;
+    if (b < nblk) {
+        const float v = s_o[b * 32 + l];
+        float amax = fabsf(v);
+        amax = g32_max_f32(amax);
+        const float d = amax / 127.0f;
+        const float id = act_id(amax, d, aq_scalar());
+        const int qv = act_q(v * id, aq_scalar());
+        int sq = qv;
+        sq = g32_sum_i32(sq);
+        const int64_t gb = (int64_t)h * nblk + b;
+        (l < 16 ? f.lo : f.hi)[gb * 16 + (l & 15)] = (int8_t)qv;
+        if (l == 0) {
+            f.dq[gb] = F16_D ? round_f16(d) : d;
+            f.sumq[gb] = sq;
+        }
+    }
+    if (f.ts && tid == 0) {
+        const int q4 = f.n_head / 4;
+        if (q4 > 0 && h % q4 == 0 && h / q4 < 4) {
+            long long *o = f.ts + (h / q4) * 8;
+            o[0] = t_entry; o[1] = t_loaded; o[2] = t_scores; o[3] = t_softmax; o[4] = t_vp;
+            o[5] = (long long)wall_clock64(); o[6] = T; o[7] = h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Contexts beyond the 512-position register window: S attention workgroups per head instead of one (S = 2 up to 1024
+// positions, 4 up to 2048), still inside the wq|wk|wv launch.  Workgroup (h, s) owns positions [512 s, 512 (s + 1)): it
+// requests exactly those K / V rows at entry (they stream under the weights), waits for the token's Q (and, if the token's own
+// position falls into its range, K / V) granules, and then runs k_attn_split_one's protocol with its S - 1 peers
+// (decode_attn_split.h): range maximum -> row maximum, range sum of the f16-rounded exps -> row sum (exact in any order), partial
+// V.P -> the last workgroup of the head to arrive adds the partials (s ascending) and re-quantizes for wo.  ggml's rounding points
+// are kept; only the f32 association of the V.P sum differs from the one-workgroup form (as for every split of a head).
+// ---------------------------------------------------------------------------------------------------
+template <bool F16_D>
+__device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, const int h, const int s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t C = f.C, Egqa = f.Egqa;
+    const int D = f.D, S = f.S;
+    constexpr int WIN = 512;
+    float *s_s = (float *)smem;               // WIN scores, then exps, of the range
+    float *s_o = s_s + WIN;                   // D floats (unused here, keeps the layout of attn_consumer's dynamic LDS in mind)
+    _Float16 *s_p = (_Float16 *)(s_o + 128);  // WIN probabilities
+    __shared__ float s_red[16];
+    __shared__ double s_redd[16];
+    __shared__ float s_mx;
+    __shared__ double s_tot;
+    __shared__ int s_last;
+    __shared__ __attribute__((aligned(16))) unsigned s_new[3 * 64];
+    const int hk = h / f.n_rep;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_past = f.prm->n_past;
+    const unsigned epoch = *f.epoch;
+    const unsigned tag = (epoch * 64u + (unsigned)(f.layer & 63)) | 0x80000000u;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int NPRE = 8;
+    const int T = n_past + 1;
+    const int t0 = s * WIN;
+    const int n = T > t0 ? (T - t0 < WIN ? T - t0 : WIN) : 0;  // positions of this range (0: the context ends before it)
+    const int n8 = (n + 7) & ~7;
+    const bool own = n_past >= t0 && n_past < t0 + WIN;        // the token's own position lies in this range
+    const int g = tid >> 4, gl = tid & 15;
+    const int d0 = gl * 8;
+    const bool act = d0 < D;
+    const __half *kbase = f.mem_k + (int64_t)hk * D + d0;
+    f16x8 kv[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int t = t0 + g + 64 * u;
+        kv[u] = zero8;
+        if (act && t < n_past) kv[u] = *(const f16x8 *)(kbase + (int64_t)t * Egqa);
+    }
+    const int cv = wave * 8 + (lane >> 3), pj = (lane & 7) * 8;
+    const bool vact = cv < D;
+    const __half *vbase = f.mem_v + ((int64_t)hk * D + cv) * C + t0 + pj;
+    f16x8 vv[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        vv[u] = zero8;
+        if (vact && 64 * u + pj < n8) vv[u] = *(const f16x8 *)(vbase + 64 * u);  // t0 + n8 <= C: the chunk lies inside the cache
+    }
+    // ---- Q first: the mat-vec workgroups take their units in ascending order, so the token's Q rows are published in the first
+    //      third of the launch, its K and V rows at the end.  Everything that needs only Q happens NOW, under the weight stream:
+    //      the scores of the cached positions and the exchange of their range maxima.
+    auto wait_rows = [&](int which /* 0 Q, 1 K, 2 V */) {  // one wave: the D/2 granules of this head's row -> s_new[which * 64 ..]
+        const int half_d = D >> 1;
+        const int base = which == 0 ? h * half_d : which == 1 ? f.k_pair0 + hk * half_d : f.v_pair0 + hk * half_d;
+        const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
+        const long long c0 = (long long)wall_clock64();
+        unsigned long long x;
+        for (;;) {
+            x = gran_load(gp);
+            const bool ok = (unsigned)(x >> 32) == epoch;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((long long)wall_clock64() - c0 > 5000000) {
+                if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        s_new[which * 64 + lane] = (unsigned)x;
+    };
+    if (wave == 0) wait_rows(0);
+    for (int i = tid; i < WIN; i += 1024) s_p[i] = (_Float16)0.0f;
+    __syncthreads();
+    f16x2 qh2[4];
+    if (act) {
+        const u32x4 q4 = *(const u32x4 *)(s_new + (d0 >> 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++) qh2[j] = u32_as_h2(q4[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) qh2[j] = f16x2{(_Float16)0.0f, (_Float16)0.0f};
+    }
+    // scores of the range's CACHED positions (t < n_past) -> LDS; their maximum -> peers; then — speculatively, against that
+    // maximum — their f16-rounded exps (parked in s_p: an f16 value is stored exactly) and the range's f64 sum -> peers.  All of
+    // it under the rest of the weight stream.  Unless the new position raises the maximum these ARE ggml's numbers (same maximum,
+    // same rounding points, exact sum), and nothing but the new position's own term is left to add behind the mat-vec.
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        if (64 * u >= n) break;  // uniform
+        const int tl = g + 64 * u;
+        float sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sc = __builtin_amdgcn_fdot2(f16x2{kv[u][2 * j], kv[u][2 * j + 1]}, qh2[j], sc, false);
+        sc = g16_sum_f32(sc);
+        if (t0 + tl < n_past) {
+            sc *= f.scale;
+            if (gl == 0) s_s[tl] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    }
+    const int nc = n_past > t0 ? (n_past - t0 < WIN ? n_past - t0 : WIN) : 0;  // cached positions of the range
+    mx = wave_max_f32(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    if (wave == 0) {
+        float m = lane < 16 ? s_red[lane] : -INFINITY;
+        m = wave_max_f32(m);
+        if (lane == 0) gran_store(f.mx_g + (int64_t)h * S + s, tag, __float_as_uint(m));  // -inf: no cached position here
+        float pm = -INFINITY;
+        if (lane < S) pm = __uint_as_float((unsigned)attn_one_wait(f.mx_g + (int64_t)h * S + lane, tag, f.err));
+        pm = wave_max_f32(pm);
+        if (lane == 0) s_mx = pm;
+    }
+    __syncthreads();
+    const float mxo = s_mx;  // maximum over the cached positions of the whole row
+    auto exchange_sum = [&](double local, unsigned long long *buf) {  // wave 0: publish the range sum, gather the row sum
+        if (lane == 0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(local);
+            gran_store(buf + ((int64_t)h * S + s) * 2, tag, (unsigned)(bits >> 32));
+            gran_store(buf + ((int64_t)h * S + s) * 2 + 1, tag, (unsigned)bits);
+        }
+        double part = 0.0;
+        if (lane < S) {
+            const unsigned hi = (unsigned)attn_one_wait(buf + ((int64_t)h * S + lane) * 2, tag, f.err);
+            const unsigned lo = (unsigned)attn_one_wait(buf + ((int64_t)h * S + lane) * 2 + 1, tag, f.err);
+            part = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+        part = wave_sum_f64(part);  // exact in any order (multiples of 2^-24 not above 1, at most 2^16 of them)
+        if (lane == 0) s_tot = part;
+    };
+    {
+        double sum = 0.0;
+        for (int i = tid; i < nc; i += 1024) {
+            const float e = round_f16(expf(round_f16(s_s[i] - mxo)));
+            s_p[i] = (_Float16)e;
+            sum += (double)e;
+        }
+        sum = wave_sum_f64(sum);
+        if (lane == 0) s_redd[wave] = sum;
+        __syncthreads();
+        if (wave == 0) {
+            double loc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) loc += s_redd[i];
+            exchange_sum(loc, f.sum_g);
+        } else if (wave == 1) {
+            // ---- the token's K row: EVERY workgroup of the head takes it and scores the new position itself; its V row only
+            //      where the position lives
+            wait_rows(1);
+        } else if (wave == 2 && own) {
+            wait_rows(2);
+        }
+    }
+    __syncthreads();
+    {
+        f16x8 knew = zero8;
+        if (act) {
+            const u32x4 k4 = *(const u32x4 *)(s_new + 64 + (d0 >> 1));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f16x2 kk = u32_as_h2(k4[j]);
+                knew[2 * j] = kk[0];
+                knew[2 * j + 1] = kk[1];
+            }
+        }
+        float sn = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sn = __builtin_amdgcn_fdot2(f16x2{knew[2 * j], knew[2 * j + 1]}, qh2[j], sn, false);
+        sn = g16_sum_f32(sn) * f.scale;  // the new position's score: the same value in every group of every workgroup of the head
+        if (sn <= mxo) {  // (uniform over the head's workgroups) the maximum stands: the parked exps and the exchanged sums are final
+            const float en = round_f16(expf(round_f16(sn - mxo)));
+            const float inv = (float)(1.0 / (s_tot + (double)en));
+            for (int i = tid; i < n; i += 1024) s_p[i] = i < nc ? (_Float16)((float)s_p[i] * inv) : (_Float16)(en * inv);  // i == nc: the new position (own)
+        } else {  // the new position raises the maximum: exps against it, a second exchange of the range sums
+            if (own && tid == 0) s_s[n_past - t0] = sn;
+            __syncthreads();
+            double sum = 0.0;
+            for (int i = tid; i < n; i += 1024) {
+                const float e = round_f16(expf(round_f16(s_s[i] - sn)));
+                s_s[i] = e;
+                sum += (double)e;
+            }
+            sum = wave_sum_f64(sum);
+            if (lane == 0) s_redd[wave] = sum;
+            __syncthreads();
+            if (wave == 0) {
+                double loc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) loc += s_redd[i];
+                exchange_sum(loc, f.sum_g + (int64_t)f.n_head * S * 2);
+            }
+            __syncthreads();
+            const float inv = (float)(1.0 / s_tot);
+            for (int i = tid; i < n; i += 1024) s_p[i] = (_Float16)(s_s[i] * inv);
+        }
+    }
+    __syncthreads();
+    // ---- partial V.P of the range
+    {
+        const unsigned vpair = (vact && own) ? s_new[128 + (cv >> 1)] : 0u;
+        const _Float16 vnew = u32_as_h2(vpair)[cv & 1];
+        const int np = n_past - t0;  // the token's position inside the range (if own)
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            if (64 * u >= n8) break;  // uniform
+            const int pos = 64 * u + pj;
+            if (pos < n8) {
+                f16x8 vr = vv[u];
+                if (own && (pos >> 3) == (np >> 3)) {
+                    const int e = np - pos;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) vr[j] = e == j ? vnew : vr[j];
+                }
+                const f16x8 pp = *(const f16x8 *)(s_p + pos);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc = __builtin_amdgcn_fdot2(f16x2{vr[2 * j], vr[2 * j + 1]}, f16x2{pp[2 * j], pp[2 * j + 1]}, acc, false);
+            }
+        }
+        acc = g8_sum_f32(acc);
+        if ((lane & 7) == 0 && vact) gran_store(f.part_g + ((int64_t)h * S + s) * D + cv, tag, __float_as_uint(acc));
+    }
+    // ---- the last workgroup of the head to arrive adds the partials and re-quantizes for wo
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(f.cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (unsigned)(S - 1);
+        if (s_last) __hip_atomic_store(f.cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int nblk = D / 32, l = tid & 31, b = tid >> 5;
+    if (b >= nblk) return;
+    float v = 0.0f;
+    for (int s2 = 0; s2 < S; s2++)
+        v += __uint_as_float((unsigned)attn_one_wait(f.part_g + ((int64_t)h * S + s2) * D + b * 32 + l, tag, f.err));
+    float amax = fabsf(v);
+    amax = g32_max_f32(amax);
+    const float d = amax / 127.0f;
+    const float id = act_id(amax, d, aq_scalar());
+    const int qv = act_q(v * id, aq_scalar());
+    int sq = qv;
+    sq = g32_sum_i32(sq);
+    const int64_t gb = (int64_t)h * nblk + b;
+    (l < 16 ? f.lo : f.hi)[gb * 16 + (l & 15)] = (int8_t)qv;
+    if (l == 0) {
+        f.dq[gb] = F16_D ? round_f16(d) : d;
+        f.sumq[gb] = sq;
+    }
+}
+
+template <int QT, bool INSTR = false>
+__global__ void __launch_bounds__(1024) k_qkv_attn(const BigArgs ba, const FusedAttnArgs fa) {
+    constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
+    const int H = fa.n_head, A = H * (fa.S > 1 ? fa.S : 1);  // attention workgroups (dispatched first)
+    if ((int)blockIdx.x < A) {
+        if (fa.S > 1)
+            attn_consumer_split<F16_D>(fa, (int)blockIdx.x % H, (int)blockIdx.x / H);
+        else
+            attn_consumer<F16_D>(fa, (int)blockIdx.x);
+        return;
+    }
+    big_body<QT, EPI_QKV, XSRC_NORM, INSTR>(ba, (int)blockIdx.x - A, (int)gridDim.x - A);
+}
