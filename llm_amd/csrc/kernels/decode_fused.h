@@ -323,9 +323,11 @@ __device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, cons
         vv[u] = zero8;
         if (vact && 64 * u + pj < n8) vv[u] = *(const f16x8 *)(vbase + 64 * u);  // t0 + n8 <= C: the chunk lies inside the cache
     }
-    // ---- Q first: the mat-vec workgroups take their units in ascending order, so the token's Q rows are published in the first
-    //      third of the launch, its K and V rows at the end.  Everything that needs only Q happens NOW, under the weight stream:
-    //      the scores of the cached positions and the exchange of their range maxima.
+    // ---- Q first: the scores of the cached positions and the exchange of their range maxima need nothing else.  (The mat-vec
+    //      waves hand all their rows over at the end of their work — epilogues after the dots — so Q, K and V become visible
+    //      almost together; what this order buys is that the row maximum is settled by ONE exchange among values every range
+    //      already holds, plus a new-position score every workgroup computes itself: no exchange has to wait for the K row.
+    //      Handing Q over inside the mat-vec loop was measured: profiles/r04_negative_results.txt item 5.)
     auto wait_rows = [&](int which /* 0 Q, 1 K, 2 V */) {  // one wave: the D/2 granules of this head's row -> s_new[which * 64 ..]
         const int half_d = D >> 1;
         const int base = which == 0 ? h * half_d : which == 1 ? f.k_pair0 + hk * half_d : f.v_pair0 + hk * half_d;
