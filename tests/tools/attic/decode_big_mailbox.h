@@ -1,0 +1,536 @@
+// attic: big_body with the LDS mailbox through which a spare wave hands finished Q pairs to the attention workgroups early (round 4, negative
+// result 6 in profiles/r04_negative_results.txt; goes with decode_fused_speculative.h).  Not compiled.
+// decode_big.h — the decode mat-vec as ONE wave of big workgroups: grid = #CUs x 1024 threads, the workgroups walk the
+// output rows together (unit u -> workgroup (u / 16) mod G, so at any moment the chip streams one contiguous window of
+// the matrix), the activation's loads are the first memory operations of the kernel, the weight stream is prefetched
+// into a register ring (2 steps before the activation is staged, the rest after), and the activation's norm /
+// re-quantization is done by each workgroup while those loads are in flight.  Same arithmetic as k_mmvq_dec
+// (decode.h) / k_mmvq (mmvq.h); same epilogues.
+//
+// Why (measured on MI355X, profiles/r01_run8 -> r01_run33): with 256-thread workgroups a LLaMA-7B mat-vec needs
+// 512..4000 workgroups, each of which re-stages x (4.6 KB from L2, ~1 us of latency before its first dot) and has one
+// K-step of weights in flight; the E x E mat-vec ran at 1.9 TB/s, wq|wk|wv at 3.0 TB/s, and the separate
+// rms_norm+quantize / quantize launches in front of them cost ~6 us each (a 1-workgroup latency chain plus a
+// kernel boundary).  Here:
+//   * 256 workgroups = one per CU, resident at once: no dispatch tail, x staged 256 times instead of 4000;
+//   * 16 waves x up to 8 steps x 16 B x rows-per-step in flight per lane: the HBM pipe is busy from the start;
+//   * staging x = rms_norm (f64 sum of squares) -> weight -> Q8 blocks in LDS overlaps the weight prefetch and
+//     removes 3 launches per layer (8 -> 5).
+// The pitfalls that made the first version slower than what it replaced are listed in DESIGN.md section 4 (in-order
+// load return, vector loads of kernarg arrays, uncountable loads in flight, epilogue loads, x queued behind the
+// prefetch, 64-bit index math).
+// A "unit" is what one wave reduces together: a pair of adjacent rows for wq|wk|wv (RoPE rotates the pair),
+// row m of w1 and of w3 for the gate, one row otherwise.  A "step" is one 64-block column of a unit.
+#pragma once
+#include "decode.h"
+
+template <int QT, int NR>
+struct BigStep {
+    u32x4 q[NR];
+    u32x4 p[QT == QT_Q8_0 ? NR : 1];
+    uint32_t h[(QT == QT_Q5_0 || QT == QT_Q5_1) ? NR : 1];
+    __half dw[NR];
+    __half mw[(QT == QT_Q4_1 || QT == QT_Q5_1) ? NR : 1];
+};
+
+// Ring depth = weight steps in flight per lane.  NOT "as many as the registers hold": a CU accepts only so many
+// outstanding requests, and a wave whose next load is not accepted sits in ISSUE — it reaches neither the staging
+// barrier nor its dots.  With the whole launch requested up front (6 steps of 2 rows) the barrier of w1|w3 fell at
+// 6.8 us of a 8.9 us kernel and all the integer work ran after the fetch instead of under it (in-kernel timeline,
+// tests/tools/timeline.py; halving the dots saved 1.1 us per launch).  ~6 KB per wave (x 15..16 waves per CU) keeps
+// the memory pipeline full and lets the barrier fall right after the staging: w1|w3 13.1 -> 11.6 us per launch,
+// wq|wk|wv 9.6 -> 8.5, wo 5.0 -> 4.3.
+#ifndef BIG_PF1
+#define BIG_PF1 5  // steps of 1 row  (1 KB of Q4/Q5 quants each)
+#endif
+#ifndef BIG_PF2
+#define BIG_PF2 3  // steps of 2 rows
+#endif
+template <int QT>
+__device__ __forceinline__ constexpr int big_pf(int NR) {
+    // at most ~64 VGPRs of weight data in flight per lane (Q8_0 and the 5-bit types carry more per row)
+    const int per = NR * (4 + (QT == QT_Q8_0 ? 4 : 0) + ((QT == QT_Q5_0 || QT == QT_Q5_1) ? 1 : 0) + 1 +
+                          ((QT == QT_Q4_1 || QT == QT_Q5_1) ? 1 : 0));
+    const int fit = 64 / per >= 2 ? 64 / per : 2;
+    int pf = NR == 1 ? BIG_PF1 : NR == 2 ? BIG_PF2 : 2;
+    if (QT == QT_Q8_0) pf = (pf + 1) / 2;  // two 16-byte planes per row step
+    return pf < 2 ? 2 : pf > fit ? fit : pf;
+}
+
+#ifndef BIG_T
+#define BIG_T 1024  // threads per workgroup of k_mmvq_big; 512 (-DBIG_T=512) starts faster (wo: barrier at 1.5 us instead
+                    // of 2.3) but streams slower with half the waves (w1|w3 10.3 us vs 9.2, lm_head 18.6 vs 12.7): 600 vs 612 tok/s
+#endif
+#define BIG_W (BIG_T / 64)
+// k_mmvq_big itself runs with any multiple of 64 threads up to BIG_T (blockDim.x): the launcher picks the number of
+// waves per workgroup that deals the launch's units most evenly (launch_big).  12 waves x 256 workgroups give every
+// wave exactly 2 of the 6144 row pairs of a 7B wq|wk|wv; with 16 waves half of them get 2 and half 1, and the
+// launch lasts as long as the workgroups with the 2s.
+
+struct BigArgs {
+    DecMmvqArgs d;
+    float *y_out;  // XSRC_NORM: optional f32 copy of the normed row (final norm -> OutputRequest.embeddings)
+    long long *ts;  // optional timeline slot (ggml_hip_set_option("timeline", n)): 8 x int64 per sampled workgroup
+    int ts_wgs;     // workgroups that record: 0, G/n, 2G/n, ... (n = 4 for "timeline" = 1, else the option's value)
+    const float *rope;  // EPI_QKV: (cos, sin) of this token's RoPE angle per pair of a head, from k_rope_table
+    int probe;          // measurement only (ggml_hip_set_option("probe", n), tests/tools/launch_probe.py): 1 = return before
+                        // the first weight request, 2 = return once x is staged and the ring requested, 3 = no epilogue stores, 4 = every
+                        // other step's dots skipped, 5 = no wave reductions; 0 = normal
+    // EPI_QKV inside k_qkv_attn (kernels/decode_fused.h): the epilogue also PUBLISHES every row pair to the attention workgroups
+    // of the same launch, as one 8-byte {tag = epoch, two f16} granule per pair (index = the pair's index over wq|wk|wv); Q is
+    // not stored as f32 then (nothing else reads it).  nullptr = plain launch.
+    unsigned long long *gran;
+    const unsigned *epoch;  // device word, bumped once per token by k_rope_table: this token's tag
+    int wdeal;              // waves of a workgroup that take units (0 = all of blockDim); the rest only help staging
+};
+__device__ __forceinline__ long long big_now() { return (long long)wall_clock64(); }  // 100 MHz, chip-wide
+
+// The activation's global loads, issued as the FIRST memory operations of the kernel: a wave's loads return in
+// order, so anything issued after the weight prefetch would only become usable after the whole prefetch landed
+// (measured: norm staging behind the prefetch made the kernels additive, 16.6 us for wq|wk|wv instead of ~8).
+template <int XSRC>
+struct BigX;
+template <>
+struct BigX<XSRC_Q8> {
+    i32x4 lo, hi;
+    float d;
+    int sum;
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
+        const int64_t i = tid < nb ? tid : 0;  // nb <= T (checked by the launcher)
+        lo = a.d.x.lo[i];
+        hi = a.d.x.hi[i];
+        d = a.d.x.d[i];
+        sum = a.d.x.sum[i];
+    }
+};
+template <>
+struct BigX<XSRC_F32> {
+    static constexpr int MAXIT = 6;  // rows up to 24 * T wide (24576 at 1024 threads; checked by the launcher)
+    f32x4 v[MAXIT];
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
+        const int64_t n4 = nb * 8;
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * T + tid;
+            v[it] = ((const f32x4 *)a.d.xf)[i4 < n4 ? i4 : 0];
+        }
+    }
+};
+template <>
+struct BigX<XSRC_NORM> {
+    // The norm is staged by the first 512 threads only (8 waves, 2 per SIMD): its fixed per-thread cost (f64
+    // reduction and division, sqrt, the block scale divisions) is then paid 512 instead of 1024 times per CU — the
+    // staging is VALU-issue-bound, not latency-bound, once its loads have landed.  Waves 8..15 issue the same
+    // number of (single-address) loads so that every wave's load queue has the same compile-time shape.
+    static constexpr int NT = 512, MAXIT = 4;  // rows up to 8192 wide
+    f32x4 v[MAXIT], w[MAXIT];
+    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
+        const int64_t n4 = nb * 8;
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * NT + tid;
+            const int64_t ic = (tid < NT && i4 < n4) ? i4 : 0;
+            v[it] = ((const f32x4 *)a.d.xf)[ic];
+            w[it] = ((const f32x4 *)a.d.xw)[ic];
+        }
+    }
+};
+
+// registers -> LDS as padded planar Q8 (nbp = nbl*64 blocks; blocks >= nb are zero so tail steps contribute 0)
+template <bool F16_D, int XSRC>
+__device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int64_t nb, int64_t nbp, int tid, int T,
+                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part) {
+    const DecMmvqArgs &d = a.d;
+    (void)s_part;
+    for (int64_t i = nb + tid; i < nbp; i += T) {
+        s_lo[i] = i32x4{0, 0, 0, 0};
+        s_hi[i] = i32x4{0, 0, 0, 0};
+        s_d[i] = 0.0f;
+        s_sum[i] = 0;
+    }
+    const int64_t n4 = nb * 8;
+    if constexpr (XSRC == XSRC_Q8) {
+        if (tid < nb) {
+            s_lo[tid] = xr.lo;
+            s_hi[tid] = xr.hi;
+            s_d[tid] = xr.d;
+            s_sum[tid] = xr.sum;
+        }
+    } else if constexpr (XSRC == XSRC_F32) {
+#pragma unroll
+        for (int it = 0; it < BigX<XSRC_F32>::MAXIT; it++) {
+            const int64_t i4 = (int64_t)it * T + tid;
+            if ((int64_t)it * T >= n4) break;  // uniform
+            const f32x4 v = i4 < n4 ? xr.v[it] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            quant4_to_lds<F16_D>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+        }
+    } else {
+        constexpr int MAXIT = BigX<XSRC_NORM>::MAXIT, NT = BigX<XSRC_NORM>::NT;
+        const bool stager = tid < NT;  // wave-uniform
+        if (stager) {
+            double ss = 0.0;
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                const int64_t i4 = (int64_t)it * NT + tid;
+                if (i4 < n4) {
+                    ss += (double)(xr.v[it][0] * xr.v[it][0]);
+                    ss += (double)(xr.v[it][1] * xr.v[it][1]);
+                    ss += (double)(xr.v[it][2] * xr.v[it][2]);
+                    ss += (double)(xr.v[it][3] * xr.v[it][3]);
+                }
+            }
+            ss = wave_sum_f64(ss);
+            if ((tid & 63) == 0) s_part[tid >> 6] = ss;
+        }
+        __syncthreads();
+        if (stager) {
+            double tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT / 64; i++) tot += s_part[i];
+            const float mean = (float)(tot / (double)(nb * 32));
+            const float scale = 1.0f / sqrtf(mean + d.eps);
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                const int64_t i4 = (int64_t)it * NT + tid;
+                if ((int64_t)it * NT >= n4) break;  // uniform
+                f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (i4 < n4) {
+                    y[0] = (xr.v[it][0] * scale) * xr.w[it][0];
+                    y[1] = (xr.v[it][1] * scale) * xr.w[it][1];
+                    y[2] = (xr.v[it][2] * scale) * xr.w[it][2];
+                    y[3] = (xr.v[it][3] * scale) * xr.w[it][3];
+                    if (a.y_out && blockIdx.x == 0) ((f32x4 *)a.y_out)[i4] = y;
+                }
+                quant4_to_lds<F16_D>(y, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+            }
+        }
+    }
+}
+
+// INSTR: the measurement build (BigArgs::probe early exits, BigArgs::ts timeline stamps), launched only while option
+// "probe" or "timeline" is set; the production instantiation (INSTR = false) carries none of those branches.
+// `bid` of `G` workgroups run the launch (blockIdx.x / gridDim.x for k_mmvq_big itself; the producer workgroups of
+// k_qkv_attn pass their index among the producers).
+template <int QT, int EPI, int XSRC, bool INSTR>
+__device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const int G) {
+    const DecMmvqArgs &a = ba.d;
+    const int probe = INSTR ? ba.probe : 0;
+    long long *const ts = INSTR ? ba.ts : nullptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_part[16];
+    __shared__ float s_rope[EPI == EPI_QKV ? 256 : 2];  // cos/sin of the RoPE angle of every pair of a head (D <= 256)
+    // k_qkv_attn: a finished Q pair goes to the attention workgroups EARLY (Q is every wave's first unit: complete half-way through
+    // the launch) — but not from the wave that summed it: a granule store in front of that wave's counted waits on its register
+    // ring stalls the ring until the write-through store is acknowledged (measured: 0.6 us per launch).  The wave parks the
+    // pair in this LDS mailbox; a spare wave (blockDim has more waves than take units) polls it and does the global store.
+    constexpr int MB_SLOTS = 2;  // a wave's first units
+    __shared__ float s_mb[EPI == EPI_QKV ? 16 * MB_SLOTS * 2 : 1];
+    __shared__ int s_mbf[EPI == EPI_QKV ? 16 * MB_SLOTS : 1];
+    constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
+    constexpr int RU = EPI == EPI_QKV ? 2 : 1, NW = EPI == EPI_GATE ? 2 : 1, NR = RU * NW;
+    constexpr int PF = big_pf<QT>(NR);
+    constexpr int PF0 = PF < 2 ? PF : 2;  // steps requested before x is staged (see step 2)
+    // all index arithmetic is 32-bit (rows <= 2^17, blocks per matrix < 2^27): 64-bit divides and multiplies in
+    // the prologue cost ~1 us of VALU time per launch
+    const int nb = (int)a.nb;
+    const int nbl = (nb + 63) >> 6;
+    const int nbp = nbl * 64;
+    i32x4 *s_lo = (i32x4 *)smem;
+    i32x4 *s_hi = s_lo + nbp;
+    float *s_d = (float *)(s_hi + nbp);
+    int *s_sum = (int *)(s_d + nbp);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int T = (int)blockDim.x;
+    const int W = ba.wdeal > 0 ? ba.wdeal : T >> 6;  // waves per workgroup that take units: chosen per launch (launch_big)
+    // wave-uniform values must be uniform FOR THE COMPILER too (scalar registers, scalar selects of the matrix
+    // pointers): a kernarg array indexed by a "divergent" segment id is fetched with vector loads, and waiting for
+    // those drains the whole in-order load queue at every step
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const long long t_entry = ts ? big_now() : 0;
+    // ---- 1. the activation's loads go first (see BigX); so does the position (needed by the QKV epilogue only)
+    int n_past = 0, store_at = 0;
+    unsigned epoch = 0;
+    if constexpr (EPI == EPI_QKV) {
+        n_past = a.prm->n_past;
+        store_at = a.prm->store_at;
+        if (ba.gran) epoch = *ba.epoch;
+    }
+    bool early = false;  // the Q pairs of the waves' first units leave through the mailbox
+    if constexpr (EPI == EPI_QKV) {
+        early = ba.gran != nullptr && W < (T >> 6) && probe == 0;
+        if (early && tid < 16 * MB_SLOTS) s_mbf[tid] = 0;  // the staging barrier below orders this before any use
+    }
+    BigX<XSRC> xr;
+    xr.load(ba, nb, tid, T);
+    // EPI_QKV: the last two waves fetch the token's RoPE table (k_rope_table); every wave issues the load so that all
+    // load queues keep one compile-time shape
+    f32x2 rope_pre = {0.0f, 0.0f};
+    if constexpr (EPI == EPI_QKV) {
+        const int kk = tid - (T - 128);
+        rope_pre = ((const f32x2 *)ba.rope)[(kk >= 0 && kk < (a.D >> 1)) ? kk : 0];
+    }
+
+    // this wave's units: ((i * G + g) * 16 + wave), i < nu — at any moment the G workgroups together stream ONE
+    // contiguous window of G*16 units of the matrix.  Lane i of the wave owns unit i's epilogue.
+    const int M0 = (int)a.w[0].M, M1 = EPI == EPI_QKV ? (int)a.w[1].M : 0, M2 = EPI == EPI_QKV ? (int)a.w[2].M : 0;
+    const int Utot = (M0 + M1 + M2) / RU;
+    // wave-major within a round: the units of the last, partial round go to waves 0..k of EVERY workgroup, so all CUs
+    // stream the same number of rows (11008 w1|w3 rows: 43 per CU instead of 45 on 222 CUs and 30 on 34)
+    const int u_first = wave * G + bid, u_stride = G * W;
+    const int nu = (wave < W && u_first < Utot) ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
+    const int S = nu * nbl;
+    // EPI_ADD: lane i preloads the residual of unit i (a load issued in the epilogue would drain the queue)
+    float res_pre = 0.0f;
+    if constexpr (EPI == EPI_ADD) {
+        const int m = u_first + u_stride * lane;
+        res_pre = a.res[(lane < nu && m < Utot) ? m : 0];
+    }
+
+    // unit -> (matrix, first row)
+    auto resolve = [&](int i, int &sg, int &m0) {
+        int r = (u_first + u_stride * i) * RU;
+        if (r >= Utot * RU) r = 0;  // dummy prefetch steps of a wave without (enough) units: any valid row
+        sg = 0;
+        m0 = r;
+        if constexpr (EPI == EPI_QKV) {
+            if (r >= M0 + M1) {
+                sg = 2;
+                m0 = r - M0 - M1;
+            } else if (r >= M0) {
+                sg = 1;
+                m0 = r - M0;
+            }
+        }
+    };
+    // The loads of a step are UNCONDITIONAL (addresses clamped; lanes past the row end read block nb-1 and meet
+    // zero x blocks in LDS): the number of memory operations in flight is a compile-time constant at every
+    // wait, so hipcc waits for exactly the step it needs (s_waitcnt vmcnt(N)) instead of draining the queue.
+    // The row bases of the producer's current unit live in scalar registers and change only when the producer moves
+    // to the next unit: a step then costs two vector instructions of address math (block index, clamp) — the
+    // per-step resolve + pointer selects + 64-bit vector adds it replaces were ~12 VALU and, for wq|wk|wv, ~50 SALU
+    // per step, on a CU whose 16 waves share one scalar unit (in-kernel timeline: loads issued 1.6 us after entry).
+    const uint8_t *ub_qs[NR], *ub_qs2[NR];
+    const uint32_t *ub_qh[NR];
+    const __half *ub_d[NR], *ub_m[NR];
+    auto set_unit = [&](int i) {
+        int sg, m0;
+        resolve(i, sg, m0);
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const uint8_t *qs = a.w[0].qs, *qs2 = a.w[0].qs2;
+            const uint32_t *qh = a.w[0].qh;
+            const __half *wd = a.w[0].d, *wm = a.w[0].m;
+            if constexpr (EPI == EPI_GATE) {
+                if (k == 1) {
+                    qs = a.w[1].qs; qs2 = a.w[1].qs2; qh = a.w[1].qh; wd = a.w[1].d; wm = a.w[1].m;
+                }
+            } else if constexpr (EPI == EPI_QKV) {  // scalar selects (sg is wave-uniform)
+                qs = sg == 0 ? a.w[0].qs : sg == 1 ? a.w[1].qs : a.w[2].qs;
+                qs2 = sg == 0 ? a.w[0].qs2 : sg == 1 ? a.w[1].qs2 : a.w[2].qs2;
+                qh = sg == 0 ? a.w[0].qh : sg == 1 ? a.w[1].qh : a.w[2].qh;
+                wd = sg == 0 ? a.w[0].d : sg == 1 ? a.w[1].d : a.w[2].d;
+                wm = sg == 0 ? a.w[0].m : sg == 1 ? a.w[1].m : a.w[2].m;
+            }
+            const size_t ro = (size_t)(uint32_t)(m0 + (EPI == EPI_QKV ? k : 0)) * (uint32_t)nb;  // first block of the row
+            ub_qs[k] = qs + ro * 16;
+            ub_qs2[k] = qs2 + ro * 16;
+            ub_qh[k] = qh + ro;
+            ub_d[k] = wd + ro;
+            ub_m[k] = wm + ro;
+        }
+    };
+    auto issue = [&](BigStep<QT, NR> &st, int j, bool dummy) {
+        const int b = lane + 64 * j;
+        const uint32_t bc = dummy ? 0u : (uint32_t)(b < nb ? b : nb - 1);  // a dummy step reads one line for the whole wave
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            st.q[k] = __builtin_nontemporal_load((const u32x4 *)(ub_qs[k] + (size_t)bc * 16));
+            if constexpr (QT == QT_Q8_0) st.p[k] = __builtin_nontemporal_load((const u32x4 *)(ub_qs2[k] + (size_t)bc * 16));
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) st.h[k] = __builtin_nontemporal_load(ub_qh[k] + bc);
+            st.dw[k] = ub_d[k][bc];
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) st.mw[k] = ub_m[k][bc];
+        }
+    };
+
+    if (probe == 1) return;  // here, not at entry: a check at entry costs every launch one more scalar-cache round trip
+    // ---- 2. weight prologue, part 1: PF0 steps.  Enough to cover the latency of x, little enough that x is not
+    //         queued behind tens of MB of weight requests in the fabric (measured with the in-kernel timeline:
+    //         with the full ring requested up front x took 3..6 us to arrive)
+    BigStep<QT, NR> ring[PF];
+    int pi = 0, pj = 0;  // producer position (unit, column); steps past the wave's last one are dummies
+    auto advance = [&](int k) {
+        if (k + 1 < S && ++pj == nbl) {
+            pj = 0;
+            set_unit(++pi);
+        }
+    };
+    set_unit(0);
+#pragma unroll
+    for (int k = 0; k < PF0; k++) {
+        issue(ring[k], pj, k >= S);
+        advance(k);
+    }
+    const long long t_issued = ts ? big_now() : 0;
+
+    // ---- 3. norm / re-quantization of x into LDS; meanwhile the last two waves (not stagers) park the RoPE table
+    if constexpr (EPI == EPI_QKV) {
+        if (tid >= T - 128 && tid - (T - 128) < (a.D >> 1)) {
+            const int kk = tid - (T - 128);
+            s_rope[2 * kk] = rope_pre[0];
+            s_rope[2 * kk + 1] = rope_pre[1];
+        }
+    }
+    big_stage_x<F16_D, XSRC>(ba, xr, nb, nbp, tid, T, s_lo, s_hi, s_d, s_sum, s_part);
+    const long long t_staged = ts ? big_now() : 0;
+    // ---- 2b. the rest of the ring
+#pragma unroll
+    for (int k = PF0; k < PF; k++) {
+        issue(ring[k], pj, k >= S);
+        advance(k);
+    }
+    __syncthreads();
+    const long long t_barrier = ts ? big_now() : 0;
+    long long t_first = 0;
+    if (probe == 2) return;
+    if constexpr (EPI == EPI_QKV) {
+        if (early && wave == W) {  // the spare wave: lane (w, j) waits for the mailbox entry of wave w's unit j if that is a Q pair
+            const int hw = lane / MB_SLOTS, hj = lane % MB_SLOTS;
+            bool pend = false;
+            int u = 0, m0 = 0;
+            if (lane < 16 * MB_SLOTS && hw < W) {
+                u = hw * G + bid + G * W * hj;
+                if (u < Utot && u * RU < M0) {
+                    pend = true;
+                    m0 = u * RU;
+                }
+            }
+            const long long c0 = big_now();
+            while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+                if (pend && __hip_atomic_load(&s_mbf[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                    const float v0 = s_mb[lane * 2], v1 = s_mb[lane * 2 + 1];
+                    const int kk = (m0 % a.D) >> 1;
+                    const float c = s_rope[2 * kk], sn = s_rope[2 * kk + 1];
+                    const __half h0 = __float2half_rn(v0 * c - v1 * sn), h1 = __float2half_rn(v0 * sn + v1 * c);
+                    gran_store(ba.gran + u, epoch, (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16));
+                    pend = false;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (big_now() - c0 > 5000000) break;  // 50 ms: cannot happen (the waves of this workgroup run); the consumers' own timeout reports it
+            }
+        }
+    }
+
+    // ---- 4. dots.  The unrolled body only accumulates; when a unit's last column is done its NR sums are reduced
+    //         across the wave and parked in lane `unit index` (myv), the epilogues run afterwards, one lane each.
+    float acc[NR], myv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) acc[k] = myv[k] = 0.0f;
+    int ci = 0, cj = 0;  // consumer position
+    for (int s = 0; s < S; s += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            if (s + k < S) {  // wave-uniform
+                const int b = lane + 64 * cj;  // < nbp: the padded LDS blocks are zero
+                const i32x4 lo = s_lo[b], hi = s_hi[b];
+                const float xd = s_d[b];
+                const int xs = s_sum[b];
+                const BigStep<QT, NR> &st = ring[k];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (probe == 4 && (k & 1)) continue;  // measurement: half the dots
+                    u32x4 p2 = st.q[r];
+                    uint32_t hh = 0;
+                    float mw = 0.0f;
+                    if constexpr (QT == QT_Q8_0) p2 = st.p[r];
+                    if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) hh = st.h[r];
+                    if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mw = __half2float(st.mw[r]);
+                    acc[r] += block_dot<QT>(st.q[r], p2, hh, __half2float(st.dw[r]), mw, lo, hi, xd, xs);
+                }
+                if (ts && s + k == 0) t_first = acc[0] != 12345.678f ? big_now() : 1;  // first step's weights landed
+                if (++cj == nbl) {
+                    cj = 0;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const float v = probe == 5 ? acc[r] : wave_sum_f32(acc[r]);  // 5: measurement, no reduction
+                        myv[r] = lane == ci ? v : myv[r];
+                        acc[r] = 0.0f;
+                    }
+                    if constexpr (EPI == EPI_QKV) {
+                        if (early && ci < MB_SLOTS && lane == ci) {  // a Q pair of one of the wave's first units: into the mailbox (LDS only)
+                            int sg, m0;
+                            resolve(ci, sg, m0);
+                            if (sg == 0) {
+                                s_mb[(wave * MB_SLOTS + ci) * 2] = myv[0];
+                                s_mb[(wave * MB_SLOTS + ci) * 2 + 1] = myv[1];
+                                __hip_atomic_store(&s_mbf[wave * MB_SLOTS + ci], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                    ci++;
+                }
+                if (s + k + PF < S) {
+                    issue(ring[k], pj, false);
+                    if (++pj == nbl) {
+                        pj = 0;
+                        if (s + k + PF + 1 < S) set_unit(++pi);
+                    }
+                }
+            }
+        }
+    }
+    const long long t_dots = ts ? big_now() : 0;
+
+    // ---- 5. epilogues: lane i finishes unit i
+    if (lane < nu && probe != 3) {
+        int sg, m0;
+        resolve(lane, sg, m0);
+        if constexpr (EPI == EPI_STORE) {
+            a.dst[m0] = myv[0];
+        } else if constexpr (EPI == EPI_ADD) {
+            a.dst[m0] = myv[0] + res_pre;
+        } else if constexpr (EPI == EPI_GATE) {
+            a.dst[m0] = silu_table(myv[0]) * myv[1];
+        } else {  // EPI_QKV, see k_mmvq_dec
+            const int p = store_at ? store_at : n_past;
+            __half h0, h1;  // the pair as f16: what the K/V cache holds, and what ggml's F16 mat-mul makes of Q (src1 -> f16)
+            if (sg == 2) {
+                h0 = __float2half_rn(myv[0]);
+                h1 = __float2half_rn(myv[1]);
+                a.mem_v[(int64_t)m0 * a.C + p] = h0;
+                a.mem_v[(int64_t)(m0 + 1) * a.C + p] = h1;
+            } else {
+                const int kk = (m0 % a.D) >> 1;
+                const float c = s_rope[2 * kk], sn = s_rope[2 * kk + 1];
+                const float r0 = myv[0] * c - myv[1] * sn, r1 = myv[0] * sn + myv[1] * c;
+                h0 = __float2half_rn(r0);
+                h1 = __float2half_rn(r1);
+                if (sg == 0) {
+                    if (!ba.gran) {
+                        a.dst[m0] = r0;
+                        a.dst[m0 + 1] = r1;
+                    }
+                } else {
+                    a.mem_k[(int64_t)p * a.Egqa + m0] = h0;
+                    a.mem_k[(int64_t)p * a.Egqa + m0 + 1] = h1;
+                }
+            }
+            if (ba.gran && !(early && sg == 0 && lane < MB_SLOTS)) {  // one aligned 8-byte agent-scope (write-through) store: the data is the flag
+                const unsigned v2 = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
+                gran_store(ba.gran + (u_first + u_stride * lane), epoch, v2);
+            }
+        }
+    }
+    if (ts && wave == 0 && lane == 0) {
+        const int q = G / ba.ts_wgs;
+        if (q > 0 && bid % q == 0 && bid / q < ba.ts_wgs) {
+            long long *o = ts + (bid / q) * 8;
+            o[0] = t_entry; o[1] = t_issued; o[2] = t_staged; o[3] = t_barrier; o[4] = t_first; o[5] = big_now();
+            o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = bid;
+        }
+    }
+}
+template <int QT, int EPI, int XSRC, bool INSTR = false>
+__global__ void __launch_bounds__(BIG_T) k_mmvq_big(const BigArgs ba) {
+    big_body<QT, EPI, XSRC, INSTR>(ba, (int)blockIdx.x, (int)gridDim.x);
+}
