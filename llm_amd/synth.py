@@ -126,7 +126,8 @@ def write_ggjt(path, hp, w, container="ggjt", version=3, vocab=None):
     """Writes a LLaMA model file the way crates/ggml/src/format/saver.rs:86-160 does: magic (+ version), the
     hyperparameters of models/llama/src/lib.rs:449-458, the vocabulary (u32 len, bytes, f32 score — no score in the
     legacy 'ggml' container), then per tensor (i32 n_dims, i32 name_len, u32 type, i32 dims[], name, padding to a
-    32-byte boundary for ggjt, data).  `w`: the dict of make_llama*(): raw GGML bytes for 2-D weights, f32 for 1-D."""
+    32-byte boundary for ggjt, data).  `w`: the dict of make_llama*(): raw GGML bytes for 2-D weights, f32 for 1-D.  hp["wtypes"] (optional): {tensor name: ggml type}
+    for files that mix types, as the *_K_S / *_K_M quantizations do (the tensor records carry their own type)."""
     import struct
     from . import ggml
     magic = {"ggml": 0x67676d6c, "ggmf": 0x67676d66, "ggjt": 0x67676a74}[container]
@@ -145,7 +146,7 @@ def write_ggjt(path, hp, w, container="ggjt", version=3, vocab=None):
                 f.write(struct.pack("<f", score))
         for name, (ne0, ne1) in shapes.items():
             nb = name.encode()
-            typ = ggml.TYPE_F32 if ne1 is None else hp["wtype"]
+            typ = ggml.TYPE_F32 if ne1 is None else hp.get("wtypes", {}).get(name, hp["wtype"])  # per-tensor types of a mixed file
             dims = (ne0,) if ne1 is None else (ne0, ne1)
             f.write(struct.pack("<iiI", len(dims), len(nb), typ))
             f.write(struct.pack(f"<{len(dims)}i", *dims))

@@ -385,3 +385,39 @@ def test_host_greedy_argmax_follows_the_scalar_rule(G):
         want = ref(a) if a.size <= 300 else int(np.flatnonzero(a == np.nanmax(a))[0]) if not np.isnan(a[0]) else 0
         for which in (0, 1):
             assert lib.llm_argmax_first(a.ctypes.data, a.size, which) == want, (a.size, which)
+
+
+def test_container_reader_takes_a_mixed_k_quant_file(tmp_path):
+    """A *_K_M-style file: attention.wv, feed_forward.w2 and output as Q6_K, the other matrices Q4_K, norms f32 — every tensor
+    record carries its own type (crates/ggml/src/format/loader.rs:160-281; file types crates/llm-base/src/loader.rs:80-93).
+    The reader must report each tensor's type, dims and (32-byte aligned) data as written.  Blocks are random bytes: the reader
+    does not interpret them.  No device involved."""
+    from llm_amd import ggml as G, llama, synth
+    hp = dict(n_vocab=64, n_embd=256, n_head=4, n_head_kv=4, n_layer=2, n_rot=64, n_ff=512, n_mult=32, wtype=G.TYPE_Q4_K)
+    wt = {"output.weight": G.TYPE_Q6_K}
+    for i in range(hp["n_layer"]):
+        wt[f"layers.{i}.attention.wv.weight"] = G.TYPE_Q6_K
+        wt[f"layers.{i}.feed_forward.w2.weight"] = G.TYPE_Q6_K
+    hp["wtypes"] = wt
+    rng = np.random.default_rng(12)
+    w = {}
+    for name, (ne0, ne1) in synth.tensor_shapes(hp).items():
+        if ne1 is None:
+            w[name] = rng.standard_normal(ne0).astype(np.float32)
+        else:
+            w[name] = rng.integers(0, 256, G.row_bytes(wt.get(name, G.TYPE_Q4_K), ne0) * ne1, dtype=np.uint8)
+    p = tmp_path / "mixed_k.bin"
+    synth.write_ggjt(p, hp, w)
+    info = llama.inspect_file(p)
+    assert info is not None and info["container"] == 2 and info["version"] == 3
+    assert info["hp"].file_type == 2000 + G.FTYPE_OF[G.TYPE_Q4_K]
+    shapes = synth.tensor_shapes(hp)
+    assert [t["name"] for t in info["tensors"]] == list(shapes)
+    n6 = 0
+    for t in info["tensors"]:
+        ne0, ne1 = shapes[t["name"]]
+        want = G.TYPE_F32 if ne1 is None else wt.get(t["name"], G.TYPE_Q4_K)
+        n6 += want == G.TYPE_Q6_K
+        assert t["type"] == want and t["offset_mod32"] == 0 and t["ne"] == (ne0, 1 if ne1 is None else ne1)
+        assert t["head"] == np.ascontiguousarray(w[t["name"]]).tobytes()[:16]
+    assert n6 == 1 + 2 * hp["n_layer"]

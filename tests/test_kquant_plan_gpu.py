@@ -277,3 +277,38 @@ def test_k_plan_at_long_context_uses_the_split_attention(G, O):
     print(f"long context: K plan vs executor worst |dlogit|/std = {worst:.2e}")
     assert worst <= 4e-2
     model.free()
+
+
+def test_mixed_k_quant_file_loads_and_decodes_on_the_k_plan(G, O, tmp_path):
+    """llm::load of a *_K_M-style GGJT v3 file (wv / w2 / output Q6_K, the rest Q4_K; written the way
+    crates/ggml/src/format/saver.rs does, every tensor record with its own type) through the C++ mmap loader: prompt feed at
+    n_batch = 8 and greedy decode on the K plan, bit-identical to the same weights handed over in memory."""
+    from llm_amd import llama, synth
+    hp0 = dict(n_vocab=256, n_embd=512, n_head=4, n_head_kv=4, n_layer=3, n_rot=128, n_ff=768, n_mult=32)  # the file format has no n_head_kv
+    wt = {"output.weight": 14}
+    for i in range(hp0["n_layer"]):
+        wt[f"layers.{i}.attention.wv.weight"] = 14
+        wt[f"layers.{i}.feed_forward.w2.weight"] = 14
+    hp, w = _model(O, hp0, 12, 19, wtypes=wt)
+    path = tmp_path / "q4_k_m.bin"
+    synth.write_ggjt(str(path), hp, w)
+    toks = np.random.default_rng(3).integers(0, hp["n_vocab"], 21).astype(np.int32)
+
+    def run(model):
+        s = model.start_session(n_batch=8)
+        k0 = _stat(G, "kplan_tokens")
+        s.feed_prompt(toks)
+        ids = [s.infer_next_token() for _ in range(10)]
+        ran = _stat(G, "kplan_tokens") - k0
+        last = s.last_logits().copy()
+        s.free()
+        return ids, last, ran
+
+    mem = llama.Llama(hp, w, context_size=64)
+    a = run(mem)
+    mem.free()
+    fil = llama.Llama.load(str(path), context_size=64)
+    b = run(fil)
+    fil.free()
+    assert a[2] == 21 + 10 and b[2] == 21 + 10  # chunks of 8, 8, 5 and ten single tokens: all on the K plan
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
