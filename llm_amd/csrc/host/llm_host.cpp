@@ -613,6 +613,10 @@ llm_model *llm_llama_new(const llm_llama_hparams *hp, const llm_model_params *mp
     h.n_layer = hp->n_layer;
     h.n_rot = hp->n_rot;
     h.file_type = hp->file_type;
+    if (mp->n_gqa > 0 && h.n_layer >= 80) {  // models/llama/src/lib.rs:106-117: "temporary fix for 70B models"
+        if (h.n_head % (size_t)mp->n_gqa != 0) ggml::panic("assuming 70B Llama2 model based on GQA == 8");  // the reference's assert_eq!
+        h.n_head_kv = h.n_head / (size_t)mp->n_gqa;
+    }
     llm::ModelParameters p;
     p.context_size = mp->context_size > 0 ? mp->context_size : 2048;
     p.use_gpu = mp->use_gpu != 0;

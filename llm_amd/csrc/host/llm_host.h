@@ -30,6 +30,10 @@ typedef struct {
     int32_t rope_frequency_base;
     /* layer-split extension: this process owns layers [layer_begin, layer_end) */
     int32_t layer_begin, layer_end; /* 0,-1 = all */
+    /* ModelParameters::n_gqa (crates/llm-base/src/model/mod.rs:213-214): grouped-query factor, 0 = None.  As in the reference
+     * (crates/models/llama/src/lib.rs:106-117) it is honoured for models of 80 layers and more only ("temporary fix for 70B"):
+     * n_head_kv = n_head / n_gqa; the container carries no n_head_kv. */
+    int32_t n_gqa;
 } llm_model_params;
 
 /* crates/llm-base/src/inference_session.rs:799-841 InferenceSessionConfig */

@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_attn_split_one(const AttnSplitOneArgs 
     const int h = blockIdx.x, s = blockIdx.y, hk = h / a.n_rep;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = a.prm->n_past + 1;
-    const unsigned tag = ((*f.epoch) * 64u + (unsigned)(f.layer & 63)) | 0x80000000u;
+    const unsigned tag = ((*f.epoch) * 4096u + (unsigned)(f.layer & 4095)) | 0x80000000u;
     int t0, t1;
     attn_split_range(T, a.S, s, t0, t1);
     const int chunk = (((T + a.S - 1) / a.S) + 63) & ~63;

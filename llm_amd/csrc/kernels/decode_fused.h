@@ -295,7 +295,7 @@ __device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_past = f.prm->n_past;
     const unsigned epoch = *f.epoch;
-    const unsigned tag = (epoch * 64u + (unsigned)(f.layer & 63)) | 0x80000000u;
+    const unsigned tag = (epoch * 4096u + (unsigned)(f.layer & 4095)) | 0x80000000u;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int NPRE = 8;
     const int T = n_past + 1;

@@ -16,7 +16,7 @@ class _HP(C.Structure):
 class _MP(C.Structure):
     _fields_ = [("context_size", C.c_int32), ("use_gpu", C.c_int32), ("gpu_layers", C.c_int32),
                 ("has_rope_overrides", C.c_int32), ("rope_frequency_scale", C.c_float),
-                ("rope_frequency_base", C.c_int32), ("layer_begin", C.c_int32), ("layer_end", C.c_int32)]
+                ("rope_frequency_base", C.c_int32), ("layer_begin", C.c_int32), ("layer_end", C.c_int32), ("n_gqa", C.c_int32)]
 
 
 class _SC(C.Structure):
@@ -144,7 +144,7 @@ class Llama:
             descs[i].data = arr.ctypes.data
         h = _HP(hp["n_vocab"], hp["n_embd"], hp.get("n_mult", 256), hp["n_head"], hp["n_head_kv"], hp["n_layer"],
                 hp["n_rot"], 2 * 1000 + ggml.FTYPE_OF[hp["wtype"]])
-        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, lb, le)
+        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, lb, le, 0)
         if rope_overrides:
             mp.has_rope_overrides = 1
             mp.rope_frequency_scale = rope_overrides["frequency_scale"]
@@ -153,7 +153,7 @@ class Llama:
         self.ptr = L.llm_llama_new(C.byref(h), C.byref(mp), descs, len(shapes))
 
     @classmethod
-    def load(cls, path, context_size=2048, gpu_layers=-1):
+    def load(cls, path, context_size=2048, gpu_layers=-1, n_gqa=0):
         """llm::load::<Llama>(path, …, ModelParameters{prefer_mmap: true, use_gpu: true}): the C++ container reader
         (llm_ggml_file_open) maps the GGML/GGMF/GGJT file and the tensors point into the mapping."""
         L = _lib()
@@ -161,13 +161,15 @@ class Llama:
         if info is None:
             raise ValueError(f"{path}: not a loadable GGML-family container")
         self = cls.__new__(cls)
-        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, 0, -1)
+        mp = _MP(context_size, 1, gpu_layers, 0, 1.0, 10000, 0, -1, n_gqa)  # n_gqa: ModelParameters::n_gqa (80 layers and more)
         self.ptr = L.llm_llama_load(str(path).encode(), C.byref(mp))
         if not self.ptr:
             raise ValueError(f"{path}: load failed")
         h = info["hp"]
         wtype = next(t["type"] for t in info["tensors"] if t["n_dims"] == 2)
         n_ff = next(t["ne"][1] for t in info["tensors"] if t["name"].endswith("feed_forward.w1.weight"))
+        if n_gqa > 0 and h.n_layer >= 80:
+            h.n_head_kv = h.n_head // n_gqa
         self.hp = dict(n_vocab=h.n_vocab, n_embd=h.n_embd, n_mult=h.n_mult, n_head=h.n_head, n_head_kv=h.n_head_kv,
                        n_layer=h.n_layer, n_rot=h.n_rot, n_ff=n_ff, wtype=wtype)
         self.weights = None

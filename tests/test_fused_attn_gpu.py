@@ -279,3 +279,41 @@ def test_several_attention_workgroups_per_head_inside_the_qkv_launch(G, O, shape
     print(f"{shape}: vs oracle worst |dlogit|/std = {worst_o[1]:.2e} (separate split attention: {worst_o[0]:.2e})")
     assert worst_o[1] <= max(4e-2, 2.0 * worst_o[0]) and worst_o[1] <= 1e-1
     model.free()
+
+
+def test_hand_off_tags_stay_unique_beyond_64_layers(G):
+    """The granules of the attention hand-offs carry tag = f(token epoch, layer) and share their buffers between layers; a model
+    with more than 64 layers (LLaMA-65B: 80) must not see an earlier layer's granules as current.  66 layers, 2048 wide:
+    (a) 2 attention workgroups per head inside the wq|wk|wv launch against the separate split attention, (b) k_attn_split_one
+    against its three launches (bit-identical), at ~600 positions."""
+    from llm_amd import llama, synth
+    hp0 = dict(n_vocab=64, n_embd=2048, n_head=16, n_head_kv=16, n_layer=66, n_rot=128, n_ff=256, n_mult=32)
+    hp, w = synth.make_llama(hp0, 2, seed=44)
+    model = llama.Llama(hp, w, context_size=1024)
+    toks = np.random.default_rng(1).integers(0, hp["n_vocab"], 640).astype(np.int32)
+
+    def run(heads, split, one):
+        G.set_option("fuse_heads", heads)
+        G.set_option("attn_split", split)
+        G.set_option("attn_one", one)
+        try:
+            s = model.start_session(n_batch=512)
+            s.feed_prompt(toks[:600])
+            outs = [s.evaluate(toks[600 + i:601 + i])[-1].copy() for i in range(4)]
+            s.free()
+        finally:
+            G.set_option("fuse_heads", 1)
+            G.set_option("attn_split", 1)
+            G.set_option("attn_one", 1)
+        return outs
+
+    fused = run(1, 1, 1)
+    one = run(0, 512, 1)
+    three = run(0, 512, 0)
+    assert _stat(G, "fused_attn_timeouts") == 0
+    for x, y in zip(one, three):
+        assert np.array_equal(x, y)
+    worst = max(float(np.max(np.abs(x - y))) / float(y.std()) for x, y in zip(fused, one))
+    print(f"66 layers: fused heads vs split attention worst |dlogit|/std = {worst:.2e}")
+    assert worst <= 1e-1  # Q8 flips through 66 layers; stale granules would give O(1)
+    model.free()

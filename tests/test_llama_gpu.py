@@ -748,3 +748,31 @@ def test_layer_split_hop_through_rccl_inside_the_library(G, O):
     finally:
         L.ggml_hip_comm_destroy()
     assert L.ggml_hip_comm_ranks() == 0
+
+
+def test_n_gqa_model_parameter_of_an_80_layer_file(G, tmp_path):
+    """ModelParameters::n_gqa (crates/llm-base/src/model/mod.rs:213-214): the container has no n_head_kv; the reference sets
+    n_head_kv = n_head / n_gqa for models of 80 layers and more (crates/models/llama/src/lib.rs:106-117).  An 80-layer grouped-query
+    model written to a GGJT file and loaded with n_gqa = 2 must reproduce the in-memory model (n_head_kv given) bit for bit."""
+    from llm_amd import llama, synth
+    hp0 = dict(n_vocab=64, n_embd=128, n_head=4, n_head_kv=2, n_layer=80, n_rot=32, n_ff=384, n_mult=32)
+    hp, w = synth.make_llama(hp0, 2, seed=80)
+    path = tmp_path / "gqa80.bin"
+    synth.write_ggjt(str(path), hp, w)
+    toks = np.random.default_rng(80).integers(0, hp["n_vocab"], 12).astype(np.int32)
+
+    def run(model):
+        s = model.start_session(n_batch=8)
+        a = s.evaluate(toks[:8]).copy()
+        b = [s.evaluate(toks[8 + i:9 + i])[-1].copy() for i in range(4)]
+        s.free()
+        return a, b
+
+    mem = llama.Llama(hp, w, context_size=32)
+    ra = run(mem)
+    mem.free()
+    fil = llama.Llama.load(str(path), context_size=32, n_gqa=2)
+    assert fil.hp["n_head_kv"] == 2
+    rb = run(fil)
+    fil.free()
+    assert np.array_equal(ra[0], rb[0]) and all(np.array_equal(x, y) for x, y in zip(ra[1], rb[1]))
