@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the token after the timed loop")
     ap.add_argument("--roofline-steps", type=int, default=20)
     ap.add_argument("--split", type=int, default=2, help="--mode split: device slots ONE session is layer-split over (one process)")
-    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "feed", "split"],
+    ap.add_argument("--sessions", default="1,2,4", help="--mode sessions: session counts to run, comma-separated")
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "feed", "split", "sessions"],
                     help="decode = BASELINE configs[1] (the metric); prefill = configs[2], 512-token prompt batch on MFMA; "
                          "feed = InferenceSession::feed_prompt in chunks of --n-batch (profiling leg)")
     ap.add_argument("--n-batch", type=int, default=8, help="--mode feed: tokens per Model::evaluate (the reference's default is 8)")
@@ -689,6 +690,68 @@ def run_split(args):
         raise SystemExit("bench.py --mode split: the split session produced different tokens")
 
 
+def run_sessions(args):
+    """Several InferenceSessions of ONE model decoding concurrently on one GPU, one thread each (the reference's contract:
+    crates/llm-base/src/inference_session.rs:43-48, model/mod.rs:275-276).  Every session lives on its own device slot of the
+    model's GPU (llm_start_session_on: own stream, arena shadows, K/V, plan cache) and streams the model's one copy of the
+    weights; value = aggregate tokens/s of the largest session count, next to one session alone in the same process."""
+    import threading
+    counts = sorted({max(1, int(c)) for c in args.sessions.split(",")})
+    os.environ["GGML_HIP_VIRTUAL_DEVICES"] = str(max(counts))
+    from llm_amd import ggml
+    L = ggml.lib()
+    hp, w, model, prep = build_model(args)
+    prompt = np.random.default_rng(42).integers(0, hp["n_vocab"], args.prompt).astype(np.int32)
+    runs = []
+    for n in counts:
+        sess = [model.start_session_on(i, n_batch=8) for i in range(n)]
+        for s in sess:
+            s.feed_prompt(prompt)
+            for _ in range(args.warmup):
+                s.infer_next_token()
+        for i in range(n):
+            L.ggml_hip_bind_thread_device(i)
+            L.ggml_hip_synchronize()
+        L.ggml_hip_bind_thread_device(0)
+        start = threading.Barrier(n + 1)
+        lat, ids = [None] * n, [None] * n
+
+        def run(i):
+            start.wait()
+            t0 = time.perf_counter()
+            ids[i] = [sess[i].infer_next_token() for _ in range(args.steps)]
+            lat[i] = (time.perf_counter() - t0) / args.steps
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+        for t in th:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        timeouts = int(L.ggml_hip_get_stat(b"fused_attn_timeouts"))
+        runs.append({"sessions": n, "aggregate_tokens_per_s": round(n * args.steps / el, 1),
+                     "per_session_ms_per_token": [round(x * 1e3, 4) for x in lat],
+                     "all_sessions_same_ids": all(x == ids[0] for x in ids), "fused_attn_timeouts": timeouts})
+        for s in sess:
+            s.free()
+        if timeouts or not runs[-1]["all_sessions_same_ids"]:
+            print(json.dumps(runs[-1]), flush=True)
+            raise SystemExit("bench.py --mode sessions: a session diverged or a hand-off gave up")
+    one = runs[0]["aggregate_tokens_per_s"] if runs[0]["sessions"] == 1 else None
+    for r in runs:
+        r["vs_one_session"] = round(r["aggregate_tokens_per_s"] / one, 3) if one else None
+    best = runs[-1]
+    print(json.dumps({"metric": f"aggregate decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}, {best['sessions']} concurrent sessions of one model on one GPU",
+                      "value": best["aggregate_tokens_per_s"], "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(1e3 / best["aggregate_tokens_per_s"], 4), "higher_is_better": True, "scaling": "weak",
+                      "data": "synthetic", "runs": runs,
+                      "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} greedy decode, {args.prompt}-token prompt per session, ctx 2048, "
+                                             "one thread and one device slot per session, one resident copy of the weights"}}), flush=True)
+    model.free()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -704,6 +767,9 @@ def main():
         return
     if args.mode == "split":
         run_split(args)
+        return
+    if args.mode == "sessions":
+        run_sessions(args)
         return
     run_single(args)
 

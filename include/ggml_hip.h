@@ -464,6 +464,10 @@ GGML_API int ggml_hip_device_count(void);
  * one model serves several of them), calls on one slot are serialised.  ggml_hip_get_main_device = the caller's slot. */
 GGML_API int ggml_hip_get_main_device(void);
 GGML_API void ggml_hip_bind_thread_device(int device);
+/* -1 while the calling thread follows the process default, else the slot it is pinned to; unbind drops the pin again (the
+ * session mirror pins a model's slot around each call and must leave a thread that followed the default following it). */
+GGML_API int ggml_hip_thread_pinned_device(void);
+GGML_API void ggml_hip_unbind_thread_device(void);
 /* ggml_hip_set_tensor_split / ggml_cuda_set_tensor_split read exactly ONE float: the reference passes the address of a
  * single stack f32 (crates/ggml/src/accelerator/mod.rs:74-75).  get returns that value (out[0]; 1 written). */
 GGML_API int ggml_hip_get_tensor_split(float *out, int cap);

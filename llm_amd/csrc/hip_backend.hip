@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -99,17 +100,21 @@ namespace {
 // ===================================================================================================
 // exported: internal seam
 // ===================================================================================================
-// Host arenas are known to every slot (a context made while one device is current may be used while another is): the
-// registry is per slot, so that each slot owns its shadows, and both calls are applied to all of them.
-static void register_arena_here(void *host_base, size_t size, int is_scratch);
-static void unregister_arena_here(void *host_base);
+// Host arenas are known to every slot; registration only appends to the process-wide event log (backend_state.inc "host
+// arenas"), each slot applies it under its own lock at its next entry point.
 extern "C" void ggml_hip_internal_register_arena(void *host_base, size_t size, int is_scratch) {
-    for_each_slot([&] { register_arena_here(host_base, size, is_scratch); });
+    arena_event(true, host_base, size, is_scratch);
 }
-extern "C" void ggml_hip_internal_unregister_arena(void *host_base) {
-    for_each_slot([&] { unregister_arena_here(host_base); });
+extern "C" void ggml_hip_internal_unregister_arena(void *host_base) { arena_event(false, host_base, 0, 0); }
+namespace {
+void evict_all_auto_tensors() {
+    for (auto it = g.auto_tensors.begin(); it != g.auto_tensors.end();) {
+        DevTensor *e = it->second;
+        it = g.auto_tensors.erase(it);
+        destroy_record(e);
+    }
 }
-static void register_arena_here(void *host_base, size_t size, int is_scratch) {
+void register_arena_here(void *host_base, size_t size, int is_scratch) {
     const uintptr_t b = (uintptr_t)host_base;
     if (size == 0) return;
     auto it = g.arenas.find(b);
@@ -141,7 +146,7 @@ static void register_arena_here(void *host_base, size_t size, int is_scratch) {
     g.arenas[b] = a;
 }
 
-static void unregister_arena_here(void *host_base) {
+void unregister_arena_here(void *host_base) {
     const uintptr_t b = (uintptr_t)host_base;
     auto it = g.arenas.find(b);
     if (it == g.arenas.end()) return;
@@ -178,6 +183,8 @@ static void unregister_arena_here(void *host_base) {
         g.arenas.erase(it);
     }
 }
+
+}  // namespace
 
 extern "C" void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) {
     SlotLock lk;
@@ -241,6 +248,11 @@ void ggml_hip_bind_thread_device(int device) {
     SlotLock lk(g_cur);
     g.slot = device;
     if (g.inited) bind_device();
+}
+int ggml_hip_thread_pinned_device(void) { return tl_pinned ? (int)(g_cur - g_backends) : -1; }
+void ggml_hip_unbind_thread_device(void) {
+    tl_pinned = false;
+    g_cur = &g_backends[g_default_slot.load(std::memory_order_relaxed)];
 }
 void ggml_hip_set_tensor_split(const float *tensor_split) {
     // crates/ggml/sys/src/cuda.rs:11.  The reference's only caller passes the address of ONE stack float
@@ -758,6 +770,12 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
     else if (k == "big") {
         if (g.opt_big != value) drop_all_plans();
         g.opt_big = value;
+    }
+    else if (k == "fused_fallback")  // 1 = a token whose in-launch hand-off gave up is re-run on the two-launch forms; 0 = abort
+        g.opt_fused_fallback = value;
+    else if (k == "test_fused_timeout") {  // test hook: the attention workgroups of layer 0 of k_qkv_attn never get their rows
+        if (g.opt_test_fused_timeout != value) drop_all_plans();
+        g.opt_test_fused_timeout = value;
     }
     else if (k == "probe") {
         if (g.opt_probe != value) drop_all_plans();

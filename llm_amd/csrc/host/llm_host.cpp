@@ -197,6 +197,11 @@ class InferenceSession {
         last_graph = nullptr;
     }
 
+    void drop_prebuilt() {  // a speculatively built next-token graph no longer describes the session's next call
+        pre_.valid = false;
+        last_graph = nullptr;
+    }
+
     // hand-off buffers of a layer-split stage: n_embd * rows floats each, rows = n_batch to begin with.  Model::evaluate may
     // be called with more tokens than n_batch (an unsplit model takes any count): the buffers then grow to that count
     // (ensure_stage_rows, called by the graph builder before it makes its views).
@@ -371,8 +376,12 @@ class Llama {
     bool is_last() const { return params.layer_end == hyperparameters.n_layer; }
     size_t n_local_layers() const { return params.layer_end - params.layer_begin; }
 
-    InferenceSession *start_session(const InferenceSessionConfig &config) const {  // :133-141
-        InferenceSession *s = new InferenceSession(config, params, n_local_layers(), hyperparameters.n_embd,
+    // on_slot >= 0: the session lives on that device slot (which the caller made current) instead of the model's — a sibling
+    // slot of the same GPU: its own stream, shadows and plan workspace, the model's weights (llm_start_session_on)
+    InferenceSession *start_session(const InferenceSessionConfig &config, int on_slot = -1) const {  // :133-141
+        ModelParameters sp = params;
+        if (on_slot >= 0) sp.main_device = on_slot;  // (keeps InferenceSession::new from re-initialising device 0, as for split stages)
+        InferenceSession *s = new InferenceSession(config, sp, n_local_layers(), hyperparameters.n_embd,
                                                    hyperparameters.n_vocab);
         // stage hand-off buffers: persistent device tensors (like memory_k/v) that RCCL sends from / receives into
         if (!is_first() || !is_last()) s->make_stage_buffers(hyperparameters.n_embd, !is_first(), !is_last());
@@ -540,16 +549,22 @@ namespace {
 // Every entry point leaves the caller's main device as it found it: an unsplit model runs on the slot it was loaded on
 // (llm_model::device), a split one walks its stages' slots.
 struct HomeDevice {
+    int pinned = ggml_hip_thread_pinned_device();  // -1: the thread follows the process default, and must again afterwards
     int home = ggml_hip_get_main_device();
     void go(int d) const {
         if (ggml_hip_get_main_device() != d) ggml_hip_bind_thread_device(d);  // this thread only: the process default stays
     }
-    ~HomeDevice() { go(home); }
+    ~HomeDevice() {
+        if (pinned < 0)
+            ggml_hip_unbind_thread_device();  // (a later ggml_hip_set_main_device from another thread reaches this one again)
+        else
+            go(home);
+    }
 };
 void model_evaluate(llm_model *m, llm_session *s, const std::vector<llm::TokenId> &toks, llm::OutputRequest &req) {
     HomeDevice hd;
     if (m->stages.empty()) {
-        hd.go(m->device);
+        hd.go(s->device);  // the session's slot: the model's, or a sibling slot of the same GPU (llm_start_session_on)
         if (!m->llama->is_first() || !m->llama->is_last())  // one stage of a per-process split (llm_amd/pipeline.py)
             s->s->ensure_stage_rows(m->llama->hyperparameters.n_embd, toks.size());
         m->llama->evaluate(*s->s, toks, req);
@@ -937,6 +952,44 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
     s->device = m->device;
     s->s = m->llama->start_session(c);
     return s;
+}
+// Several sessions of ONE model on one GPU (crates/llm-base/src/inference_session.rs:43-48: a session is Send;
+// model/mod.rs:275-276: "spawn several sessions for one model"): every session gets its own device SLOT on the model's GPU — its
+// own stream, arena shadows, K/V memory, plan cache and workspace — and reads the model's weights where the model's slot put them
+// (slots of one physical device may read each other's weights, backend_state.inc extra_of).  Sessions on different slots run
+// concurrently (per-slot locks; the host arenas are an event log, no cross-slot locking per token), so two decode streams fill
+// each other's kernel-boundary and latency gaps.  `slot` must drive the same physical device as the model's slot
+// (GGML_HIP_VIRTUAL_DEVICES=n provides n slots on a 1-GPU box; slot = -1: the model's own).  Unsplit models only.
+llm_session *llm_start_session_on(llm_model *m, const llm_session_config *cfg, int slot) {
+    if (slot < 0 || !m->stages.empty() || slot == m->device) return llm_start_session(m, cfg);
+    llm::InferenceSessionConfig c;
+    if (cfg) {
+        c.memory_k_type = (ggml_type)cfg->memory_k_type;
+        c.memory_v_type = (ggml_type)cfg->memory_v_type;
+        c.n_batch = cfg->n_batch > 0 ? (size_t)cfg->n_batch : 8;
+        c.n_threads = cfg->n_threads > 0 ? (size_t)cfg->n_threads : 8;
+    }
+    llm_session *s = new llm_session();
+    HomeDevice hd;
+    hd.go(slot);
+    s->device = slot;
+    s->s = m->llama->start_session(c, slot);
+    return s;
+}
+// test / restore hook: the session continues at position n_past (what InferenceSession::from_snapshot does with the snapshot's
+// npast, inference_session.rs:640) — the caller has put the K/V of the positions before it in place (llm_session_kv)
+void llm_session_seek(llm_session *s, int n_past) {
+    s->s->n_past = (size_t)n_past;
+    for (auto *st : s->stage_sessions) st->n_past = (size_t)n_past;
+    s->s->drop_prebuilt();
+}
+// 0 = the reference's own call sequence inside InferenceSession::compute (build the graph, then ggml_graph_compute, synchronously:
+// inference_session.rs:220-295); 1 (default; env LLM_HOST_SPECULATE) = the patched sequence that builds the NEXT token's graph
+// between ggml_hip_graph_compute_begin / _end while the device runs
+void llm_session_set_speculate(llm_session *s, int on) {
+    s->s->speculate = on != 0;
+    for (auto *st : s->stage_sessions) st->speculate = on != 0;
+    s->s->drop_prebuilt();
 }
 void llm_session_free(llm_session *s) {
     if (!s) return;

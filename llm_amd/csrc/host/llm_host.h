@@ -86,6 +86,10 @@ GGML_API int llm_ggml_file_vocab(const llm_ggml_file *f, int i, char *buf, int c
 /* llm::load for LLaMA: open + Llama::new over the mapping (kept alive by the model); hyperparameters from the file */
 GGML_API llm_model *llm_llama_load(const char *path, const llm_model_params *params);
 GGML_API llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg);
+/* a session of an unsplit model on another device slot of the model's GPU: own stream / shadows / K/V / plans, shared weights */
+GGML_API llm_session *llm_start_session_on(llm_model *m, const llm_session_config *cfg, int slot);
+GGML_API void llm_session_seek(llm_session *s, int n_past);
+GGML_API void llm_session_set_speculate(llm_session *s, int on);
 GGML_API void llm_session_free(llm_session *s);
 /* Model::evaluate (models/llama/src/lib.rs:144-368): feeds n tokens at the session's n_past.
  * all_logits (nullable): n*n_vocab floats (OutputRequest.all_logits); embeddings (nullable): n_embd floats. */

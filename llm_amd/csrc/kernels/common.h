@@ -175,6 +175,13 @@ __device__ __forceinline__ void gran_store(unsigned long long *g_, unsigned epoc
 __device__ __forceinline__ unsigned long long gran_load(const unsigned long long *g_) {
     return __hip_atomic_load((gu64 *)g_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Every in-launch wait is bounded, and bounded in POLLS, not in wall-clock time: a poll is an L2 round trip plus an s_sleep
+// (>= ~0.7 us), so 2^18 of them are >= ~0.2 s of the wave actually running.  A wave that is context-switched out (another
+// process's queue on the same GPU) does not poll, so time-slicing cannot trip the bound the way a wall-clock limit could; a peer
+// that is never scheduled (the launch is not fully resident) does.  A wait that gives up raises the plan's error word, which the
+// host reads back with every token's results (llama_plan.inc token_finish): the token is re-run on the kernels that do not wait
+// inside a launch, or the process aborts with a message.
+#define GRAN_SPIN_MAX (1 << 18)
 
 // ---- which branch of ggml's activation quantizer (quantize_row_q8_0 / quantize_row_q8_1) the kernels restate ---------
 // The reference builds ggml with -mavx2 -mfma -mf16c on every AVX2 host (crates/ggml/sys/build.rs:46-62), so what its CPU

@@ -200,18 +200,19 @@ __global__ void __launch_bounds__(256) k_attn_split_out(const AttnSplitArgs a) {
 //     follows the second hand-off runs out of registers;
 //   * the S partial outputs travel as granules too; an arrival counter per head elects the LAST workgroup, which sums the
 //     partials (s ascending) and re-quantizes for wo.  Nobody waits for it.
-// tag = f(token epoch, layer): unique per launch, so the buffers are reused by every layer and a replayed hipGraph never
-// takes an older launch's granules for current.  Same float operations in the same order as the three launches:
+// tag = the token's epoch (all 32 bits; k_rope_table bumps it once per token) and every layer has its OWN hand-off buffers,
+// so a launch never takes another launch's granules for current — neither another layer's of this token nor, in a replayed
+// hipGraph, an older token's (a 19-bit epoch shared with 12 bits of layer would repeat every 2^19 tokens).  Same float operations in the same order as the three launches:
 // BIT-IDENTICAL outputs (tests/test_fused_attn_gpu.py runs both).  Every spin is bounded (err is raised).
 // ---------------------------------------------------------------------------------------------------
 struct AttnSplitOneArgs {
     AttnSplitArgs a;            // q, caches, prm, scale, shapes, Q8 outputs (sc / pmax / part unused)
-    unsigned long long *mx_g;   // [n_head][S] range maxima
-    unsigned long long *sum_g;  // [n_head][S][2] range sums (f64 as hi, lo words)
-    unsigned long long *part_g; // [n_head][S][D] partial-output granules
+    unsigned long long *mx_g;   // THIS layer's [n_head][S] range maxima
+    unsigned long long *sum_g;  // ... [n_head][S][2] range sums (f64 as hi, lo words)
+    unsigned long long *part_g; // ... [n_head][S][D] partial-output granules
     unsigned *cnt;              // [n_head] arrival counters (zero between launches)
     const unsigned *epoch;      // the token's epoch (k_rope_table)
-    int layer;
+    int layer;                  // (informational)
     unsigned *err;
     float *out_f32;             // nullable: the merged heads as f32 [n_head * D] (the K plan re-quantizes them to Q8_K itself)
 };
@@ -219,12 +220,11 @@ struct AttnSplitOneArgs {
 __device__ __forceinline__ unsigned long long attn_one_wait(const unsigned long long *gp, unsigned tag, unsigned *err) {
     unsigned long long x = gran_load(gp);
     if ((unsigned)(x >> 32) == tag) return x;
-    const long long t0 = (long long)wall_clock64();
-    for (;;) {
+    for (int spin = 0;; spin++) {
         __builtin_amdgcn_s_sleep(1);
         x = gran_load(gp);
         if ((unsigned)(x >> 32) == tag) return x;
-        if ((long long)wall_clock64() - t0 > 5000000) {  // 50 ms at 100 MHz: a peer never arrived
+        if (spin > GRAN_SPIN_MAX) {  // a peer never arrived (see GRAN_SPIN_MAX, kernels/common.h)
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return x;
         }
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_attn_split_one(const AttnSplitOneArgs 
     const int h = blockIdx.x, s = blockIdx.y, hk = h / a.n_rep;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = a.prm->n_past + 1;
-    const unsigned tag = ((*f.epoch) * 4096u + (unsigned)(f.layer & 4095)) | 0x80000000u;
+    const unsigned tag = *f.epoch;  // the token's epoch, all 32 bits: the hand-off buffers are per layer (AttnSplitOneArgs)
     int t0, t1;
     attn_split_range(T, a.S, s, t0, t1);
     const int chunk = (((T + a.S - 1) / a.S) + 63) & ~63;

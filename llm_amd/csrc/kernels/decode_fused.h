@@ -15,7 +15,8 @@
 // polling loads, no fence, no counter); it does not depend on which XCD or in which order workgroups run: producers never
 // wait, consumers wait only for producers, and all G workgroups fit the chip at once (one 1024-thread workgroup per CU).  The
 // tag is a device word bumped once per token (k_rope_table), so a replayed hipGraph never sees its own previous granules as
-// current.  Every spin is bounded (FusedAttnArgs::err is raised, the token's logits are then garbage but nothing hangs).
+// current.  Every spin is bounded (GRAN_SPIN_MAX polls; FusedAttnArgs::err is raised and read back with the token's results: the host
+// re-runs the token on the two-launch pair or aborts with a message, llama_plan.inc token_finish).
 // Arithmetic = k_attn_decode's, hence ggml's: f32 dot of f16 K with f16 Q, scale, row max, f16-rounded exp of the f16-rounded
 // difference, f64 sum, f16 probabilities, f32 V.P, Q8 re-quantization for wo.
 #pragma once
@@ -38,7 +39,7 @@ struct FusedAttnArgs {
     unsigned *err;  // raised when a wait gave up
     // S > 1: S attention workgroups per head, workgroup s takes positions [512 s, 512 (s + 1)) (attn_consumer_split below)
     int S, layer;
-    unsigned long long *mx_g, *sum_g, *part_g;  // hand-off granules of k_attn_split_one (decode_attn_split.h): [n_head][S], [..][S][2], [..][S][D]
+    unsigned long long *mx_g, *sum_g, *part_g;  // this LAYER's hand-off granules of k_attn_split_one (decode_attn_split.h): [n_head][S], [..][S][2], [..][S][D]
     unsigned *cnt;                              // [n_head] arrival counters
 };
 
@@ -95,14 +96,13 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
         const int half_d = D >> 1;
         const int base = wave == 0 ? h * half_d : wave == 1 ? f.k_pair0 + hk * half_d : f.v_pair0 + hk * half_d;
         const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
-        const long long t0 = (long long)wall_clock64();
         unsigned long long x;
-        for (;;) {
+        for (int spin = 0;; spin++) {
             x = gran_load(gp);
             const bool ok = (unsigned)(x >> 32) == epoch;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
             __builtin_amdgcn_s_sleep(2);
-            if ((long long)wall_clock64() - t0 > 5000000) {  // 50 ms at 100 MHz: a producer never arrived
+            if (spin > GRAN_SPIN_MAX) {  // a producer never arrived (see GRAN_SPIN_MAX, kernels/common.h)
                 if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -295,7 +295,7 @@ __device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_past = f.prm->n_past;
     const unsigned epoch = *f.epoch;
-    const unsigned tag = (epoch * 4096u + (unsigned)(f.layer & 4095)) | 0x80000000u;
+    const unsigned tag = epoch;  // all 32 bits of the token's epoch: mx_g / sum_g / part_g are this layer's own buffers
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int NPRE = 8;
     const int T = n_past + 1;
@@ -332,14 +332,13 @@ __device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, cons
         const int half_d = D >> 1;
         const int base = which == 0 ? h * half_d : which == 1 ? f.k_pair0 + hk * half_d : f.v_pair0 + hk * half_d;
         const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
-        const long long c0 = (long long)wall_clock64();
         unsigned long long x;
-        for (;;) {
+        for (int spin = 0;; spin++) {
             x = gran_load(gp);
             const bool ok = (unsigned)(x >> 32) == epoch;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
             __builtin_amdgcn_s_sleep(2);
-            if ((long long)wall_clock64() - c0 > 5000000) {
+            if (spin > GRAN_SPIN_MAX) {
                 if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }

@@ -226,6 +226,8 @@ PROTOTYPES.update({
     "ggml_hip_read_timeline": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ggml_hip_get_main_device": (C.c_int, []),
     "ggml_hip_bind_thread_device": (None, [C.c_int]),
+    "ggml_hip_thread_pinned_device": (C.c_int, []),
+    "ggml_hip_unbind_thread_device": (None, []),
     "ggml_hip_get_tensor_split": (C.c_int, [C.c_void_p, C.c_int]),
     "ggml_hip_set_layer_split": (None, [C.c_void_p, C.c_int]),
     "ggml_hip_get_layer_split": (C.c_int, [C.c_void_p, C.c_int]),

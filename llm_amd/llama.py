@@ -55,6 +55,10 @@ def _lib():
         L.llm_start_session.restype = C.c_void_p
         L.llm_start_session.argtypes = [C.c_void_p, C.POINTER(_SC)]
         L.llm_session_free.argtypes = [C.c_void_p]
+        L.llm_start_session_on.restype = C.c_void_p
+        L.llm_start_session_on.argtypes = [C.c_void_p, C.POINTER(_SC), C.c_int]
+        L.llm_session_seek.argtypes = [C.c_void_p, C.c_int]
+        L.llm_session_set_speculate.argtypes = [C.c_void_p, C.c_int]
         L.llm_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.llm_feed_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.llm_infer_next_token_greedy.restype = C.c_int32
@@ -188,6 +192,11 @@ class Llama:
     def start_session(self, n_batch=8, kv_type=ggml.TYPE_F16):
         return Session(self, n_batch, kv_type)
 
+    def start_session_on(self, slot, n_batch=8, kv_type=ggml.TYPE_F16):
+        """A session of this (unsplit) model on another device slot of the model's GPU: its own stream, K/V and plans, the
+        model's weights — sessions on different slots run concurrently (llm_start_session_on)."""
+        return Session(self, n_batch, kv_type, slot=slot)
+
     def session_from_snapshot(self, blob):
         """InferenceSession::from_snapshot; None on SnapshotError."""
         blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
@@ -205,10 +214,20 @@ class Llama:
 
 
 class Session:
-    def __init__(self, model, n_batch, kv_type):
+    def __init__(self, model, n_batch, kv_type, slot=-1):
         self.model = model
         cfg = _SC(kv_type, kv_type, n_batch, 8)
-        self.ptr = _lib().llm_start_session(model.ptr, C.byref(cfg))
+        self.ptr = (_lib().llm_start_session(model.ptr, C.byref(cfg)) if slot < 0 else
+                    _lib().llm_start_session_on(model.ptr, C.byref(cfg), slot))
+
+    def seek(self, n_past):
+        """The session continues at position n_past (the caller has put the K/V before it in place: set_kv)."""
+        _lib().llm_session_seek(self.ptr, int(n_past))
+
+    def set_speculate(self, on):
+        """False = the reference's own call sequence per token (build the graph, then ggml_graph_compute); True = the next
+        token's graph is built between ggml_hip_graph_compute_begin / _end while the device runs."""
+        _lib().llm_session_set_speculate(self.ptr, 1 if on else 0)
 
     @property
     def n_past(self):

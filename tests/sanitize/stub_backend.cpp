@@ -55,6 +55,8 @@ int ggml_hip_device_count(void) { return 1; }
 void ggml_hip_set_main_device(int d) { g_main_device = d; }
 int ggml_hip_get_main_device(void) { return g_main_device; }
 void ggml_hip_bind_thread_device(int) {}
+int ggml_hip_thread_pinned_device(void) { return -1; }
+void ggml_hip_unbind_thread_device(void) {}
 void ggml_hip_set_tensor_split(const float *s) { g_split = s ? s[0] : 0.0f; }
 int ggml_hip_get_layer_split(float *out, int cap) {
     if (out && cap > 0) out[0] = g_split;

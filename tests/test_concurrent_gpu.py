@@ -31,8 +31,7 @@ def _decode(sess, toks, n):
 def test_sessions_on_two_slots_overlap_and_match_the_sequential_runs(G):
     from llm_amd import llama, synth
     L = G.lib()
-    if L.ggml_hip_get_main_device() != 0:
-        pytest.skip("another test left a different main device")
+    assert L.ggml_hip_get_main_device() == 0  # every test (and every entry point) leaves the main device as it found it
     hp, w = synth.make_llama(HP, 2, seed=23)
     os.environ["GGML_HIP_VIRTUAL_DEVICES"] = "2"
     models = []
@@ -88,11 +87,69 @@ def test_sessions_on_two_slots_overlap_and_match_the_sequential_runs(G):
     assert peak >= 2  # both threads were inside the library at once (with one library lock this could never exceed 1)
 
 
+def test_sessions_of_one_model_on_sibling_slots_share_its_weights(G):
+    """The reference's use (model/mod.rs:275-276): ONE model, several sessions, each on its own thread.  Every session sits on its
+    own device slot of the model's GPU (llm_start_session_on: own stream, shadows, K/V, plans) and reads the model's one copy of
+    the weights.  Results = the same sessions run one after the other on the model's own slot, bit for bit — decode through the
+    fused launches (which stay legal: 2 slots x 8 attention workgroups), prompt chunks, and a 40-token prompt batch through the
+    prompt plan (resident f16 weight copies made by whichever slot comes first, under the library's w16 lock)."""
+    from llm_amd import llama, synth
+    L = G.lib()
+    assert L.ggml_hip_get_main_device() == 0
+    hp, w = synth.make_llama(HP, 2, seed=29)
+    os.environ["GGML_HIP_VIRTUAL_DEVICES"] = "3"
+    model = None
+    try:
+        G.set_option("fuse_attn", 2)
+        model = llama.Llama(hp, w, context_size=160)
+        prompts = [np.random.default_rng(s).integers(0, hp["n_vocab"], 19 + 40).astype(np.int32) for s in (11, 12, 13)]
+        N = 48
+
+        def decode(sess, p):
+            sess.feed_prompt(p[:19])          # chunks of 8: the multi-token plan
+            out = _decode(sess, p[19:], N)    # then 40 tokens in one evaluation (n_batch = 64: the prompt plan), then decode
+            return out, sess.get_kv()
+
+        ref = []
+        for p in prompts:
+            s = model.start_session(n_batch=64)
+            ref.append(decode(s, p))
+            s.free()
+        f0 = _stat(G, "fused_attn_tokens")
+        sessions = [model.start_session_on(i, n_batch=64) for i in range(3)]
+        got = [None] * 3
+        start = threading.Barrier(3)
+
+        def run(i):
+            start.wait()
+            got[i] = decode(sessions[i], prompts[i])
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for s in sessions:
+            s.free()
+        assert _stat(G, "fused_attn_timeouts") == 0
+        assert L.ggml_hip_get_main_device() == 0
+    finally:
+        G.set_option("fuse_attn", 1)
+        if model is not None:
+            model.free()
+        L.ggml_hip_set_main_device(0)
+        os.environ.pop("GGML_HIP_VIRTUAL_DEVICES", None)
+    for (ro, (rk, rv)), (go, (gk, gv)) in zip(ref, got):
+        assert [t for t, _ in ro] == [t for t, _ in go]
+        for (_, la), (_, lb) in zip(ro, go):
+            assert np.array_equal(la, lb)
+        assert np.array_equal(rk, gk) and np.array_equal(rv, gv)
+
+
 def test_bind_thread_device_is_per_thread(G):
     """ggml_hip_bind_thread_device pins the calling thread only; ggml_hip_set_main_device also moves the process default."""
     L = G.lib()
-    if L.ggml_hip_get_main_device() != 0:
-        pytest.skip("another test left a different main device")
+    assert L.ggml_hip_get_main_device() == 0  # every test (and every entry point) leaves the main device as it found it
     os.environ["GGML_HIP_VIRTUAL_DEVICES"] = "3"
     seen = {}
     try:

@@ -150,8 +150,7 @@ def test_k_plan_stages_of_a_layer_split_reproduce_the_unsplit_session(G, O):
     residual crosses unchanged — bit-identical to the unsplit session."""
     import os
     from llm_amd import llama
-    if G.lib().ggml_hip_get_main_device() != 0:
-        pytest.skip("another test left a different main device")
+    assert G.lib().ggml_hip_get_main_device() == 0  # every test (and every entry point) leaves the main device as it found it
     hp0 = dict(n_vocab=256, n_embd=256, n_head=4, n_head_kv=4, n_layer=5, n_rot=64, n_ff=512, n_mult=32)
     hp, w = _model(O, hp0, 12, 41)
     toks = np.random.default_rng(4).integers(0, hp["n_vocab"], 20).astype(np.int32)

@@ -138,14 +138,15 @@ def _stat(G, key):
     return int(G.lib().ggml_hip_get_stat(key.encode()))
 
 
-def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
+def _layers_alone(G, O, hp0, wtype, n_layer, P=21, ctx=64, with_chunks=True, want_variant=None):
+    """`n_layer - 1` layers of an `n_layer`-deep stack of the given width, each run ALONE on the device (a layer-split stage: the
+    graphs the fused plans accept) on the ORACLE's input rows and K/V; the layer's output is bounded by 2 x the oracle's own
+    two-order band on the same rows (cap LAYER_CAP).  P = prompt length = position of the decode token."""
     from llm_amd import llama, synth
-    Q4_0 = 2
-    hp0 = dict(synth.LLAMA_7B)
-    hp0["n_layer"], hp0["n_vocab"] = 6, 512  # layers 0..4 are checked (the last one ends in the lm_head, not in a residual)
-    hp, w = synth.make_llama_gaussian(hp0, Q4_0)
-    L, E, ctx = hp["n_layer"], hp["n_embd"], 64
-    P = 21
+    hp0 = dict(hp0)
+    hp0["n_layer"], hp0["n_vocab"] = n_layer, 512  # the last layer ends in the lm_head, not in a residual: not checked
+    hp, w = synth.make_llama_gaussian(hp0, wtype)
+    L, E = hp["n_layer"], hp["n_embd"]
     toks = np.random.default_rng(42).integers(0, hp["n_vocab"], P + 1).astype(np.int32)
     mode = O.ref_mode()
     orc = O.Llama(hp, w, ctx)
@@ -155,7 +156,7 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
     k_prompt, v_prompt = orc.memory_k.copy(), orc.memory_v.copy()
     _, td = orc.evaluate(toks[P:], mode=mode, taps=True)
     k_full, v_full = orc.memory_k.copy(), orc.memory_v.copy()
-    Eg = E  # n_head_kv == n_head
+    Eg = E // (hp["n_head"] // hp["n_head_kv"])
     per = ctx * Eg
     worst, n_strict, n_cases, results = 0.0, 0, 0, []
     band_mx, band_rms = 0.0, 0.0
@@ -181,6 +182,7 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
         sess = stage.start_session(n_batch=32)
         in_dev, out_dev, nbytes = sess.stage_buffers()
         assert (in_dev or il == 0) and out_dev and nbytes >= 13 * E * 4  # layer 0 starts from the token ids (get_rows)
+        fh0 = _stat(G, "fused_heads_tokens")
         zero = np.zeros(per, np.uint16)
 
         def run(rows_in, n_past, tok_slice, k_before, v_before):
@@ -191,6 +193,8 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
             sess.set_kv(kk, vv)
             if sess.n_past > n_past:
                 assert sess.rewind(sess.n_past - n_past) == 0
+            elif sess.n_past < n_past:
+                sess.seek(n_past)  # the K/V of the positions before it are the oracle's (set_kv above)
             assert sess.n_past == n_past
             x = np.ascontiguousarray(rows_in, np.float32)
             if il > 0:
@@ -205,9 +209,9 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
         # K/V "before" a prompt chunk: the oracle's cache holds the whole prompt; positions >= n_past are rewritten by the
         # device before anything reads them (the chunk's own rows), so handing it the full prompt cache is teacher forcing
         # for the rows below n_past and harmless above
-        cases = (("chunk of 8 at 0", lay_in_p[:8], 0, toks[:8], k_prompt, v_prompt, tp["layer_out_all"][il][:8]),
-                 ("chunk of 13 at 8", lay_in_p[8:21], 8, toks[8:21], k_prompt, v_prompt, tp["layer_out_all"][il][8:21]),
-                 ("decode at 21", lay_in_d, P, toks[P:], k_prompt, v_prompt, td["layer_out_all"][il]))
+        cases = ((("chunk of 8 at 0", lay_in_p[:8], 0, toks[:8], k_prompt, v_prompt, tp["layer_out_all"][il][:8]),
+                  ("chunk of 13 at 8", lay_in_p[8:21], 8, toks[8:21], k_prompt, v_prompt, tp["layer_out_all"][il][8:21])) if with_chunks else ()) + (
+                 (f"decode at {P}", lay_in_d, P, toks[P:], k_prompt, v_prompt, td["layer_out_all"][il]),)
         for name, rows_in, n_past, tsl, kb, vb, want in cases:
             p0 = _stat(G, "plan_tokens")
             got = run(rows_in, n_past, tsl, kb, vb)
@@ -234,11 +238,38 @@ def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
             worst = max(worst, mx)
             n_strict += mx <= STRICT
             n_cases += 1
+        if want_variant == "fused_heads":  # the decode token took k_qkv_attn with several attention workgroups per head
+            assert _stat(G, "fused_heads_tokens") - fh0 == 1
         sess.free()
         stage.free()
     print(f"per-layer teacher forcing: device worst max {worst:.2e}, {n_strict} of {n_cases} evaluations within STRICT {STRICT}; "
           f"oracle's own band over the same cases: max {band_mx:.2e} rms {band_rms:.2e}")
-    assert n_strict >= 1  # a row without a flipped quant exists among 15 evaluations, and there the device is exact to 2e-5
+    if with_chunks and L >= 6:
+        assert n_strict >= 1  # a row without a flipped quant exists among 15 evaluations, and there the device is exact to 2e-5
     for il, name, mx, rms, nkv, tot in results:
         assert mx <= LAYER_CAP and mx <= max(2 * band_mx, 10 * STRICT) and rms <= max(2 * band_rms, 10 * STRICT), (il, name, mx, rms, band_mx, band_rms)
         assert nkv <= 0.01 * tot, (il, name, nkv, tot)
+
+
+def test_every_layer_alone_on_the_oracles_input_at_7b_width(G, O):
+    from llm_amd import synth
+    _layers_alone(G, O, synth.LLAMA_7B, 2, 6)  # Q4_0, layers 0..4: BASELINE configs[1] / [2]
+
+
+def test_a_layer_alone_at_13b_width_q5_1(G, O):
+    """BASELINE configs[3]'s shape and block format (E = 5120, 40 heads, F = 13824, Q5_1): two layers, one at a time."""
+    from llm_amd import synth
+    _layers_alone(G, O, synth.LLAMA_13B, 7, 3)
+
+
+def test_a_layer_alone_at_65b_width_q8_0(G, O):
+    """BASELINE configs[4]'s shape and block format (E = 8192, 64 heads, F = 22016, Q8_0): one layer."""
+    from llm_amd import synth
+    _layers_alone(G, O, synth.LLAMA_65B, 8, 2, with_chunks=False)
+
+
+def test_a_layer_alone_beyond_512_positions_takes_two_attention_workgroups_per_head(G, O):
+    """The decode token at position 600 of a 7B-wide layer: k_qkv_attn with S = 2 attention workgroups per head (the form the
+    long-context decode lines run), teacher-forced like the short-context case — oracle input rows, oracle K/V of 600 positions."""
+    from llm_amd import synth
+    _layers_alone(G, O, synth.LLAMA_7B, 2, 3, P=600, ctx=1024, with_chunks=False, want_variant="fused_heads")

@@ -34,8 +34,7 @@ def _run(G, model, toks, n_batch):
 @pytest.mark.parametrize("how", ["env3", "fractions"])
 def test_layer_split_over_device_slots_reproduces_the_unsplit_session(G, how):
     from llm_amd import llama, synth
-    if G.lib().ggml_hip_get_main_device() != 0:
-        pytest.skip("another test left a different main device")
+    assert G.lib().ggml_hip_get_main_device() == 0  # every test (and every entry point) leaves the main device as it found it
     hp, w = synth.make_llama(HP, 2, seed=17)
     toks = np.random.default_rng(2).integers(0, hp["n_vocab"], 64).astype(np.int32)
     whole = llama.Llama(hp, w, context_size=96)
@@ -83,8 +82,7 @@ def test_snapshot_moves_between_a_split_and_an_unsplit_session(G):
     concatenated in layer order are the unsplit layout, so a snapshot taken from a 3-slot session restores into an unsplit
     model (and the other way round) and decoding continues with the same tokens and logits."""
     from llm_amd import llama, synth
-    if G.lib().ggml_hip_get_main_device() != 0:
-        pytest.skip("another test left a different main device")
+    assert G.lib().ggml_hip_get_main_device() == 0  # every test (and every entry point) leaves the main device as it found it
     hp, w = synth.make_llama(HP, 2, seed=19)
     toks = np.random.default_rng(4).integers(0, hp["n_vocab"], 30).astype(np.int32)
     whole = llama.Llama(hp, w, context_size=96)
