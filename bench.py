@@ -376,6 +376,27 @@ def run_single(args):
     parity = parity_check(args, hp, w, sess) if not args.no_parity_check else None
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
     h1 = {k: stat(k) - v for k, v in h0.items()}
+    # the same steps through the reference's OWN call sequence: InferenceSession::compute builds the graph and then calls
+    # ggml_graph_compute synchronously (crates/llm-base/src/inference_session.rs:220-295) — no ggml_hip_graph_compute_begin / _end,
+    # nothing built ahead: what a rustformers/llm binary gets by linking this library with no source change at all
+    sess.set_speculate(False)
+    for _ in range(4):
+        sess.infer_next_token()
+    L.ggml_hip_synchronize()
+    n_ref = max(16, args.steps // 2)
+    sess.host_timing(reset=True)
+    tr = time.perf_counter()
+    for _ in range(n_ref):
+        sess.infer_next_token()
+    L.ggml_hip_synchronize()
+    ref_s = time.perf_counter() - tr
+    ht_ref = [x / n_ref / 1e3 for x in sess.host_timing()]
+    sess.set_speculate(True)
+    sess.infer_next_token()
+    reference_sequence = {"tokens_per_s": round(n_ref / ref_s, 2), "ms_per_token": round(ref_s / n_ref * 1e3, 4), "tokens": n_ref,
+                          "graph_build_us_per_token": round(ht_ref[0], 1),
+                          "what": "build the token's graph, then ggml_graph_compute (synchronous): InferenceSession::compute as the reference "
+                                  "has it (inference_session.rs:220-295), zero caller-side changes"}
     # the same greedy decode with the sampler on the device: ids identical to the loop above
     # (tests/test_llama_gpu.py), no logits read-back / host sync per token.  Reported beside the metric, not as it.
     sess.infer_next_token()
@@ -453,25 +474,41 @@ def run_single(args):
     att_ms, att_n, att_bytes = ggml.bench_plan_class(ggml.KCLASS_ATTN, rs)
     oth_ms, oth_n, _ = ggml.bench_plan_class(ggml.KCLASS_OTHER, rs)
     nl = hp["n_layer"]
-    dom = per_kind["gate_up"]
+    # the DOMINANT kernel = the launch kind with the most device time per token (launches x period), whatever its name
+    dom_kind = max(per_kind, key=lambda k: per_kind[k]["launches"] * per_kind[k]["us_per_launch"])
+    dom = per_kind[dom_kind]
+    for k, v in per_kind.items():
+        v["us_per_token"] = round(v["launches"] * v["us_per_launch"], 2)
+        v["frac"] = round(v["GBps"] / HBM_PEAK_GBS, 4)
     achieved = dom["GBps"]
     wb, nparams = weight_bytes_per_token(hp, ggml.BLOCK_BYTES[hp["wtype"]], ggml.BLOCK_ELEMS[hp["wtype"]])
-    traffic, traffic_from = None, None
-    for tp in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    traffic, traffic_from, traffic_all = None, None, None
+    for tp in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tp)
         if os.path.exists(tpath) and args.model == "7b" and args.wtype == "q4_0":
-            traffic = json.load(open(tpath))["gate_up"]["hbm_bytes_per_launch"]
+            tj = json.load(open(tpath))
+            traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+            traffic = traffic_all.get(dom_kind)
             traffic_from = ("profiles/" + tp + ": a COMMITTED figure from separate rocprofv3 --pmc passes of this kernel "
-                            "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run")
+                            "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run"
+                            + ("" if traffic is not None else "; it holds no entry for this launch kind"))
             break
     is_k = args.wtype.endswith("_k")
-    kernel_label = (f"k_mmvq_k / k_mmvq_k2<{args.wtype.upper()}, 1 column> (K plan: w1 and w3 as one launch each, Q8_K activations "
-                    f"staged in LDS; {2 * nl} launches per token)") if is_k else (
-                    f"k_mmvq_big<{args.wtype.upper()}, EPI_GATE, XSRC_NORM> (w1|w3 mat-vec, rms_norm + Q8 staging and "
-                    f"silu(w1 x)*(w3 x) epilogue fused; {nl} launches per token)")
-    roofline = {"bound": "hbm", "kernel": kernel_label,
+    W = args.wtype.upper()
+    labels = {"gate_up": f"k_mmvq_big<{W}, EPI_GATE, XSRC_NORM> (w1|w3 mat-vec, rms_norm + Q8 staging and silu(w1 x)*(w3 x) epilogue fused)",
+              "qkv": (f"k_qkv_attn<{W}> (wq|wk|wv mat-vec with rms_norm + Q8 staging, RoPE and K/V store on G - n_head workgroups + the "
+                      "attention of the token on n_head workgroups of the same launch; bytes = weights + the K/V the attention reads)")
+                     if fused_tokens else f"k_mmvq_big<{W}, EPI_QKV, XSRC_NORM> (wq|wk|wv mat-vec, rms_norm + Q8 staging, RoPE and K/V store fused)",
+              "down": f"k_mmvq_big<{W}, EPI_ADD, XSRC_F32> (w2 mat-vec, Q8 staging of the gate and residual add fused)",
+              "wo": f"k_mmvq_big<{W}, EPI_ADD, XSRC_Q8> (wo mat-vec + residual add)",
+              "lm_head": f"k_mmvq_big<{W}, EPI_STORE, XSRC_NORM> (final norm + lm_head)"}
+    kernel_label = (f"k_mmvq_k / k_mmvq_k2<{W}, 1 column> (K plan, launch kind '{dom_kind}': Q8_K activations staged in LDS)") if is_k else labels[dom_kind]
+    kernel_label += f"; {dom['launches']} launches per token = {dom['us_per_token']} us, the largest share of the token's device time"
+    roofline = {"bound": "hbm", "kernel": kernel_label, "kernel_kind": dom_kind,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_from": traffic_from,
+                "traffic_over_algo": round(traffic / dom["bytes_per_launch"], 4) if traffic else None,
+                "traffic_per_kind": traffic_all,
                 "avg_launch_us": dom["us_per_launch"], "algo_bytes_per_launch": dom["bytes_per_launch"],
                 "method": f"{rs} replays of a hipGraph with that launch of every layer between two HIP events on the "
                           "backend stream: launch period incl. the kernel boundary (= rocprofv3's per-kernel duration)",
@@ -503,6 +540,10 @@ def run_single(args):
            "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode "
                                   f"(BASELINE configs[1]), {args.prompt}-token prompt, ctx 2048, f16 KV, batch 1",
                       "n_past_at_start": args.prompt + args.warmup, "parallelism": "1 GPU",
+                      "call_sequence": {"value_uses": "InferenceSession::compute of the host mirror with the next token's graph built between "
+                                                      "ggml_hip_graph_compute_begin and _end while the device runs (two extension entry points; "
+                                                      "a caller-side change of ~10 lines, INTEGRATION.md section 2)",
+                                        "reference_call_sequence": reference_sequence},
                       "weights_in_hbm_before_timing": True, "host_split_per_token": host_split,
                       "decode_launches": {"qkv_and_attention_in_one_launch_tokens": int(fused_tokens), "of_timed_tokens": int(args.steps),
                                           "per_layer": "K plan, 13 launches: norm+Q8_K, wq, wk, wv, rope+K/V store, k_attn_decode, Q8_K, wo+residual, "

@@ -174,6 +174,35 @@ static void format_name(struct ggml_tensor *t, const char *fmt, ...) {
     vsnprintf(t->name, sizeof(t->name), fmt, args);
     va_end(args);
 }
+// The two name patterns on the per-token path — "<src> (view)" and friends for every view / reshape / permute, "node_<n>" /
+// "leaf_<n>" for every unnamed tensor the graph visits — without vsnprintf: a LLaMA-7B graph formats ~1400 names per token, and
+// the caller rebuilds the graph for every token (crates/llm-base/src/inference_session.rs:230); same bytes as the format strings
+// "%s<suffix>" and "<prefix>%d" give, truncated to the name field like snprintf.
+static void name_suffix(struct ggml_tensor *t, const char *src, const char *suffix) {
+    char *d = t->name;
+    char *const end = t->name + sizeof(t->name) - 1;
+    if (src != t->name)
+        while (*src && d < end) *d++ = *src++;
+    else
+        d += strlen(t->name) < (size_t)(end - d) ? strlen(t->name) : (size_t)(end - d);
+    while (*suffix && d < end) *d++ = *suffix++;
+    *d = 0;
+}
+static void name_index(struct ggml_tensor *t, const char *prefix, int n) {
+    char *d = t->name;
+    char *const end = t->name + sizeof(t->name) - 1;
+    while (*prefix && d < end) *d++ = *prefix++;
+    char digits[12];
+    int k = 0;
+    unsigned u = n < 0 ? 0u - (unsigned)n : (unsigned)n;
+    do {
+        digits[k++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    if (n < 0 && d < end) *d++ = '-';
+    while (k > 0 && d < end) *d++ = digits[--k];
+    *d = 0;
+}
 
 static inline bool same_shape(const ggml_tensor *a, const ggml_tensor *b) {
     return a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3];
@@ -378,7 +407,7 @@ struct ggml_tensor *ggml_dup_tensor(struct ggml_context *ctx, const struct ggml_
 }
 struct ggml_tensor *ggml_view_tensor(struct ggml_context *ctx, const struct ggml_tensor *src) {
     ggml_tensor *result = new_tensor_impl(ctx, src->type, src->n_dims, src->ne, src->data);
-    format_name(result, "%s (view)", src->name);
+    name_suffix(result, src->name, " (view)");
     for (int i = 0; i < GGML_MAX_DIMS; i++) result->nb[i] = src->nb[i];
     return result;
 }
@@ -475,7 +504,7 @@ struct ggml_tensor *ggml_cpy(struct ggml_context *ctx, struct ggml_tensor *a, st
     if (strlen(b->name) > 0)
         format_name(result, "%s (copy of %s)", b->name, a->name);
     else
-        format_name(result, "%s (copy)", a->name);
+        name_suffix(result, a->name, " (copy)");
     result->op = GGML_OP_CPY;
     result->src[0] = a;
     result->src[1] = b;
@@ -483,7 +512,7 @@ struct ggml_tensor *ggml_cpy(struct ggml_context *ctx, struct ggml_tensor *a, st
 }
 struct ggml_tensor *ggml_cont(struct ggml_context *ctx, struct ggml_tensor *a) {
     ggml_tensor *result = ggml_dup_tensor(ctx, a);
-    format_name(result, "%s (cont)", a->name);
+    name_suffix(result, a->name, " (cont)");
     result->op = GGML_OP_CONT;
     result->src[0] = a;
     return result;
@@ -494,7 +523,7 @@ static ggml_tensor *reshape_nd(ggml_context *ctx, ggml_tensor *a, int n_dims, co
     for (int i = 0; i < n_dims; i++) n *= ne[i];
     GGML_ASSERT(ggml_nelements(a) == n);
     ggml_tensor *result = new_tensor_impl(ctx, a->type, n_dims, ne, a->data);
-    format_name(result, "%s (reshaped)", a->name);
+    name_suffix(result, a->name, " (reshaped)");
     result->op = GGML_OP_RESHAPE;
     result->src[0] = a;
     return result;
@@ -517,7 +546,7 @@ struct ggml_tensor *ggml_reshape_3d(struct ggml_context *ctx, struct ggml_tensor
 }
 static ggml_tensor *view_nd(ggml_context *ctx, ggml_tensor *a, int n_dims, const int64_t *ne, size_t offset) {
     ggml_tensor *result = new_tensor_impl(ctx, a->type, n_dims, ne, (char *)a->data + offset);
-    format_name(result, "%s (view)", a->name);
+    name_suffix(result, a->name, " (view)");
     set_op_params(result, &offset, sizeof(offset));
     result->op = GGML_OP_VIEW;
     result->src[0] = a;
@@ -551,7 +580,7 @@ struct ggml_tensor *ggml_permute(struct ggml_context *ctx, struct ggml_tensor *a
     GGML_ASSERT(axis0 != axis1 && axis0 != axis2 && axis0 != axis3 && axis1 != axis2 && axis1 != axis3 &&
                 axis2 != axis3);
     ggml_tensor *result = ggml_view_tensor(ctx, a);
-    format_name(result, "%s (permuted)", a->name);
+    name_suffix(result, a->name, " (permuted)");
     int64_t ne[4];
     size_t nb[4];
     ne[axis0] = a->ne[0];
@@ -574,7 +603,7 @@ struct ggml_tensor *ggml_permute(struct ggml_context *ctx, struct ggml_tensor *a
 }
 struct ggml_tensor *ggml_transpose(struct ggml_context *ctx, struct ggml_tensor *a) {
     ggml_tensor *result = ggml_view_tensor(ctx, a);
-    format_name(result, "%s (transposed)", a->name);
+    name_suffix(result, a->name, " (transposed)");
     result->ne[0] = a->ne[1];
     result->ne[1] = a->ne[0];
     result->nb[0] = a->nb[1];
@@ -680,11 +709,11 @@ static void visit_parents(ggml_cgraph *cgraph, ggml_tensor *node) {
         if (node->src[i]) visit_parents(cgraph, node->src[i]);
     if (node->op == GGML_OP_NONE && node->grad == nullptr) {
         GGML_ASSERT(cgraph->n_leafs < GGML_MAX_NODES);
-        if (strlen(node->name) == 0) format_name(node, "leaf_%d", cgraph->n_leafs);
+        if (node->name[0] == 0) name_index(node, "leaf_", cgraph->n_leafs);
         cgraph->leafs[cgraph->n_leafs++] = node;
     } else {
         GGML_ASSERT(cgraph->n_nodes < GGML_MAX_NODES);
-        if (strlen(node->name) == 0) format_name(node, "node_%d", cgraph->n_nodes);
+        if (node->name[0] == 0) name_index(node, "node_", cgraph->n_nodes);
         cgraph->nodes[cgraph->n_nodes] = node;
         cgraph->grads[cgraph->n_nodes] = node->grad;
         cgraph->n_nodes++;

@@ -767,6 +767,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_fuse_attn != value) drop_all_plans();
         g.opt_fuse_attn = value;
     }
+    else if (k == "fuse_wo") {
+        if (g.opt_fuse_wo != value) drop_all_plans();
+        g.opt_fuse_wo = value;
+    }
     else if (k == "big") {
         if (g.opt_big != value) drop_all_plans();
         g.opt_big = value;
@@ -776,6 +780,8 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
     else if (k == "test_fused_timeout") {  // test hook: the attention workgroups of layer 0 of k_qkv_attn never get their rows
         if (g.opt_test_fused_timeout != value) drop_all_plans();
         g.opt_test_fused_timeout = value;
+        if (!value) g.stat_fused_timeouts = 0;  // the hook's own give-ups do not count against the rest of the process
+
     }
     else if (k == "probe") {
         if (g.opt_probe != value) drop_all_plans();

@@ -41,7 +41,187 @@ struct FusedAttnArgs {
     int S, layer;
     unsigned long long *mx_g, *sum_g, *part_g;  // this LAYER's hand-off granules of k_attn_split_one (decode_attn_split.h): [n_head][S], [..][S][2], [..][S][D]
     unsigned *cnt;                              // [n_head] arrival counters
+    // WO form (k_qkv_attn<.., WO = true>): the heads' re-quantized outputs are PUBLISHED to the mat-vec workgroups of the same
+    // launch instead of stored for a following wo launch: this layer's E/32 x OGRAN granules (publish_head_q8 below)
+    unsigned long long *ogran;
 };
+
+// ---------------------------------------------------------------------------------------------------
+// wo under the attention's tail.  After its last wq|wk|wv row pair (about 7 us into a 7B launch) a mat-vec workgroup is idle
+// while the attention workgroups run their latency chain (4 us), and the wo launch that follows pays a kernel boundary, a cold
+// start and 9.4 MB of weights on top.  In the WO form every mat-vec workgroup instead pulls ITS rows of wo (row m of wo belongs
+// to mat-vec workgroup m mod G; 42 KB at 7B) into registers while the attention runs, then gathers the heads' outputs — E int8
+// quants + E/32 scales and sums = 1280 granules at 7B, published by the n_head attention workgroups as they finish — and computes
+// its rows of wo.x + residual.  Same per-row arithmetic as k_mmvq_big<EPI_ADD, XSRC_Q8> (lane-strided blocks, steps in
+// order, DPP wave reduction, + residual): BIT-IDENTICAL to the separate launch.  Needs the whole launch resident like every
+// in-launch hand-off here, and now in BOTH directions (attention waits for the mat-vec's rows, the mat-vec's second phase for the
+// attention): the launcher takes it only while this slot has the GPU's CUs to itself (fused_qkv_shape).
+// ---------------------------------------------------------------------------------------------------
+#define OGRAN 10  // granules per Q8 block of the attention output: 4 words of quants 0..15, 4 of quants 16..31, d, sum
+struct WoTailArgs {
+    QWeight w;            // wo
+    const float *res;     // residual (the layer's input row)
+    float *dst;           // wo.x + residual
+    int cap;              // (unused)
+    long long *ts;        // optional timeline slot (option "timeline"): 8 x int64 per sampled workgroup, as big_body's
+    int ts_wgs;
+};
+constexpr int WO_NG_MAX = 2;  // granules per thread it may gather (E / 32 * OGRAN <= 2048)
+
+// the D outputs of head h (already in LDS s_o[D]) as Q8 blocks: plain stores for a following wo launch, or granules for the WO form
+template <bool F16_D>
+__device__ __forceinline__ void publish_head_q8(const FusedAttnArgs &f, const int h, const float v, const int nblk, const int l, const int b,
+                                                const unsigned epoch) {
+    float amax = fabsf(v);
+    amax = g32_max_f32(amax);
+    const float d = amax / 127.0f;
+    const float id = act_id(amax, d, aq_scalar());
+    const int qv = act_q(v * id, aq_scalar());
+    int sq = qv;
+    sq = g32_sum_i32(sq);
+    const int64_t gb = (int64_t)h * nblk + b;
+    if (f.ogran) {
+        // four neighbouring lanes' bytes -> one word (disjoint bits: the quad's OR by two DPP steps), published by the quad's first lane
+        int wv = (qv & 0xFF) << (8 * (l & 3));
+        wv |= dpp_i32<DPP_QUAD_XOR1>(wv);
+        wv |= dpp_i32<DPP_QUAD_XOR2>(wv);
+        unsigned long long *go = f.ogran + gb * OGRAN;
+        if ((l & 3) == 0) gran_store(go + (l >> 2), epoch, (unsigned)wv);
+        if (l == 0) {
+            gran_store(go + 8, epoch, __float_as_uint(F16_D ? round_f16(d) : d));
+            gran_store(go + 9, epoch, (unsigned)sq);
+        }
+        return;
+    }
+    (l < 16 ? f.lo : f.hi)[gb * 16 + (l & 15)] = (int8_t)qv;
+    if (l == 0) {
+        f.dq[gb] = F16_D ? round_f16(d) : d;
+        f.sumq[gb] = sq;
+    }
+}
+
+// second phase of a mat-vec workgroup in the WO form (bid of G, as in big_body); smem = the dynamic LDS of the launch, whose first
+// nbp * 40 bytes (the staged activation of wq|wk|wv) are re-used for the gathered attention output.  Wave w owns rows
+// w, w + 16 (of the workgroup's rows bid + G i) and keeps their blocks in REGISTERS, unpacked to int8 codes while the attention
+// still runs: behind the gather only 8 v_dot4 + the scale formula per block are left (block_dot_codes = block_dot's arithmetic).
+constexpr int WO_RW = 2;  // rows per wave (the workgroup holds at most 32 rows: ceil(M / G) <= 32)
+template <int QT, int NBLT>
+__device__ __forceinline__ void wo_tail(const WoTailArgs &t, const FusedAttnArgs &f, const int bid, const int G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nb = (int)t.w.nb, M = (int)t.w.M;
+    const int nbl = (nb + 63) >> 6, nbp = nbl * 64;  // nbl <= NBLT (launcher)
+    i32x4 *s_lo = (i32x4 *)smem;
+    i32x4 *s_hi = s_lo + nbp;
+    float *s_d = (float *)(s_hi + nbp);
+    int *s_sum = (int *)(s_d + nbp);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned epoch = *f.epoch;
+    const int nrows = bid < M ? (M - bid + G - 1) / G : 0;
+    const int nrw = wave < nrows ? (nrows - wave + 15) >> 4 : 0;  // rows of this wave: <= WO_RW
+    const long long t0 = t.ts ? (long long)wall_clock64() : 0;
+    // ---- this wave's rows of wo: requested now, they land while the attention runs
+    u32x4 q[WO_RW][NBLT], q2[QT == QT_Q8_0 ? WO_RW : 1][QT == QT_Q8_0 ? NBLT : 1];
+    uint32_t qh[(QT == QT_Q5_0 || QT == QT_Q5_1) ? WO_RW : 1][(QT == QT_Q5_0 || QT == QT_Q5_1) ? NBLT : 1];
+    __half dw[WO_RW][NBLT], mw[(QT == QT_Q4_1 || QT == QT_Q5_1) ? WO_RW : 1][(QT == QT_Q4_1 || QT == QT_Q5_1) ? NBLT : 1];
+#pragma unroll
+    for (int r = 0; r < WO_RW; r++) {
+        const int m = bid + G * (wave + 16 * r);
+        const size_t ro = (size_t)(uint32_t)(r < nrw ? m : 0) * (uint32_t)nb;
+#pragma unroll
+        for (int j = 0; j < NBLT; j++) {
+            const int b = lane + 64 * j;
+            const size_t o = ro + (uint32_t)(b < nb ? b : nb - 1);  // clamped: the loads are unconditional, invalid ones are not used
+            q[r][j] = __builtin_nontemporal_load((const u32x4 *)(t.w.qs + o * 16));
+            if constexpr (QT == QT_Q8_0) q2[r][j] = __builtin_nontemporal_load((const u32x4 *)(t.w.qs2 + o * 16));
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) qh[r][j] = __builtin_nontemporal_load(t.w.qh + o);
+            dw[r][j] = t.w.d[o];
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mw[r][j] = t.w.m[o];
+        }
+    }
+    // the residual of this wave's rows: lane r preloads row (wave + 16 r) of the workgroup
+    const float res_pre = t.res[lane < nrw ? bid + G * (wave + 16 * lane) : 0];
+    const long long t1 = t.ts ? (long long)wall_clock64() : 0;
+    __syncthreads();  // every wave is done with the staged activation of wq|wk|wv: its LDS is re-used from here on
+    for (int i = nb + tid; i < nbp; i += 1024) {  // padded blocks (a row that does not fill its last 64-block step) stay zero
+        s_lo[i] = i32x4{0, 0, 0, 0};
+        s_hi[i] = i32x4{0, 0, 0, 0};
+        s_d[i] = 0.0f;
+        s_sum[i] = 0;
+    }
+    uint32_t wl[WO_RW][NBLT][4], wh[WO_RW][NBLT][4];
+#pragma unroll
+    for (int r = 0; r < WO_RW; r++)
+#pragma unroll
+        for (int j = 0; j < NBLT; j++) {
+            u32x4 p2 = q[r][j];
+            uint32_t hh = 0;
+            if constexpr (QT == QT_Q8_0) p2 = q2[r][j];
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) hh = qh[r][j];
+            block_unpack<QT>(q[r][j], p2, hh, wl[r][j], wh[r][j]);
+        }
+    const long long t2 = t.ts ? (long long)wall_clock64() : 0;
+    // ---- the heads' outputs: nb * OGRAN granules, swept by all threads until every tag is this token's epoch
+    const int ngran = nb * OGRAN;
+#pragma unroll
+    for (int k = 0; k < WO_NG_MAX; k++) {
+        const int idx = tid + 1024 * k;
+        if (1024 * k >= ngran) break;  // uniform
+        const unsigned long long *gp = f.ogran + (idx < ngran ? idx : 0);
+        unsigned long long x;
+        for (int spin = 0;; spin++) {
+            x = gran_load(gp);
+            const bool ok = (unsigned)(x >> 32) == epoch;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (spin > GRAN_SPIN_MAX) {
+                if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (idx < ngran) {
+            const int blk = idx / OGRAN, j = idx - blk * OGRAN;
+            const unsigned v = (unsigned)x;
+            if (j < 4)
+                ((unsigned *)s_lo)[blk * 4 + j] = v;
+            else if (j < 8)
+                ((unsigned *)s_hi)[blk * 4 + (j - 4)] = v;
+            else if (j == 8)
+                s_d[blk] = __uint_as_float(v);
+            else
+                s_sum[blk] = (int)v;
+        }
+    }
+    const long long t3 = t.ts ? (long long)wall_clock64() : 0;
+    __syncthreads();
+    const long long t4 = t.ts ? (long long)wall_clock64() : 0;
+    // ---- rows: one row = nbl steps of 64 blocks, accumulated per lane in step order, DPP wave reduction: as in big_body
+    float myv = 0.0f;
+#pragma unroll
+    for (int r = 0; r < WO_RW; r++) {
+        if (r >= nrw) break;  // uniform
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NBLT; j++) {
+            const int b = lane + 64 * j;
+            if (b < nb) {
+                float m_ = 0.0f;
+                if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) m_ = __half2float(mw[r][j]);
+                acc += block_dot_codes<QT>(wl[r][j], wh[r][j], __half2float(dw[r][j]), m_, s_lo[b], s_hi[b], s_d[b], s_sum[b]);
+            }
+        }
+        const float v = wave_sum_f32(acc);
+        myv = lane == r ? v : myv;
+    }
+    if (lane < nrw) t.dst[bid + G * (wave + 16 * lane)] = myv + res_pre;
+    if (t.ts && tid == 0) {
+        const int qq = G / t.ts_wgs;
+        if (qq > 0 && bid % qq == 0 && bid / qq < t.ts_wgs) {
+            long long *o = t.ts + (bid / qq) * 8;
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = (long long)wall_clock64(); o[6] = nrows; o[7] = bid;
+        }
+    }
+}
 
 __device__ __forceinline__ f16x2 u32_as_h2(unsigned u) { return __builtin_bit_cast(f16x2, u); }
 
@@ -240,22 +420,7 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
     const long long t_vp = f.ts ? (long long)wall_clock64() : 0;
     // ---- the head's D outputs as Q8 blocks for wo ----
     const int nblk = D / 32, l = tid & 31, b = tid >> 5;
-    if (b < nblk) {
-        const float v = s_o[b * 32 + l];
-        float amax = fabsf(v);
-        amax = g32_max_f32(amax);
-        const float d = amax / 127.0f;
-        const float id = act_id(amax, d, aq_scalar());
-        const int qv = act_q(v * id, aq_scalar());
-        int sq = qv;
-        sq = g32_sum_i32(sq);
-        const int64_t gb = (int64_t)h * nblk + b;
-        (l < 16 ? f.lo : f.hi)[gb * 16 + (l & 15)] = (int8_t)qv;
-        if (l == 0) {
-            f.dq[gb] = F16_D ? round_f16(d) : d;
-            f.sumq[gb] = sq;
-        }
-    }
+    if (b < nblk) publish_head_q8<F16_D>(f, h, s_o[b * 32 + l], nblk, l, b, epoch);
     if (f.ts && tid == 0) {
         const int q4 = f.n_head / 4;
         if (q4 > 0 && h % q4 == 0 && h / q4 < 4) {
@@ -483,19 +648,7 @@ __device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, cons
     float v = 0.0f;
     for (int s2 = 0; s2 < S; s2++)
         v += __uint_as_float((unsigned)attn_one_wait(f.part_g + ((int64_t)h * S + s2) * D + b * 32 + l, tag, f.err));
-    float amax = fabsf(v);
-    amax = g32_max_f32(amax);
-    const float d = amax / 127.0f;
-    const float id = act_id(amax, d, aq_scalar());
-    const int qv = act_q(v * id, aq_scalar());
-    int sq = qv;
-    sq = g32_sum_i32(sq);
-    const int64_t gb = (int64_t)h * nblk + b;
-    (l < 16 ? f.lo : f.hi)[gb * 16 + (l & 15)] = (int8_t)qv;
-    if (l == 0) {
-        f.dq[gb] = F16_D ? round_f16(d) : d;
-        f.sumq[gb] = sq;
-    }
+    publish_head_q8<F16_D>(f, h, v, nblk, l, b, epoch);
 }
 
 template <int QT, bool INSTR = false>
@@ -510,4 +663,19 @@ __global__ void __launch_bounds__(1024) k_qkv_attn(const BigArgs ba, const Fused
         return;
     }
     big_body<QT, EPI_QKV, XSRC_NORM, INSTR>(ba, (int)blockIdx.x - A, (int)gridDim.x - A);
+}
+// the WO form: wq|wk|wv + attention + wo + residual in one launch (see wo_tail)
+template <int QT, int NBLT>
+__global__ void __launch_bounds__(1024) k_qkv_attn_wo(const BigArgs ba, const FusedAttnArgs fa, const WoTailArgs wt) {
+    constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
+    const int H = fa.n_head, A = H * (fa.S > 1 ? fa.S : 1);
+    if ((int)blockIdx.x < A) {
+        if (fa.S > 1)
+            attn_consumer_split<F16_D>(fa, (int)blockIdx.x % H, (int)blockIdx.x / H);
+        else
+            attn_consumer<F16_D>(fa, (int)blockIdx.x);
+        return;
+    }
+    big_body<QT, EPI_QKV, XSRC_NORM, false>(ba, (int)blockIdx.x - A, (int)gridDim.x - A);
+    wo_tail<QT, NBLT>(wt, fa, (int)blockIdx.x - A, (int)gridDim.x - A);
 }

@@ -52,10 +52,12 @@ def test_a_hand_off_that_never_arrives_is_rerun_on_the_two_launch_pair(G):
         got, k1, v1 = _run(G, model, toks, 6)
         t1, f1 = _stat(G, "fused_attn_timeouts"), _stat(G, "fused_attn_tokens")
     finally:
+        G.set_option("test_fused_timeout", 1)  # (the fallback switched the hook off on the slot: on again, so that "off" clears the counter)
         G.set_option("test_fused_timeout", 0)
         G.set_option("fuse_attn", 1)
         G.set_option("attn_one", 1)
         model.free()
+    assert _stat(G, "fused_attn_timeouts") == 0  # switching the hook off clears its give-ups: later tests start from zero
     assert t1 - t0 == 1  # the first decode token ran into the dead hand-off once ...
     assert f1 - f0 == 1  # ... and the slot took the two-launch pair for the tokens after it
     for (ta, la), (tb, lb) in zip(ref, got):
