@@ -767,6 +767,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_fuse_attn != value) drop_all_plans();
         g.opt_fuse_attn = value;
     }
+    else if (k == "speculate_next") {  // 1 = run the greedy next token speculatively behind every single-token plan run (llama_plan.inc)
+        spec_cancel();
+        g.opt_speculate_next = value;
+    }
     else if (k == "fuse_wo") {
         if (g.opt_fuse_wo != value) drop_all_plans();
         g.opt_fuse_wo = value;
@@ -812,6 +816,7 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
         kclass = GGML_HIP_KCLASS_MMVQ;
     }
     if (g_plans.empty() || kclass < 0 || kclass >= GGML_HIP_KCLASS_COUNT || replays < 1) return -1;
+    spec_cancel();  // the replays below run on the plan's buffers
     DecodePlan *p = g_plans.back();
     HIP_CHECK(hipStreamSynchronize(g.stream));
     DecParams saved, park;
