@@ -374,6 +374,32 @@ def run_single(args):
     if fused_timeouts:
         raise SystemExit(f"bench.py: {fused_timeouts} attention workgroup(s) of k_qkv_attn gave up waiting for their rows")
     parity = parity_check(args, hp, w, sess) if not args.no_parity_check else None
+    # roofline leg, taken HERE — at the context length the timed steps ended on, before the other legs move the session on.
+    # Per launch kind: two HIP events on the backend's own stream around `rs` replays of a hipGraph that holds
+    # only that launch of every layer (32 per replay): the average launch PERIOD, kernel-to-kernel boundary included.
+    # rocprofv3's per-kernel duration of the same launches agrees with it (profiles/), so this is the roofline figure;
+    # the same for every mat-vec kind and for all 129 mat-vec launches of a token replayed together.
+    rs = max(args.roofline_steps, 1)
+    kinds = {"qkv": 0, "wo": 1, "gate_up": 2, "down": 3, "lm_head": 4}
+    per_kind = {}
+    if stat("plan_tokens") == h0["plan_tokens"]:  # e.g. GGML_HIP_PLAN_K=0: the node-by-node executor ran, nothing to replay
+        print(json.dumps({"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}", "value": round(tok_s, 2),
+                          "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": DTYPES[args.wtype], "parity_check": parity, "data": "synthetic",
+                          "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode on the "
+                                                 "node-by-node executor (no decode plan matched or the plan option is off)"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+        sess.free()
+        return
+    for name, k in kinds.items():
+        kms, kn, kb = ggml.bench_plan_class(ggml.KKIND_BASE + k, rs)
+        per_kind[name] = {"launches": kn, "bytes_per_launch": int(kb / max(kn, 1)),
+                          "us_per_launch": round(kms * 1e3 / max(kn * rs, 1), 3),
+                          "GBps": round(kb * rs / 1e9 / (kms / 1e3), 1) if kms > 0 else 0.0}
+    ms, launches, algo_bytes = ggml.bench_plan_class(ggml.KCLASS_MMVQ, rs)
+    att_ms, att_n, att_bytes = ggml.bench_plan_class(ggml.KCLASS_ATTN, rs)
+    oth_ms, oth_n, _ = ggml.bench_plan_class(ggml.KCLASS_OTHER, rs)
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
     h1 = {k: stat(k) - v for k, v in h0.items()}
     # the same steps through the reference's OWN call sequence: InferenceSession::compute builds the graph and then calls
@@ -476,32 +502,6 @@ def run_single(args):
                                      "compute_end_wait_and_copy": round(ht[4], 1), "argmax": round(ht[5], 1),
                                      "evaluate_total": round(ht[6], 1)}}
 
-    # roofline leg.  Dominant kernel = the w1|w3 (gate/up) mat-vec, k_mmvq_big<Q4_0, EPI_GATE, XSRC_NORM>: 45 % of the
-    # weight bytes of a layer.  Two HIP events on the backend's own stream around `rs` replays of a hipGraph that holds
-    # only that launch of every layer (32 per replay): the average launch PERIOD, kernel-to-kernel boundary included.
-    # rocprofv3's per-kernel duration of the same launches agrees with it (profiles/), so this is the roofline figure;
-    # the same for every mat-vec kind and for all 129 mat-vec launches of a token replayed together.
-    rs = max(args.roofline_steps, 1)
-    kinds = {"qkv": 0, "wo": 1, "gate_up": 2, "down": 3, "lm_head": 4}
-    per_kind = {}
-    if stat("plan_tokens") == h0["plan_tokens"]:  # e.g. GGML_HIP_PLAN_K=0: the node-by-node executor ran, nothing to replay
-        print(json.dumps({"metric": f"decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}", "value": round(tok_s, 2),
-                          "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": DTYPES[args.wtype], "parity_check": parity, "data": "synthetic",
-                          "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} single-token greedy decode on the "
-                                                 "node-by-node executor (no decode plan matched or the plan option is off)"},
-                          "roofline": None, "cpu_baseline": None}), flush=True)
-        sess.free()
-        return
-    for name, k in kinds.items():
-        kms, kn, kb = ggml.bench_plan_class(ggml.KKIND_BASE + k, rs)
-        per_kind[name] = {"launches": kn, "bytes_per_launch": int(kb / max(kn, 1)),
-                          "us_per_launch": round(kms * 1e3 / max(kn * rs, 1), 3),
-                          "GBps": round(kb * rs / 1e9 / (kms / 1e3), 1) if kms > 0 else 0.0}
-    ms, launches, algo_bytes = ggml.bench_plan_class(ggml.KCLASS_MMVQ, rs)
-    att_ms, att_n, att_bytes = ggml.bench_plan_class(ggml.KCLASS_ATTN, rs)
-    oth_ms, oth_n, _ = ggml.bench_plan_class(ggml.KCLASS_OTHER, rs)
     nl = hp["n_layer"]
     # the DOMINANT kernel = the launch kind with the most device time per token (launches x period), whatever its name
     dom_kind = max(per_kind, key=lambda k: per_kind[k]["launches"] * per_kind[k]["us_per_launch"])

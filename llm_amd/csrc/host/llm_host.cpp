@@ -1274,6 +1274,17 @@ size_t llm_session_read_node(const llm_session *s, int index, const char *name, 
     return n;
 }
 
+// test hook: the HOST bytes of node `n_nodes - 1 - from_end` of the last evaluated graph (what an unchanged caller that reads
+// tensor->data sees; from_end = 1 is the embedding_result node of the LLaMA graph, models/llama/src/lib.rs:343-347)
+size_t llm_session_read_node_host(const llm_session *s, int from_end, void *dst, size_t max_bytes) {
+    ggml_cgraph *g = s->s->last_graph;
+    if (!g || from_end < 0 || from_end >= g->n_nodes) return 0;
+    ggml_tensor *t = g->nodes[g->n_nodes - 1 - from_end];
+    const size_t n = ggml_nbytes(t);
+    if (dst && n <= max_bytes && t->data) memcpy(dst, t->data, n);
+    return n;
+}
+
 // The k best logits of the last evaluated token without reading n_vocab floats back (ggml_hip_topk on the logits node of
 // the last graph = its last node, last row): what the sampler chain's top-k stage needs (samplers.rs:289-306).
 // `extra_ids`: tokens whose raw logits the caller wants too (repetition-penalty window, bias list).  0 on success.

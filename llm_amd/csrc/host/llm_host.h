@@ -103,6 +103,7 @@ GGML_API int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s);
 /* n greedy tokens with the argmax on the device (ggml_hip_decode_greedy_chain): same ids and final logits as n calls
  * of llm_infer_next_token_greedy, no per-token logits read-back; falls back to that loop when chaining is impossible */
 GGML_API int llm_infer_tokens_greedy_device(llm_model *m, llm_session *s, int n, int32_t *out);
+GGML_API size_t llm_session_read_node_host(const llm_session *s, int from_end, void *dst, size_t max_bytes);
 GGML_API int llm_session_rewind(llm_session *s, int num);
 /* host nanoseconds per phase of the decode loop, accumulated: [0] adopt/build graph, [1] token write + plan,
  * [2] compute begin (match + enqueue), [3] speculative build of the next graph, [4] compute end (wait + copy),

@@ -258,7 +258,7 @@ enum { XSRC_Q8 = 0, XSRC_NORM = 1, XSRC_F32 = 2 };
 
 // thread t of the 256 owns elements 4i..4i+3 with i = it*256 + t; a Q8 block = 8 consecutive threads
 template <bool F16_D, bool SC>
-__device__ __forceinline__ void quant4_to_lds_t(const f32x4 v, int64_t i4, int64_t nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
+__device__ __forceinline__ void quant4_to_lds_t(const f32x4 v, int i4, int nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
                                                 float *s_d, int *s_sum) {
     float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     amax = g8_max_f32(amax);
@@ -267,7 +267,7 @@ __device__ __forceinline__ void quant4_to_lds_t(const f32x4 v, int64_t i4, int64
     const int q0 = act_q<SC>(v[0] * id), q1 = act_q<SC>(v[1] * id), q2 = act_q<SC>(v[2] * id), q3 = act_q<SC>(v[3] * id);
     int sq = (q0 + q1) + (q2 + q3);
     sq = g8_sum_i32(sq);
-    const int64_t b = i4 >> 3;  // block index
+    const int b = i4 >> 3;  // block index (32-bit: 64-bit index math costs the staging several VALU ops per element group)
     if (b >= nb) return;
     const int j = tid & 7;
     const int packed = (q0 & 0xFF) | ((q1 & 0xFF) << 8) | ((q2 & 0xFF) << 16) | ((int)((unsigned)q3 << 24));
@@ -279,7 +279,7 @@ __device__ __forceinline__ void quant4_to_lds_t(const f32x4 v, int64_t i4, int64
 }
 // the quantizer branch (common.h: act_quant) is wave-uniform: one scalar branch around two straight-line bodies
 template <bool F16_D>
-__device__ __forceinline__ void quant4_to_lds(const f32x4 v, int64_t i4, int64_t nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
+__device__ __forceinline__ void quant4_to_lds(const f32x4 v, int i4, int nb, int tid, i32x4 *s_lo, i32x4 *s_hi,
                                               float *s_d, int *s_sum) {
     if (aq_scalar())
         quant4_to_lds_t<F16_D, true>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
@@ -302,7 +302,7 @@ __device__ __forceinline__ void stage_x(const QAct &xq, const float *xf, const f
         for (int64_t i4 = tid; i4 < ((n4 + 255) & ~(int64_t)255); i4 += 256) {
             f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
             if (i4 < n4) v = ((const f32x4 *)xf)[i4];
-            quant4_to_lds<F16_D>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+            quant4_to_lds<F16_D>(v, (int)i4, (int)nb, tid, s_lo, s_hi, s_d, s_sum);
         }
     } else {
         __shared__ double s_part[4];
@@ -340,7 +340,7 @@ __device__ __forceinline__ void stage_x(const QAct &xq, const float *xf, const f
                 y[2] = (v[it][2] * scale) * w4[2];
                 y[3] = (v[it][3] * scale) * w4[3];
             }
-            quant4_to_lds<F16_D>(y, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
+            quant4_to_lds<F16_D>(y, (int)i4, (int)nb, tid, s_lo, s_hi, s_d, s_sum);
         }
     }
 }

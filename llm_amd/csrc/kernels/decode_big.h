@@ -93,8 +93,8 @@ struct BigX<XSRC_Q8> {
     i32x4 lo, hi;
     float d;
     int sum;
-    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
-        const int64_t i = tid < nb ? tid : 0;  // nb <= T (checked by the launcher)
+    __device__ __forceinline__ void load(const BigArgs &a, int nb, int tid, int T) {
+        const int i = tid < nb ? tid : 0;  // nb <= T (checked by the launcher)
         lo = a.d.x.lo[i];
         hi = a.d.x.hi[i];
         d = a.d.x.d[i];
@@ -105,11 +105,11 @@ template <>
 struct BigX<XSRC_F32> {
     static constexpr int MAXIT = 6;  // rows up to 24 * T wide (24576 at 1024 threads; checked by the launcher)
     f32x4 v[MAXIT];
-    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
-        const int64_t n4 = nb * 8;
+    __device__ __forceinline__ void load(const BigArgs &a, int nb, int tid, int T) {
+        const int n4 = nb * 8;
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
-            const int64_t i4 = (int64_t)it * T + tid;
+            const int i4 = it * T + tid;
             v[it] = ((const f32x4 *)a.d.xf)[i4 < n4 ? i4 : 0];
         }
     }
@@ -122,12 +122,12 @@ struct BigX<XSRC_NORM> {
     // number of (single-address) loads so that every wave's load queue has the same compile-time shape.
     static constexpr int NT = 512, MAXIT = 4;  // rows up to 8192 wide
     f32x4 v[MAXIT], w[MAXIT];
-    __device__ __forceinline__ void load(const BigArgs &a, int64_t nb, int tid, int T) {
-        const int64_t n4 = nb * 8;
+    __device__ __forceinline__ void load(const BigArgs &a, int nb, int tid, int T) {
+        const int n4 = nb * 8;
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
-            const int64_t i4 = (int64_t)it * NT + tid;
-            const int64_t ic = (tid < NT && i4 < n4) ? i4 : 0;
+            const int i4 = it * NT + tid;
+            const int ic = (tid < NT && i4 < n4) ? i4 : 0;
             v[it] = ((const f32x4 *)a.d.xf)[ic];
             w[it] = ((const f32x4 *)a.d.xw)[ic];
         }
@@ -136,17 +136,17 @@ struct BigX<XSRC_NORM> {
 
 // registers -> LDS as padded planar Q8 (nbp = nbl*64 blocks; blocks >= nb are zero so tail steps contribute 0)
 template <bool F16_D, int XSRC>
-__device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int64_t nb, int64_t nbp, int tid, int T,
+__device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int nb, int nbp, int tid, int T,
                                             i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part) {
     const DecMmvqArgs &d = a.d;
     (void)s_part;
-    for (int64_t i = nb + tid; i < nbp; i += T) {
+    for (int i = nb + tid; i < nbp; i += T) {
         s_lo[i] = i32x4{0, 0, 0, 0};
         s_hi[i] = i32x4{0, 0, 0, 0};
         s_d[i] = 0.0f;
         s_sum[i] = 0;
     }
-    const int64_t n4 = nb * 8;
+    const int n4 = nb * 8;
     if constexpr (XSRC == XSRC_Q8) {
         if (tid < nb) {
             s_lo[tid] = xr.lo;
@@ -157,8 +157,8 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
     } else if constexpr (XSRC == XSRC_F32) {
 #pragma unroll
         for (int it = 0; it < BigX<XSRC_F32>::MAXIT; it++) {
-            const int64_t i4 = (int64_t)it * T + tid;
-            if ((int64_t)it * T >= n4) break;  // uniform
+            const int i4 = it * T + tid;
+            if (it * T >= n4) break;  // uniform
             const f32x4 v = i4 < n4 ? xr.v[it] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             quant4_to_lds<F16_D>(v, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
         }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
             double ss = 0.0;
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
-                const int64_t i4 = (int64_t)it * NT + tid;
+                const int i4 = it * NT + tid;
                 if (i4 < n4) {
                     ss += (double)(xr.v[it][0] * xr.v[it][0]);
                     ss += (double)(xr.v[it][1] * xr.v[it][1]);
@@ -185,12 +185,16 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
             double tot = 0.0;
 #pragma unroll
             for (int i = 0; i < NT / 64; i++) tot += s_part[i];
-            const float mean = (float)(tot / (double)(nb * 32));
+            // tot / n in f64: for a power-of-two row width (4096, 8192) the division is an exact scaling — the same bits as the
+            // division, without its ~15 dependent f64 instructions on eight waves of every workgroup
+            const int n_el = nb * 32;
+            const bool pow2 = (n_el & (n_el - 1)) == 0;  // uniform
+            const float mean = pow2 ? (float)__builtin_ldexp(tot, -(31 - __builtin_clz((unsigned)n_el))) : (float)(tot / (double)n_el);
             const float scale = 1.0f / sqrtf(mean + d.eps);
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
-                const int64_t i4 = (int64_t)it * NT + tid;
-                if ((int64_t)it * NT >= n4) break;  // uniform
+                const int i4 = it * NT + tid;
+                if (it * NT >= n4) break;  // uniform
                 f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (i4 < n4) {
                     y[0] = (xr.v[it][0] * scale) * xr.w[it][0];

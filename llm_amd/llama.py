@@ -57,6 +57,8 @@ def _lib():
         L.llm_session_free.argtypes = [C.c_void_p]
         L.llm_start_session_on.restype = C.c_void_p
         L.llm_start_session_on.argtypes = [C.c_void_p, C.POINTER(_SC), C.c_int]
+        L.llm_session_read_node_host.restype = C.c_size_t
+        L.llm_session_read_node_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.llm_session_seek.argtypes = [C.c_void_p, C.c_int]
         L.llm_session_set_speculate.argtypes = [C.c_void_p, C.c_int]
         L.llm_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -324,6 +326,13 @@ class Session:
             raise KeyError((index, name, occurrence))
         out = np.zeros(n // np.dtype(dtype).itemsize, dtype=dtype)
         _lib().llm_session_read_node(self.ptr, index, nm, occurrence, out.ctypes.data, out.nbytes)
+        return out
+
+    def read_node_host(self, from_end, dtype=np.float32):
+        """Test hook: the HOST bytes of node n_nodes - 1 - from_end of the last evaluated graph (tensor->data)."""
+        n = _lib().llm_session_read_node_host(self.ptr, from_end, None, 0)
+        out = np.zeros(n // np.dtype(dtype).itemsize, dtype=dtype)
+        _lib().llm_session_read_node_host(self.ptr, from_end, out.ctypes.data, out.nbytes)
         return out
 
     def graph_stats(self):

@@ -188,22 +188,22 @@ def test_k_plan_stages_of_a_layer_split_reproduce_the_unsplit_session(G, O):
 
 
 @pytest.mark.parametrize("wtype", [12, 14, 10])
-def test_k_plan_takes_prompt_chunks_of_up_to_8_tokens(G, O, wtype):
-    """InferenceSession::feed_prompt at the reference's default n_batch = 8 (crates/llm-base/src/inference_session.rs:315-316, :837):
-    chunks of 8, 5, 3 and 2 tokens of a K-quant model run on the K plan (columns of the mat-vecs in chunks of 8 / 4 / 2 / 1 exactly
-    as the node-by-node executor takes them), chunks of 9 and more on the executor; logits of every token, the embeddings
-    and the K/V cache against the executor and the oracle."""
+def test_k_plan_takes_prompt_chunks_of_up_to_31_tokens(G, O, wtype):
+    """InferenceSession::feed_prompt at the reference's default n_batch = 8 (crates/llm-base/src/inference_session.rs:315-316, :837)
+    and at the batch sizes its GPU users set: chunks of 8, 5, 3, 2, 11 and 31 tokens of a K-quant model run on the K plan (columns of
+    the mat-vecs in passes of 8 / 4 / 2 / 1 exactly as the node-by-node executor takes them; 32 and more go to the executor and
+    its f16 GEMMs); logits of every token, the embeddings and the K/V cache against the executor and the oracle."""
     from llm_amd import llama
     hp, w = _model(O, GQA_K, wtype, 23)
-    ctx = 64
+    ctx = 96
     model = llama.Llama(hp, w, context_size=ctx)
-    toks = np.random.default_rng([wtype, 9]).integers(0, hp["n_vocab"], 40).astype(np.int32)
-    cuts = [(0, 8), (8, 13), (13, 16), (16, 18), (18, 19), (19, 30), (30, 38)]  # 8, 5, 3, 2, 1, 11 (executor), 8
+    toks = np.random.default_rng([wtype, 9]).integers(0, hp["n_vocab"], 72).astype(np.int32)
+    cuts = [(0, 8), (8, 13), (13, 16), (16, 18), (18, 19), (19, 30), (30, 38), (38, 69)]  # 8, 5, 3, 2, 1, 11, 8, 31
 
     def run(plan_k):
         G.set_option("plan_k", plan_k)
         try:
-            sess = model.start_session(n_batch=16)
+            sess = model.start_session(n_batch=32)
             outs, ran = [], []
             for lo, hi in cuts:
                 k0 = _stat(G, "kplan_tokens")
@@ -217,7 +217,7 @@ def test_k_plan_takes_prompt_chunks_of_up_to_8_tokens(G, O, wtype):
 
     a, ran_a, ka, va = run(1)
     b, ran_b, kb, vb = run(0)
-    assert ran_a == [8, 5, 3, 2, 1, 0, 8] and ran_b == [0] * 7
+    assert ran_a == [8, 5, 3, 2, 1, 11, 8, 31] and ran_b == [0] * 8
     worst = 0.0
     for x, y in zip(a, b):
         assert x.shape == y.shape
@@ -225,9 +225,9 @@ def test_k_plan_takes_prompt_chunks_of_up_to_8_tokens(G, O, wtype):
     print(f"type {wtype}: chunks, K plan vs executor worst |dlogit|/std = {worst:.2e}")
     assert worst <= 8e-2
     Eg = hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])
-    assert np.array_equal(ka[:38 * Eg], kb[:38 * Eg])  # layer 0's K rows: same launches, same bits
+    assert np.array_equal(ka[:69 * Eg], kb[:69 * Eg])  # layer 0's K rows: same launches, same bits
     # the oracle, chunk by chunk on the device's own K/V state
-    sess = model.start_session(n_batch=16)
+    sess = model.start_session(n_batch=32)
     orc = O.Llama(hp, w, ctx)
     worst = 0.0
     for lo, hi in cuts:

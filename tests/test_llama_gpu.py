@@ -536,6 +536,12 @@ def test_decode_plan_embeddings_and_f32_kv_fallback(G, O):
     ref, taps = orc.evaluate(np.array([4], np.int32), mode=O.ref_mode(), taps=True)
     assert np.allclose(emb, taps["final_norm"][-1], rtol=1e-4, atol=1e-5)
     assert np.max(np.abs(logits - ref)) <= EDGE * ref.std()
+    # an UNCHANGED caller reads the node's host pointer (common::extract_embeddings, model/common.rs:41-59): the plan mirrors the
+    # rows of a decode token / prompt chunk there with the logits
+    assert np.array_equal(s.read_node_host(1), emb)
+    s.evaluate(np.array([5, 6, 7], np.int32), want_all_logits=False)  # a chunk of 3 on the multi-token plan
+    host_rows = s.read_node_host(1).reshape(3, -1)
+    assert np.array_equal(host_rows, s.read_node(index=s.graph_stats()[0] - 2).reshape(3, -1))
     s.free()
     s32 = model.start_session(kv_type=G.TYPE_F32)
     s32.feed_prompt(np.array([1, 2, 3], np.int32))

@@ -10,8 +10,8 @@ import sys
 
 # qkv: the fused launch (wq|wk|wv + attention, k_qkv_attn) where it ran, else the plain wq|wk|wv mat-vec; its traffic also holds
 # the attention's K/V read and the granule polling of the attention workgroups
-KINDS = {"qkv": "%k_qkv_attn<0,%", "qkv_unfused": "%k_mmvq_big<0, 3, 1%", "wo": "%k_mmvq_big<0, 1, 0%", "gate_up": "%k_mmvq_big<0, 2, 1%",
-         "down": "%k_mmvq_big<0, 1, 2%", "lm_head": "%k_mmvq_big<0, 0, 1%", "wo_attn_fused": "%k_qkv_attn_wo<0,%"}
+KINDS = {"qkv": "%k_qkv_attn%<0,%", "qkv_unfused": "%k_mmvq_big<0, 3, 1%", "wo": "%k_mmvq_big<0, 1, 0%", "gate_up": "%k_mmvq_big<0, 2, 1%",
+         "down": "%k_mmvq_big<0, 1, 2%", "lm_head": "%k_mmvq_big<0, 0, 1%"}  # qkv: k_qkv_attn or its WO form k_qkv_attn_wo (whichever ran)
 
 
 def avg(d, like, counter):
