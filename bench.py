@@ -357,6 +357,7 @@ def run_single(args):
     stat = lambda k: int(L.ggml_hip_get_stat(k.encode()))
     h0 = {k: stat(k) for k in ("ns_match", "ns_launch", "ns_wait", "ns_compute", "plan_tokens")}
     fused0 = stat("fused_attn_tokens")
+    fused_wo0 = stat("fused_wo_tokens")
     sess.host_timing(reset=True)
     per_step = np.zeros(args.steps)
     t0 = time.perf_counter()
@@ -370,6 +371,7 @@ def run_single(args):
     elapsed = time.perf_counter() - t0
     tok_s = args.steps / elapsed
     fused_tokens = stat("fused_attn_tokens") - fused0
+    fused_wo_tokens = stat("fused_wo_tokens") - fused_wo0
     fused_timeouts = stat("fused_attn_timeouts")
     if fused_timeouts:
         raise SystemExit(f"bench.py: {fused_timeouts} attention workgroup(s) of k_qkv_attn gave up waiting for their rows")
@@ -525,8 +527,11 @@ def run_single(args):
     is_k = args.wtype.endswith("_k")
     W = args.wtype.upper()
     labels = {"gate_up": f"k_mmvq_big<{W}, EPI_GATE, XSRC_NORM> (w1|w3 mat-vec, rms_norm + Q8 staging and silu(w1 x)*(w3 x) epilogue fused)",
-              "qkv": (f"k_qkv_attn<{W}> (wq|wk|wv mat-vec with rms_norm + Q8 staging, RoPE and K/V store on G - n_head workgroups + the "
-                      "attention of the token on n_head workgroups of the same launch; bytes = weights + the K/V the attention reads)")
+              "qkv": ((f"k_qkv_attn_wo<{W}> (wq|wk|wv mat-vec with rms_norm + Q8 staging, RoPE and K/V store on G - n_head workgroups, the "
+                       "attention of the token on n_head workgroups of the same launch, and wo + residual as the mat-vec workgroups' second "
+                       "phase; bytes = wq|wk|wv + wo + the K/V the attention reads)") if fused_wo_tokens else
+                      (f"k_qkv_attn<{W}> (wq|wk|wv mat-vec with rms_norm + Q8 staging, RoPE and K/V store on G - n_head workgroups + the "
+                       "attention of the token on n_head workgroups of the same launch; bytes = weights + the K/V the attention reads)"))
                      if fused_tokens else f"k_mmvq_big<{W}, EPI_QKV, XSRC_NORM> (wq|wk|wv mat-vec, rms_norm + Q8 staging, RoPE and K/V store fused)",
               "down": f"k_mmvq_big<{W}, EPI_ADD, XSRC_F32> (w2 mat-vec, Q8 staging of the gate and residual add fused)",
               "wo": f"k_mmvq_big<{W}, EPI_ADD, XSRC_Q8> (wo mat-vec + residual add)",
@@ -577,9 +582,13 @@ def run_single(args):
                       "decode_launches": {"qkv_and_attention_in_one_launch_tokens": int(fused_tokens), "of_timed_tokens": int(args.steps),
                                           "per_layer": "K plan, 13 launches: norm+Q8_K, wq, wk, wv, rope+K/V store, k_attn_decode, Q8_K, wo+residual, "
                                                        "norm+Q8_K, w1, w3, silu*mul+Q8_K, w2+residual" if is_k else
+                                                       "k_qkv_attn_wo (wq|wk|wv mat-vec on G - n_head workgroups + one attention workgroup per head + wo "
+                                                       "as the mat-vec workgroups' second phase, all hand-offs as epoch-tagged 8-byte granules) -> w1|w3 -> w2"
+                                                       if fused_wo_tokens else
                                                        "k_qkv_attn (wq|wk|wv mat-vec on G - n_head workgroups + one attention workgroup per head "
                                                        "in the same launch, rows handed over as epoch-tagged 8-byte granules) -> wo -> w1|w3 -> w2"
                                                        if fused_tokens else "wq|wk|wv -> k_attn_decode -> wo -> w1|w3 -> w2",
+                                          "wo_in_the_attention_launch_tokens": int(fused_wo_tokens),
                                           "k_plan_tokens": stat("kplan_tokens") if is_k else None,
                                           "note": "roofline.per_kind.qkv is the fused launch when it ran: its bytes include the K/V read of the "
                                                   "attention, its time the hand-off wait and the attention tail"},

@@ -52,6 +52,7 @@
 #include "kernels/mmq_cols.h"
 #include "kernels/decode_attn_split.h"
 #include "kernels/kquant_plan.h"
+#include "kernels/kquant_big.h"
 #include "kernels/prompt.h"
 #include "kernels/prompt_attn.h"
 
@@ -754,6 +755,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
     else if (k == "plan_prompt") {
         if (g.opt_plan_prompt != value) drop_all_plans();
         g.opt_plan_prompt = value;
+    }
+    else if (k == "kbig") {
+        if (g.opt_kbig != value) drop_all_plans();
+        g.opt_kbig = value;
     }
     else if (k == "plan_k") {
         if (g.opt_plan_k != value) drop_all_plans();

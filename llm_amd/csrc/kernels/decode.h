@@ -36,11 +36,22 @@ __global__ void __launch_bounds__(1024) k_argmax_next(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 1024) {  // increasing i: strict > keeps the first maximum of this thread's subsequence
-        const float v = logits[i];
-        if (v > bv || bi == 0x7fffffff) {
-            bv = v;
-            bi = i;
+    // eight independent loads in flight per thread, then the scan in index order (one load per dependent compare made this
+    // kernel a chain of 32 L2 round trips: ~25 us of the device-sampled chain and of the speculative next token, per token)
+    for (int i0 = tid; i0 < V; i0 += 8 * 1024) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * 1024;
+            v8[u] = i < V ? logits[i] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // increasing i: strict > keeps the first maximum of this thread's subsequence
+            const int i = i0 + u * 1024;
+            if (i < V && (v8[u] > bv || bi == 0x7fffffff)) {
+                bv = v8[u];
+                bi = i;
+            }
         }
     }
     auto better = [](float v, int i, float bv_, int bi_) { return v > bv_ || (v == bv_ && i < bi_); };

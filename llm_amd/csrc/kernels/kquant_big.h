@@ -1,0 +1,341 @@
+// kquant_big.h — the K plan's decode mat-vec as ONE wave of big workgroups (Q4_K and Q6_K: what the *_K_M / *_K_S files of
+// crates/llm-base/src/loader.rs:80-93 are made of), with the activation's norm / SiLU·mul and Q8_K quantization done by each
+// workgroup while it stages x — the structure of k_mmvq_big (decode_big.h) for super-blocks of 256.
+//
+// Why: the K plan of round 4 ran the node-by-node executor's k_mmvq_k (four rows per 256-thread workgroup, 2048 workgroups) and
+// needed a helper launch in front of every mat-vec group to produce the Q8_K row: 10 launches per layer, 163 helper launches per
+// token = 0.46 ms of a 2.2 ms token.  Folding the quantization into k_mmvq_k's staging does not pay (2048 workgroups would each
+// re-quantize the row); with 256 workgroups of 1024 threads it does: 6 launches per layer
+//     wq|wk|wv (norm + Q8_K staged) | rope + K/V store | attention | wo (Q8_K staged) + residual | w1|w3 (norm + Q8_K staged) |
+//     w2 (silu·mul + Q8_K staged) + residual
+// Arithmetic: the row dots are k_mmvq_k<KT, 1>'s (same per-lane chunks, same f32 expression per chunk, same step order, same DPP
+// wave reduction), the staging is k_k_norm_quant / k_k_quant / k_k_silu_mul_quant's (kquant_plan.h): the f64 sum of squares in the
+// 256-thread order of k_rms_norm, Q8_K's order-free extreme / rounding / 16-sums.  The plan's results are BIT-IDENTICAL to the
+// helper-launch form (tests/test_kquant_plan_gpu.py runs both).
+#pragma once
+#include "kquant.h"
+#include "decode.h"
+
+enum { KX_Q8K = 0, KX_NORM = 1, KX_F32 = 2, KX_SILU_MUL = 3 };
+
+enum { KE_ROW = 0, KE_GATE = 1, KE_QKV = 2 };
+struct KBigArgs {
+    MmvqKArgs m;       // weights (up to three matrices of ONE type), dst, res; m.x only for KX_Q8K
+    const float *xf;   // KX_NORM / KX_F32: the f32 row;  KX_SILU_MUL: w1 x
+    const float *xw;   // KX_NORM: the norm weight;        KX_SILU_MUL: w3 x
+    float eps;
+    float *y_out;      // KX_NORM, nullable: f32 copy of the normed row (final norm -> OutputRequest.embeddings), written by workgroup 0
+    // KE_QKV: the launch's matrices are some of wq / wk / wv (seg_kind[i] = 0 / 1 / 2 for m.w / m.wb / m.wc); a unit = two adjacent
+    // rows of one matrix; the epilogue is k_k_rope_store's: RoPE of the pair (Q: f32 in place of dst; K: -> f16 -> the cache row of
+    // the token's position), V: f16 into the transposed cache
+    int seg_kind[3];
+    const float *rope;      // the token's (cos, sin) table (k_rope_table)
+    const DecParams *prm;
+    __half *mem_k, *mem_v;  // + layer offset
+    int64_t Egqa, C;
+    int D;
+    int wdeal;  // waves of a workgroup that take rows / units (0 = all 16): chosen per launch so that the units deal evenly (big_waves)
+};
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_i32<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_i32<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_i32<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_i32<DPP_ROW_MIRROR>(v));
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32),
+              r3 = __builtin_amdgcn_readlane(v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
+// one super-block (256 values: lane l holds 4l .. 4l + 3) -> Q8_K in LDS; quantize_row_q8_K's arithmetic (k_quant_q8k): the
+// first value of largest magnitude, iscale = -128 / max, q = min(127, nearest_int(iscale x)), 16-sums, d = 1 / iscale
+__device__ __forceinline__ void q8k_wave_block(const f32x4 v, const int lane, const int sb, int8_t *s_q, float *s_d, int *s_b) {
+    const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
+    const float am = wave_max_f32(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    int idx = a0 == am ? 4 * lane : a1 == am ? 4 * lane + 1 : a2 == am ? 4 * lane + 2 : a3 == am ? 4 * lane + 3 : 256;
+    idx = wave_min_i32(idx);  // wave-uniform
+    const int k = idx & 3;
+    const float cand = k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3];
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), (idx >> 2) & 63));
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    float dd = 0.0f;
+    if (am != 0.0f) {  // uniform
+        const float iscale = -128.0f / mx;
+        q0 = min(127, __float2int_rn(iscale * v[0]));
+        q1 = min(127, __float2int_rn(iscale * v[1]));
+        q2 = min(127, __float2int_rn(iscale * v[2]));
+        q3 = min(127, __float2int_rn(iscale * v[3]));
+        dd = 1.0f / iscale;
+    }
+    ((int *)s_q)[sb * 64 + lane] = (q0 & 0xFF) | ((q1 & 0xFF) << 8) | ((q2 & 0xFF) << 16) | (int)((unsigned)q3 << 24);
+    int s16 = (q0 + q1) + (q2 + q3);
+    s16 += dpp_i32<DPP_QUAD_XOR1>(s16);
+    s16 += dpp_i32<DPP_QUAD_XOR2>(s16);
+    if ((lane & 3) == 0) s_b[sb * 16 + (lane >> 2)] = s16;
+    if (lane == 0) s_d[sb] = dd;
+}
+
+// one step of one row: this lane's 16-byte chunk of super-block sb against the staged Q8_K row — k_mmvq_k<KT, 1>'s expression
+template <int KT>
+__device__ __forceinline__ float kbig_chunk(const KStep<KT> &cur, const int c, const int sb, const int8_t *s_q, const float *s_d,
+                                            const int *s_b) {
+    if constexpr (KT == KT_Q4_K) {
+        const int j = c >> 1, half = c & 1;
+        const uint32_t scw = j < 2 ? cur.sc[0] : cur.sc[1];
+        const int sc_lo = (int)((scw >> ((j & 1) * 16)) & 0xFF), sc_hi = (int)((scw >> ((j & 1) * 16 + 8)) & 0xFF);
+        const uint32_t mw = c < 4 ? cur.sc[2] : cur.sc[3];
+        const int mc = (int)((mw >> ((c & 3) * 8)) & 0xFF);
+        const float d = __half2float(__ushort_as_half((unsigned short)(cur.dm & 0xFFFF)));
+        const float dmin = __half2float(__ushort_as_half((unsigned short)(cur.dm >> 16)));
+        const u32x4 lo = cur.q & 0x0F0F0F0Fu, hi = (cur.q >> 4) & 0x0F0F0F0Fu;
+        const int8_t *xq = s_q + sb * 256 + 64 * j + 16 * half;
+        const i32x4 xl = *(const i32x4 *)xq, xh = *(const i32x4 *)(xq + 32);
+        const int isum = sc_lo * dot16(lo, xl, 0) + sc_hi * dot16(hi, xh, 0);
+        const int *bp = s_b + sb * 16 + 2 * c;
+        const int msum = mc * (bp[0] + bp[1]);
+        const float d8 = s_d[sb];
+        return (d * d8) * (float)isum - (dmin * d8) * (float)msum;
+    } else {
+        const int n2 = c >> 2, o = 16 * (c & 3);
+        const uint32_t wa = n2 ? cur.sc[2] : cur.sc[0], wb = n2 ? cur.sc[3] : cur.sc[1];
+        const int sc_a = (int)(int8_t)((wa >> (8 * (c & 3))) & 0xFF), sc_b = (int)(int8_t)((wb >> (8 * (c & 3))) & 0xFF);
+        const float d = __half2float(__ushort_as_half((unsigned short)cur.dm));
+        u32x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lo[k] = (cur.q[k] & 0x0F0F0F0Fu) | (((cur.hA >> (2 * k)) & 0x03030303u) << 4);
+            hi[k] = ((cur.q[k] >> 4) & 0x0F0F0F0Fu) | (((cur.hB >> (2 * k)) & 0x03030303u) << 4);
+        }
+        const int8_t *xq = s_q + sb * 256 + 128 * n2 + o;
+        const i32x4 xl = *(const i32x4 *)xq, xh = *(const i32x4 *)(xq + 64);
+        const int *bp = s_b + sb * 16 + 8 * n2 + (c & 3);
+        const int isum = sc_a * (dot16(lo, xl, 0) - 32 * bp[0]) + sc_b * (dot16(hi, xh, 0) - 32 * bp[4]);
+        return (d * s_d[sb]) * (float)isum;
+    }
+}
+
+#define KBIG_T 1024
+#define KBIG_PF 4  // steps (8 super-blocks of one row) a wave keeps requested ahead
+
+// EPI = KE_GATE: the launch computes silu(w1 x) * (w3 x) (a.w = w1, a.wb = w3, same shape and type; dst = the product row): a wave's
+// unit = row m of w1 followed by row m of w3, the epilogue lane of the unit applies ggml's f16-table SiLU and the multiply — the
+// operations of k_k_silu_mul_quant's first half, once per element instead of once per workgroup and element in w2's staging.
+// EPI = KE_QKV: unit = rows 2u, 2u + 1 of the launch's concatenated matrices (each with an even row count), epilogue = k_k_rope_store.
+template <int KT, int XSRC, int EPI = KE_ROW>
+__global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
+    const MmvqKArgs &a = ka.m;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_part[4];
+    const int nsb = (int)a.w.nsb, K = nsb * 256;
+    int8_t *s_q = (int8_t *)smem;                          // [K]
+    float *s_d = (float *)(smem + (size_t)K);              // [nsb]
+    int *s_b = (int *)(s_d + ((nsb + 3) & ~3));            // [nsb * 16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    constexpr int W = KBIG_T / 64;
+    const int c = lane & 7, sbl = lane >> 3;
+    const int nsteps = (nsb + 7) >> 3;
+    constexpr bool GATE = EPI == KE_GATE, PAIR = EPI != KE_ROW;
+    const int Mt = GATE ? (int)a.w.M : EPI == KE_QKV ? (int)(mmvq_k_rows(a) >> 1) : (int)mmvq_k_rows(a);
+    // rows (GATE: units) of this wave: dealt wave-major like k_mmvq_big: row = wave * G + bid + G * W * i
+    const int Wd = ka.wdeal > 0 ? ka.wdeal : W;
+    const int r_first = wave * G + bid, r_stride = G * Wd;
+    const int nrw = (wave < Wd && r_first < Mt) ? (Mt - r_first + r_stride - 1) / r_stride : 0;
+    const int nhr = PAIR ? 2 * nrw : nrw;  // weight rows the wave walks (GATE: w1's and w3's row of every unit; QKV: the pair's two rows)
+    const int S = nhr * nsteps;            // steps of this wave
+
+    // The load cursor walks (row of the wave, step of the row); the row's plane bases are wave-uniform and change only at a row
+    // switch (scalar registers): a step costs a clamp and four small offsets instead of a division, a matrix select and 64-bit
+    // index arithmetic — with 16 waves per CU sharing the VALU with the dots that was a third of the launch.
+    int li = 0, ls = 0;
+    const uint8_t *l_qs = a.w.qs, *l_sc = a.w.sc;
+    const uint32_t *l_aux = a.w.aux;
+    const __half *l_d = a.w.d;
+    auto set_row = [&](int i) {
+        KWeight w;
+        int64_t row, ldd_;
+        float *dst_;
+        if constexpr (GATE) {
+            w = (i & 1) ? a.wb : a.w;
+            row = (int64_t)(r_first + r_stride * (i >> 1));
+        } else if constexpr (EPI == KE_QKV) {
+            mmvq_k_select(a, (int64_t)(2 * (r_first + r_stride * (i >> 1)) + (i & 1)), w, row, dst_, ldd_);
+        } else {
+            mmvq_k_select(a, (int64_t)(r_first + r_stride * i), w, row, dst_, ldd_);
+        }
+        const int64_t g0 = row * nsb;
+        l_qs = w.qs + g0 * 128;
+        l_sc = w.sc + g0 * 16;
+        l_aux = w.aux + g0 * 16;
+        l_d = w.d + g0 * (KT == KT_Q4_K ? 2 : 1);
+    };
+    auto load = [&](KStep<KT> &st) {
+        int sb = ls * 8 + sbl;
+        sb = sb < nsb ? sb : nsb - 1;  // lanes past the row end re-read the last super-block and are masked below
+        st.q = __builtin_nontemporal_load((const u32x4 *)(l_qs + sb * 128 + c * 16));
+        st.sc = *(const u32x4 *)(l_sc + sb * 16);
+        if constexpr (KT == KT_Q4_K) {
+            st.dm = *(const uint32_t *)(l_d + sb * 2);
+        } else {
+            const u32x2 h = __builtin_nontemporal_load((const u32x2 *)(l_aux + (sb * 8 + c) * 2));
+            st.hA = h[0];
+            st.hB = h[1];
+            st.dm = (uint32_t) * (const uint16_t *)(l_d + sb);
+        }
+        if (++ls == nsteps) {
+            ls = 0;
+            if (++li < nhr) set_row(li);
+        }
+    };
+    // ---- 1. the activation's loads go FIRST (a wave's loads return in order: issued behind the weight ring they would only
+    //         become usable once the whole ring has landed — the lesson of k_mmvq_big): this wave's
+    //         super-blocks w, w + 16, ... (at most KBIG_SBW of them), and for the norm the 256-thread strided sum's elements
+    constexpr int KBIG_SBW = 4;   // super-blocks a wave stages: nsb <= 64 (rows up to 16384 wide)
+    constexpr int KBIG_SQ = 32;   // elements per thread of the 256-thread sum of squares: rows up to 8192 wide (launcher)
+    f32x4 xv[KBIG_SBW], xw4[XSRC == KX_NORM || XSRC == KX_SILU_MUL ? KBIG_SBW : 1];
+    float sq[XSRC == KX_NORM ? KBIG_SQ : 1];
+    if constexpr (XSRC != KX_Q8K) {
+#pragma unroll
+        for (int u = 0; u < KBIG_SBW; u++) {
+            const int sb = wave + W * u;
+            const int i4 = (sb < nsb ? sb : 0) * 64 + lane;
+            xv[u] = ((const f32x4 *)ka.xf)[i4];
+            if constexpr (XSRC == KX_NORM || XSRC == KX_SILU_MUL) xw4[u] = ((const f32x4 *)ka.xw)[i4];
+        }
+        if constexpr (XSRC == KX_NORM) {
+#pragma unroll
+            for (int u = 0; u < KBIG_SQ; u++) {
+                const int i = (tid & 255) + 256 * u;
+                sq[u] = ka.xf[i < K ? i : 0];
+            }
+        }
+    }
+    // ---- 2. the weight stream starts before the activation is staged
+    KStep<KT> ring[KBIG_PF];
+    if (nhr > 0) set_row(0);
+#pragma unroll
+    for (int k = 0; k < KBIG_PF; k++)
+        if (k < S) load(ring[k]);
+
+    // ---- 3. stage x as Q8_K: wave w takes super-blocks w, w + 16, ...; lane l the values 4l .. 4l + 3 of the super-block
+    if constexpr (XSRC == KX_Q8K) {
+        for (int i = tid; i < K / 16; i += KBIG_T) ((i32x4 *)s_q)[i] = ((const i32x4 *)a.x.q8)[i];
+        for (int i = tid; i < nsb; i += KBIG_T) s_d[i] = a.x.d8[i];
+        for (int i = tid; i < nsb * 16; i += KBIG_T) s_b[i] = (int)a.x.bs[i];
+    } else {
+        float scale = 1.0f;
+        if constexpr (XSRC == KX_NORM) {
+            // k_rms_norm's / k_k_norm_quant's order: thread t of 256 adds elements t, t + 256, ... in f64, waves by DPP, (s0 + s1) + (s2 + s3)
+            if (tid < 256) {
+                double s = 0.0;
+#pragma unroll
+                for (int u = 0; u < KBIG_SQ; u++)
+                    if (tid + 256 * u < K) s += (double)(sq[u] * sq[u]);
+                s = wave_sum_f64(s);
+                if (lane == 0) s_part[wave] = s;
+            }
+            __syncthreads();
+            const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+            const float mean = (float)(tot / (double)K);
+            scale = 1.0f / sqrtf(mean + ka.eps);
+        }
+#pragma unroll
+        for (int u = 0; u < KBIG_SBW; u++) {
+            const int sb = wave + W * u;
+            if (sb >= nsb) break;  // uniform
+            const int i4 = sb * 64 + lane;
+            f32x4 v = xv[u];
+            if constexpr (XSRC == KX_NORM) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float t = v[k] * scale;
+                    v[k] = t * xw4[u][k];
+                }
+                if (ka.y_out && bid == 0) ((f32x4 *)ka.y_out)[i4] = v;
+            } else if constexpr (XSRC == KX_SILU_MUL) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float t = silu_table(v[k]);
+                    v[k] = t * xw4[u][k];
+                }
+            }
+            q8k_wave_block(v, lane, sb, s_q, s_d, s_b);
+        }
+    }
+    __syncthreads();
+
+    // ---- rows
+    float acc = 0.0f, myv = 0.0f, myv3 = 0.0f;
+    int ri = 0, rs = 0;  // row index of the wave, step inside the row
+    for (int k0 = 0; k0 < S; k0 += KBIG_PF) {
+#pragma unroll
+        for (int u = 0; u < KBIG_PF; u++) {
+            const int k = k0 + u;
+            if (k < S) {  // uniform
+                const int sb = rs * 8 + sbl;
+                if (sb < nsb) acc += kbig_chunk<KT>(ring[u], c, sb, s_q, s_d, s_b);
+                if (++rs == nsteps) {
+                    rs = 0;
+                    const float v = wave_sum_f32(acc);
+                    if constexpr (PAIR) {
+                        if (ri & 1)
+                            myv3 = lane == (ri >> 1) ? v : myv3;
+                        else
+                            myv = lane == (ri >> 1) ? v : myv;
+                    } else {
+                        myv = lane == ri ? v : myv;
+                    }
+                    acc = 0.0f;
+                    ri++;
+                }
+                if (k + KBIG_PF < S) load(ring[u]);
+            }
+        }
+    }
+    if constexpr (GATE) {
+        if (lane < nrw) a.dst[r_first + r_stride * lane] = silu_table(myv) * myv3;
+        return;
+    }
+    if constexpr (EPI == KE_QKV) {
+        if (lane < nrw) {
+            const int64_t grow = (int64_t)2 * (r_first + r_stride * lane);
+            int seg = 0;
+            int64_t m0 = grow;
+            if (a.nseg > 1 && grow >= a.w.M) {
+                seg = 1;
+                m0 = grow - a.w.M;
+                if (a.nseg > 2 && m0 >= a.wb.M) {
+                    seg = 2;
+                    m0 -= a.wb.M;
+                }
+            }
+            const int kind = ka.seg_kind[seg];
+            const int p = ka.prm->n_past;
+            if (kind == 2) {  // V: f16 into the transposed cache
+                ka.mem_v[m0 * ka.C + p] = __float2half_rn(myv);
+                ka.mem_v[(m0 + 1) * ka.C + p] = __float2half_rn(myv3);
+            } else {
+                const int kk = (int)(m0 % ka.D) >> 1;
+                const float cs = ka.rope[2 * kk], sn = ka.rope[2 * kk + 1];
+                const float r0 = myv * cs - myv3 * sn, r1 = myv * sn + myv3 * cs;
+                if (kind == 0) {
+                    float *q = seg == 0 ? a.dst : seg == 1 ? a.dst_b : a.dst_c;
+                    q[m0] = r0;
+                    q[m0 + 1] = r1;
+                } else {
+                    ka.mem_k[(int64_t)p * ka.Egqa + m0] = __float2half_rn(r0);
+                    ka.mem_k[(int64_t)p * ka.Egqa + m0 + 1] = __float2half_rn(r1);
+                }
+            }
+        }
+        return;
+    }
+    if (lane < nrw) {
+        KWeight w_;
+        int64_t lrow, ldd_;
+        float *dst_;
+        mmvq_k_select(a, (int64_t)(r_first + r_stride * lane), w_, lrow, dst_, ldd_);
+        dst_[lrow] = a.res ? myv + a.res[lrow] : myv;
+    }
+}

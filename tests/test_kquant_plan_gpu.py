@@ -126,6 +126,44 @@ def test_k_plan_on_a_mixed_type_model(G, O):
     model.free()
 
 
+@pytest.mark.parametrize("case", ["q4_k", "q6_k", "k_m mix", "gqa q4_k"])
+def test_big_workgroup_k_mat_vecs_equal_the_helper_launch_form(G, O, case):
+    """The K plan's decode mat-vecs as one wave of 1024-thread workgroups that stage the activation themselves (k_mmvq_kbig,
+    kernels/kquant_big.h: norm / silu·mul + Q8_K inside the mat-vec's staging, 6 launches per layer) against option kbig = 0
+    (k_mmvq_k behind helper launches, 10 per layer): the row dots and the quantizer are the same expressions in the same order,
+    so logits, K/V and greedy ids are BIT-IDENTICAL; whole model and a stage of a layer split."""
+    from llm_amd import llama
+    wt = {"q4_k": 12, "q6_k": 14, "k_m mix": 12, "gqa q4_k": 12}[case]
+    hp0 = GQA_K if case == "gqa q4_k" else TINY_K
+    wtypes = None
+    if case == "k_m mix":
+        wtypes = {"output.weight": 14}
+        for il in range(hp0["n_layer"]):
+            wtypes[f"layers.{il}.attention.wv.weight"] = 14
+            wtypes[f"layers.{il}.feed_forward.w2.weight"] = 14
+    hp, w = _model(O, hp0, wt, 31, wtypes)
+    model = llama.Llama(hp, w, context_size=96)
+    toks = np.random.default_rng(12).integers(0, hp["n_vocab"], 30).astype(np.int32)
+    res = {}
+    try:
+        for kbig in (1, 0):
+            G.set_option("kbig", kbig)
+            outs, k, v, ran = _decode(G, model, toks, 11, 1)
+            sess = model.start_session(n_batch=8)
+            sess.feed_prompt(toks[:9])
+            ids = [sess.infer_next_token() for _ in range(12)]
+            sess.free()
+            res[kbig] = (outs, k, v, ran, ids)
+    finally:
+        G.set_option("kbig", 1)
+        model.free()
+    assert res[1][3] == 19 and res[0][3] == 19  # both forms are the K plan
+    for a, b in zip(res[1][0], res[0][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[1][1], res[0][1]) and np.array_equal(res[1][2], res[0][2])
+    assert res[1][4] == res[0][4]
+
+
 def test_k_plan_greedy_tokens_equal_the_executor(G, O):
     """infer_next_token (greedy) over 24 tokens: the K plan and the executor pick the same ids."""
     from llm_amd import llama
