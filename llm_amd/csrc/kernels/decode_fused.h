@@ -44,6 +44,9 @@ struct FusedAttnArgs {
     // WO form (k_qkv_attn<.., WO = true>): the heads' re-quantized outputs are PUBLISHED to the mat-vec workgroups of the same
     // launch instead of stored for a following wo launch: this layer's E/32 x OGRAN granules (publish_head_q8 below)
     unsigned long long *ogran;
+    // K plan (k_qkv_attn_k, kernels/kquant_big.h): the merged heads as f32 [n_head * D] instead of Q8_0 blocks (wo stages its own
+    // Q8_K row from them); nullptr = the Q8_0 forms above
+    float *out_f32;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -420,7 +423,12 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
     const long long t_vp = f.ts ? (long long)wall_clock64() : 0;
     // ---- the head's D outputs as Q8 blocks for wo ----
     const int nblk = D / 32, l = tid & 31, b = tid >> 5;
-    if (b < nblk) publish_head_q8<F16_D>(f, h, s_o[b * 32 + l], nblk, l, b, epoch);
+    if (b < nblk) {
+        if (f.out_f32)
+            f.out_f32[(int64_t)h * D + b * 32 + l] = s_o[b * 32 + l];
+        else
+            publish_head_q8<F16_D>(f, h, s_o[b * 32 + l], nblk, l, b, epoch);
+    }
     if (f.ts && tid == 0) {
         const int q4 = f.n_head / 4;
         if (q4 > 0 && h % q4 == 0 && h / q4 < 4) {

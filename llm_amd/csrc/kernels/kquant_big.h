@@ -15,6 +15,7 @@
 #pragma once
 #include "kquant.h"
 #include "decode.h"
+#include "decode_fused.h"  // attn_consumer: the attention workgroups of k_qkv_attn_k
 
 enum { KX_Q8K = 0, KX_NORM = 1, KX_F32 = 2, KX_SILU_MUL = 3 };
 
@@ -35,6 +36,10 @@ struct KBigArgs {
     int64_t Egqa, C;
     int D;
     int wdeal;  // waves of a workgroup that take rows / units (0 = all 16): chosen per launch so that the units deal evenly (big_waves)
+    // KE_QKV inside k_qkv_attn_k (below): every finished row pair is also PUBLISHED to the attention workgroups of the same launch as
+    // one {epoch, f16 x 2} granule (index = the pair's index over wq|wk|wv), exactly as k_mmvq_big does inside k_qkv_attn
+    unsigned long long *gran;
+    const unsigned *epoch;
 };
 
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -121,8 +126,8 @@ __device__ __forceinline__ float kbig_chunk(const KStep<KT> &cur, const int c, c
 // unit = row m of w1 followed by row m of w3, the epilogue lane of the unit applies ggml's f16-table SiLU and the multiply — the
 // operations of k_k_silu_mul_quant's first half, once per element instead of once per workgroup and element in w2's staging.
 // EPI = KE_QKV: unit = rows 2u, 2u + 1 of the launch's concatenated matrices (each with an even row count), epilogue = k_k_rope_store.
-template <int KT, int XSRC, int EPI = KE_ROW>
-__global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
+template <int KT, int XSRC, int EPI>
+__device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, const int G) {
     const MmvqKArgs &a = ka.m;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_part[4];
@@ -132,7 +137,6 @@ __global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
     int *s_b = (int *)(s_d + ((nsb + 3) & ~3));            // [nsb * 16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
     constexpr int W = KBIG_T / 64;
     const int c = lane & 7, sbl = lane >> 3;
     const int nsteps = (nsb + 7) >> 3;
@@ -191,8 +195,9 @@ __global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
     // ---- 1. the activation's loads go FIRST (a wave's loads return in order: issued behind the weight ring they would only
     //         become usable once the whole ring has landed — the lesson of k_mmvq_big): this wave's
     //         super-blocks w, w + 16, ... (at most KBIG_SBW of them), and for the norm the 256-thread strided sum's elements
-    constexpr int KBIG_SBW = 4;   // super-blocks a wave stages: nsb <= 64 (rows up to 16384 wide)
-    constexpr int KBIG_SQ = 32;   // elements per thread of the 256-thread sum of squares: rows up to 8192 wide (launcher)
+    constexpr int KBIG_SBW = XSRC == KX_NORM ? 2 : 4;  // super-blocks a wave stages: the normed rows are E wide (<= 8192: nsb <= 32),
+                                                       // the others up to 16384 (nsb <= 64) (launcher)
+    constexpr int KBIG_SQ = 16;   // elements per thread and pass of the 256-thread sum of squares (two passes for rows beyond 4096)
     f32x4 xv[KBIG_SBW], xw4[XSRC == KX_NORM || XSRC == KX_SILU_MUL ? KBIG_SBW : 1];
     float sq[XSRC == KX_NORM ? KBIG_SQ : 1];
     if constexpr (XSRC != KX_Q8K) {
@@ -232,6 +237,16 @@ __global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
 #pragma unroll
                 for (int u = 0; u < KBIG_SQ; u++)
                     if (tid + 256 * u < K) s += (double)(sq[u] * sq[u]);
+                if (K > 256 * KBIG_SQ) {  // rows beyond 4096: the rest of the thread's elements, still in ascending order
+#pragma unroll
+                    for (int u = 0; u < KBIG_SQ; u++) {
+                        const int i = tid + 256 * (KBIG_SQ + u);
+                        sq[u] = ka.xf[i < K ? i : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < KBIG_SQ; u++)
+                        if (tid + 256 * (KBIG_SQ + u) < K) s += (double)(sq[u] * sq[u]);
+                }
                 s = wave_sum_f64(s);
                 if (lane == 0) s_part[wave] = s;
             }
@@ -310,23 +325,32 @@ __global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
                     m0 -= a.wb.M;
                 }
             }
-            const int kind = ka.seg_kind[seg];
+            const int kind = seg == 0 ? ka.seg_kind[0] : seg == 1 ? ka.seg_kind[1] : ka.seg_kind[2];  // (a run-time index would put the argument block in scratch)
             const int p = ka.prm->n_past;
+            __half h0, h1;  // the pair as f16: what the cache holds, and what ggml's F16 mat-mul makes of Q
             if (kind == 2) {  // V: f16 into the transposed cache
-                ka.mem_v[m0 * ka.C + p] = __float2half_rn(myv);
-                ka.mem_v[(m0 + 1) * ka.C + p] = __float2half_rn(myv3);
+                h0 = __float2half_rn(myv);
+                h1 = __float2half_rn(myv3);
+                ka.mem_v[m0 * ka.C + p] = h0;
+                ka.mem_v[(m0 + 1) * ka.C + p] = h1;
             } else {
                 const int kk = (int)(m0 % ka.D) >> 1;
                 const float cs = ka.rope[2 * kk], sn = ka.rope[2 * kk + 1];
                 const float r0 = myv * cs - myv3 * sn, r1 = myv * sn + myv3 * cs;
+                h0 = __float2half_rn(r0);
+                h1 = __float2half_rn(r1);
                 if (kind == 0) {
                     float *q = seg == 0 ? a.dst : seg == 1 ? a.dst_b : a.dst_c;
                     q[m0] = r0;
                     q[m0 + 1] = r1;
                 } else {
-                    ka.mem_k[(int64_t)p * ka.Egqa + m0] = __float2half_rn(r0);
-                    ka.mem_k[(int64_t)p * ka.Egqa + m0 + 1] = __float2half_rn(r1);
+                    ka.mem_k[(int64_t)p * ka.Egqa + m0] = h0;
+                    ka.mem_k[(int64_t)p * ka.Egqa + m0 + 1] = h1;
                 }
+            }
+            if (ka.gran) {  // one aligned 8-byte agent-scope store: the data is the flag (kernels/common.h gran_store)
+                const unsigned v2 = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
+                gran_store(ka.gran + (r_first + r_stride * lane), *ka.epoch, v2);
             }
         }
         return;
@@ -338,4 +362,23 @@ __global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
         mmvq_k_select(a, (int64_t)(r_first + r_stride * lane), w_, lrow, dst_, ldd_);
         dst_[lrow] = a.res ? myv + a.res[lrow] : myv;
     }
+}
+template <int KT, int XSRC, int EPI = KE_ROW>
+__global__ void __launch_bounds__(KBIG_T) k_mmvq_kbig(const KBigArgs ka) {
+    kbig_body<KT, XSRC, EPI>(ka, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// wq|wk|wv of a K-quant model and the attention of the token in ONE launch: k_qkv_attn's structure (kernels/decode_fused.h) with
+// the K mat-vec as the producer — workgroups 0 .. n_head - 1 are the attention (attn_consumer: K / V of the context preloaded while
+// the weights stream, the token's own Q / K / V rows received as epoch-tagged granules, output as f32 for wo's staging), the
+// others run kbig_body<KE_QKV> and publish every finished row pair.  Same arithmetic as k_attn_decode: bit-identical to the
+// two-launch form.  One attention workgroup per head (contexts below the split threshold); all three matrices of one type.
+template <int KT>
+__global__ void __launch_bounds__(KBIG_T) k_qkv_attn_k(const KBigArgs ka, const FusedAttnArgs fa) {
+    const int H = fa.n_head;
+    if ((int)blockIdx.x < H) {
+        attn_consumer<true>(fa, (int)blockIdx.x);
+        return;
+    }
+    kbig_body<KT, KX_NORM, KE_QKV>(ka, (int)blockIdx.x - H, (int)gridDim.x - H);
 }
