@@ -536,7 +536,8 @@ def run_single(args):
               "down": f"k_mmvq_big<{W}, EPI_ADD, XSRC_F32> (w2 mat-vec, Q8 staging of the gate and residual add fused)",
               "wo": f"k_mmvq_big<{W}, EPI_ADD, XSRC_Q8> (wo mat-vec + residual add)",
               "lm_head": f"k_mmvq_big<{W}, EPI_STORE, XSRC_NORM> (final norm + lm_head)"}
-    kernel_label = (f"k_mmvq_k / k_mmvq_k2<{W}, 1 column> (K plan, launch kind '{dom_kind}': Q8_K activations staged in LDS)") if is_k else labels[dom_kind]
+    kernel_label = (f"k_mmvq_kbig / k_qkv_attn_k<{W}> (K plan on big workgroups, launch kind '{dom_kind}': the activation is normed / "
+                    "quantized to Q8_K in the launch's own staging)") if is_k else labels[dom_kind]
     kernel_label += f"; {dom['launches']} launches per token = {dom['us_per_token']} us, the largest share of the token's device time"
     roofline = {"bound": "hbm", "kernel": kernel_label, "kernel_kind": dom_kind,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -580,8 +581,9 @@ def run_single(args):
                                         "reference_call_sequence": reference_sequence},
                       "weights_in_hbm_before_timing": True, "host_split_per_token": host_split,
                       "decode_launches": {"qkv_and_attention_in_one_launch_tokens": int(fused_tokens), "of_timed_tokens": int(args.steps),
-                                          "per_layer": "K plan, 13 launches: norm+Q8_K, wq, wk, wv, rope+K/V store, k_attn_decode, Q8_K, wo+residual, "
-                                                       "norm+Q8_K, w1, w3, silu*mul+Q8_K, w2+residual" if is_k else
+                                          "per_layer": "K plan on big workgroups, 4 launches: k_qkv_attn_k (norm + Q8_K staged, wq|wk|wv, RoPE + K/V store, the attention "
+                                                       "on n_head workgroups of the same launch) -> wo (Q8_K staged) + residual -> w1|w3 (norm + Q8_K staged, "
+                                                       "silu*mul epilogue) -> w2 (Q8_K staged) + residual; beyond the split threshold wq|wk|wv -> k_attn_split_one" if is_k else
                                                        "k_qkv_attn_wo (wq|wk|wv mat-vec on G - n_head workgroups + one attention workgroup per head + wo "
                                                        "as the mat-vec workgroups' second phase, all hand-offs as epoch-tagged 8-byte granules) -> w1|w3 -> w2"
                                                        if fused_wo_tokens else
@@ -622,6 +624,9 @@ DTYPES = {  # the arithmetic the decode path computes in: ggml's block dot of th
     "q8_0": "i8*i8->i32 block dots, f32 accumulate (ggml's Q8_0·Q8_0)",
     "q4_k": "i8*u4->i32 sub-block dots with 6-bit scales, f32 accumulate (ggml's Q4_K·Q8_K)",
     "q6_k": "i8*i6->i32 sub-block dots with 8-bit scales, f32 accumulate (ggml's Q6_K·Q8_K)",
+    "q5_k": "i8*u5->i32 sub-block dots with 6-bit scales and mins, f32 accumulate (ggml's Q5_K·Q8_K)",
+    "q3_k": "i8*i3->i32 sub-block dots with 6-bit scales, f32 accumulate (ggml's Q3_K·Q8_K)",
+    "q2_k": "i8*u2->i32 sub-block dots with 4-bit scales and mins, f32 accumulate (ggml's Q2_K·Q8_K)",
 }
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X dense f16 MFMA peak, MI355X_MICROARCH.md "BF16/F16 ~2.5 PF dense"
 

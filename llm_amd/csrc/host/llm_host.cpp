@@ -1330,6 +1330,23 @@ void llm_synth_blocks(int type, void *dst, int64_t nblocks, uint64_t seed, float
                 memcpy(p + 208, &d6, 2);
                 continue;
             }
+            if (type == GGML_TYPE_Q5_K) {  // block_q5_K: d dmin scales[12] qh[32] qs[128] — x = d*sc*q - dmin*m, q five-bit, sc, m six-bit
+                const ggml_fp16_t d5 = ggml_fp32_to_fp16(d * (1.0f / 64.0f)), m5 = ggml_fp32_to_fp16(d * (15.5f / 64.0f));
+                memcpy(p, &d5, 2);
+                memcpy(p + 2, &m5, 2);
+                continue;
+            }
+            if (type == GGML_TYPE_Q3_K) {  // block_q3_K: hmask[32] qs[64] scales[12] d — x = d*(sc-32)*(q-4), sc six-bit, q three-bit
+                const ggml_fp16_t d3 = ggml_fp32_to_fp16(d * (1.0f / 16.0f));
+                memcpy(p + 108, &d3, 2);
+                continue;
+            }
+            if (type == GGML_TYPE_Q2_K) {  // block_q2_K: scales[16] qs[64] d dmin — x = d*sc*q - dmin*m, sc, m four-bit, q two-bit
+                const ggml_fp16_t d2 = ggml_fp32_to_fp16(d * (1.0f / 4.0f)), m2 = ggml_fp32_to_fp16(d * (1.5f / 4.0f));
+                memcpy(p + 80, &d2, 2);
+                memcpy(p + 82, &m2, 2);
+                continue;
+            }
             if (type == GGML_TYPE_Q4_K) {  // block_q4_K: d dmin scales[12] qs[128] — x = d*sc*q - dmin*m, sc, m six-bit
                 const ggml_fp16_t d4 = ggml_fp32_to_fp16(d * (1.0f / 32.0f)), m4 = ggml_fp32_to_fp16(d * (7.5f / 32.0f));
                 memcpy(p, &d4, 2);

@@ -14,6 +14,7 @@
 // helper-launch form (tests/test_kquant_plan_gpu.py runs both).
 #pragma once
 #include "kquant.h"
+#include "kquant2.h"
 #include "decode.h"
 #include "decode_fused.h"  // attn_consumer: the attention workgroups of k_qkv_attn_k
 
@@ -119,6 +120,77 @@ __device__ __forceinline__ float kbig_chunk(const KStep<KT> &cur, const int c, c
     }
 }
 
+// ---- the 16-lanes-per-super-block family (Q2_K, Q3_K, Q5_K: kquant2.h): a lane's RAW loads of one 16-element group (what
+// k2_load reads, kept in the ring) and their decoding + dot at consume time — k2_load's and k_mmvq_k2<KT, 1>'s expressions
+template <int KT>
+struct K2Raw {
+    u32x4 q, a;    // quant bytes; Q3_K: hmask half, Q5_K: qh half
+    uint32_t sm;   // Q2_K / Q3_K: the group's scale byte; Q5_K: scale | min << 8
+    uint32_t dm;   // d | dmin << 16 (f16 pair)
+};
+template <int KT>
+__device__ __forceinline__ void k2_issue(K2Raw<KT> &r, const uint8_t *qs, const uint8_t *aux, const uint8_t *sc, const __half *d,
+                                         const int sb, const int g) {
+    if constexpr (KT == KT_Q2_K || KT == KT_Q3_K) {
+        r.q = *(const u32x4 *)(qs + sb * 64 + (2 * (g >> 3) + (g & 1)) * 16);
+        if constexpr (KT == KT_Q3_K) r.a = *(const u32x4 *)(aux + sb * 32 + (g & 1) * 16);
+        r.sm = sc[sb * 16 + g];
+    } else {
+        const int j64 = g >> 2, half = g & 1;
+        r.q = *(const u32x4 *)(qs + sb * 128 + j64 * 32 + half * 16);
+        r.a = *(const u32x4 *)(aux + sb * 32 + half * 16);
+        r.sm = (uint32_t)sc[sb * 16 + (g >> 1)] | ((uint32_t)sc[sb * 16 + 8 + (g >> 1)] << 8);
+    }
+    r.dm = *(const uint32_t *)(d + sb * 2);
+}
+template <int KT>
+__device__ __forceinline__ float k2_chunk(const K2Raw<KT> &r, const int g, const int sb, const int8_t *s_q, const float *s_d,
+                                          const int *s_b) {
+    u32x4 w;
+    int sc, mn = 0;
+    if constexpr (KT == KT_Q2_K) {
+        const int shift = 2 * ((g >> 1) & 3);
+        w = (r.q >> shift) & 0x03030303u;
+        sc = (int)(r.sm & 15);
+        mn = (int)(r.sm >> 4);
+    } else if constexpr (KT == KT_Q3_K) {
+        const int shift = 2 * ((g >> 1) & 3), bit = g >> 1;
+        w = ((r.q >> shift) & 0x03030303u) | (((r.a >> bit) & 0x01010101u) << 2);
+        sc = (int)r.sm - 32;
+    } else {
+        const int j64 = g >> 2, hi = (g >> 1) & 1;
+        const u32x4 nib = hi ? ((r.q >> 4) & 0x0F0F0F0Fu) : (r.q & 0x0F0F0F0Fu);
+        w = nib | (((r.a >> (2 * j64 + hi)) & 0x01010101u) << 4);
+        sc = (int)(r.sm & 0xFF);
+        mn = (int)(r.sm >> 8);
+    }
+    const float d = __half2float(__ushort_as_half((unsigned short)(r.dm & 0xFFFF)));
+    const float dmin = __half2float(__ushort_as_half((unsigned short)(r.dm >> 16)));
+    const i32x4 x = *(const i32x4 *)(s_q + sb * 256 + 16 * g);
+    const int isum = dot16(w, x, 0), bsum = s_b[sb * 16 + g];
+    const float d8 = s_d[sb];
+    if constexpr (KT == KT_Q3_K)
+        return (d * d8) * (float)(sc * (isum - 4 * bsum));
+    else
+        return (d * d8) * (float)(sc * isum) - (dmin * d8) * (float)(mn * bsum);
+}
+template <int KT>
+struct KBigRing {
+    using T = KStep<KT>;
+};
+template <>
+struct KBigRing<KT_Q2_K> {
+    using T = K2Raw<KT_Q2_K>;
+};
+template <>
+struct KBigRing<KT_Q3_K> {
+    using T = K2Raw<KT_Q3_K>;
+};
+template <>
+struct KBigRing<KT_Q5_K> {
+    using T = K2Raw<KT_Q5_K>;
+};
+
 #define KBIG_T 1024
 #define KBIG_PF 4  // steps (8 super-blocks of one row) a wave keeps requested ahead
 
@@ -138,8 +210,11 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int W = KBIG_T / 64;
-    const int c = lane & 7, sbl = lane >> 3;
-    const int nsteps = (nsb + 7) >> 3;
+    constexpr bool K2 = KT == KT_Q2_K || KT == KT_Q3_K || KT == KT_Q5_K;  // 16 lanes per super-block, 4 super-blocks per step
+    constexpr int LPS = K2 ? 16 : 8, SBS = 64 / LPS;
+    const int c = lane & (LPS - 1), sbl = lane / LPS;
+    const int nsteps = (nsb + SBS - 1) / SBS;
+    using RingT = typename KBigRing<KT>::T;
     constexpr bool GATE = EPI == KE_GATE, PAIR = EPI != KE_ROW;
     const int Mt = GATE ? (int)a.w.M : EPI == KE_QKV ? (int)(mmvq_k_rows(a) >> 1) : (int)mmvq_k_rows(a);
     // rows (GATE: units) of this wave: dealt wave-major like k_mmvq_big: row = wave * G + bid + G * W * i
@@ -169,23 +244,33 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
             mmvq_k_select(a, (int64_t)(r_first + r_stride * i), w, row, dst_, ldd_);
         }
         const int64_t g0 = row * nsb;
-        l_qs = w.qs + g0 * 128;
         l_sc = w.sc + g0 * 16;
-        l_aux = w.aux + g0 * 16;
-        l_d = w.d + g0 * (KT == KT_Q4_K ? 2 : 1);
-    };
-    auto load = [&](KStep<KT> &st) {
-        int sb = ls * 8 + sbl;
-        sb = sb < nsb ? sb : nsb - 1;  // lanes past the row end re-read the last super-block and are masked below
-        st.q = __builtin_nontemporal_load((const u32x4 *)(l_qs + sb * 128 + c * 16));
-        st.sc = *(const u32x4 *)(l_sc + sb * 16);
-        if constexpr (KT == KT_Q4_K) {
-            st.dm = *(const uint32_t *)(l_d + sb * 2);
+        if constexpr (K2) {
+            l_qs = w.qs + g0 * (KT == KT_Q5_K ? 128 : 64);
+            l_aux = (const uint32_t *)((const uint8_t *)w.aux + g0 * 32);
+            l_d = w.d + g0 * 2;
         } else {
-            const u32x2 h = __builtin_nontemporal_load((const u32x2 *)(l_aux + (sb * 8 + c) * 2));
-            st.hA = h[0];
-            st.hB = h[1];
-            st.dm = (uint32_t) * (const uint16_t *)(l_d + sb);
+            l_qs = w.qs + g0 * 128;
+            l_aux = w.aux + g0 * 16;
+            l_d = w.d + g0 * (KT == KT_Q4_K ? 2 : 1);
+        }
+    };
+    auto load = [&](RingT &st) {
+        int sb = ls * SBS + sbl;
+        sb = sb < nsb ? sb : nsb - 1;  // lanes past the row end re-read the last super-block and are masked below
+        if constexpr (K2) {
+            k2_issue<KT>(st, l_qs, (const uint8_t *)l_aux, l_sc, l_d, sb, c);
+        } else {
+            st.q = __builtin_nontemporal_load((const u32x4 *)(l_qs + sb * 128 + c * 16));
+            st.sc = *(const u32x4 *)(l_sc + sb * 16);
+            if constexpr (KT == KT_Q4_K) {
+                st.dm = *(const uint32_t *)(l_d + sb * 2);
+            } else {
+                const u32x2 h = __builtin_nontemporal_load((const u32x2 *)(l_aux + (sb * 8 + c) * 2));
+                st.hA = h[0];
+                st.hB = h[1];
+                st.dm = (uint32_t) * (const uint16_t *)(l_d + sb);
+            }
         }
         if (++ls == nsteps) {
             ls = 0;
@@ -217,7 +302,7 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
         }
     }
     // ---- 2. the weight stream starts before the activation is staged
-    KStep<KT> ring[KBIG_PF];
+    RingT ring[KBIG_PF];
     if (nhr > 0) set_row(0);
 #pragma unroll
     for (int k = 0; k < KBIG_PF; k++)
@@ -288,8 +373,13 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
         for (int u = 0; u < KBIG_PF; u++) {
             const int k = k0 + u;
             if (k < S) {  // uniform
-                const int sb = rs * 8 + sbl;
-                if (sb < nsb) acc += kbig_chunk<KT>(ring[u], c, sb, s_q, s_d, s_b);
+                const int sb = rs * SBS + sbl;
+                if (sb < nsb) {
+                    if constexpr (K2)
+                        acc += k2_chunk<KT>(ring[u], c, sb, s_q, s_d, s_b);
+                    else
+                        acc += kbig_chunk<KT>(ring[u], c, sb, s_q, s_d, s_b);
+                }
                 if (++rs == nsteps) {
                     rs = 0;
                     const float v = wave_sum_f32(acc);

@@ -85,7 +85,8 @@ def make_llama_fast(hp, wtype, seed=1234, d_scale=0.0043, only=None):
         nblk = ne1 * (ne0 // be)
         # per-type scale so that dequantized std stays ≈ 0.02: q4 std≈4.6, q5 std≈9.2, q8 std≈74
         sc = {ggml.TYPE_Q4_0: d_scale, ggml.TYPE_Q4_1: d_scale, ggml.TYPE_Q5_0: d_scale / 2,
-              ggml.TYPE_Q5_1: d_scale / 2, ggml.TYPE_Q8_0: d_scale / 16, ggml.TYPE_Q4_K: d_scale, ggml.TYPE_Q6_K: d_scale}[wtype]
+              ggml.TYPE_Q5_1: d_scale / 2, ggml.TYPE_Q8_0: d_scale / 16, ggml.TYPE_Q4_K: d_scale, ggml.TYPE_Q6_K: d_scale,
+              ggml.TYPE_Q2_K: d_scale, ggml.TYPE_Q3_K: d_scale, ggml.TYPE_Q5_K: d_scale}[wtype]
         raw = np.empty(nblk * bs, dtype=np.uint8)
         fill = ggml.lib().llm_synth_blocks
         fill.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float]

@@ -126,17 +126,17 @@ def test_k_plan_on_a_mixed_type_model(G, O):
     model.free()
 
 
-@pytest.mark.parametrize("case", ["q4_k", "q6_k", "k_m mix", "gqa q4_k"])
+@pytest.mark.parametrize("case", ["q4_k", "q6_k", "k_m mix", "gqa q4_k", "q5_k", "q3_k", "q2_k", "q5_k_m mix"])
 def test_big_workgroup_k_mat_vecs_equal_the_helper_launch_form(G, O, case):
     """The K plan's decode mat-vecs as one wave of 1024-thread workgroups that stage the activation themselves (k_mmvq_kbig,
     kernels/kquant_big.h: norm / silu·mul + Q8_K inside the mat-vec's staging, 6 launches per layer) against option kbig = 0
     (k_mmvq_k behind helper launches, 10 per layer): the row dots and the quantizer are the same expressions in the same order,
     so logits, K/V and greedy ids are BIT-IDENTICAL; whole model and a stage of a layer split."""
     from llm_amd import llama
-    wt = {"q4_k": 12, "q6_k": 14, "k_m mix": 12, "gqa q4_k": 12}[case]
+    wt = {"q4_k": 12, "q6_k": 14, "k_m mix": 12, "gqa q4_k": 12, "q5_k": 13, "q3_k": 11, "q2_k": 10, "q5_k_m mix": 13}[case]
     hp0 = GQA_K if case == "gqa q4_k" else TINY_K
     wtypes = None
-    if case == "k_m mix":
+    if case in ("k_m mix", "q5_k_m mix"):
         wtypes = {"output.weight": 14}
         for il in range(hp0["n_layer"]):
             wtypes[f"layers.{il}.attention.wv.weight"] = 14
