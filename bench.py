@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the token after the timed loop")
     ap.add_argument("--roofline-steps", type=int, default=20)
+    ap.add_argument("--headline-only", action="store_true", help="stop the decode run behind the timed steps + roofline replays: no call-sequence, device-sampling or long-context legs (the PMC passes: every dispatch then runs at the context the roofline bytes are stated for)")
     ap.add_argument("--split", type=int, default=2, help="--mode split: device slots ONE session is layer-split over (one process)")
     ap.add_argument("--sessions", default="1,2,4", help="--mode sessions: session counts to run, comma-separated")
     ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "feed", "split", "sessions"],
@@ -382,6 +383,7 @@ def run_single(args):
     # rocprofv3's per-kernel duration of the same launches agrees with it (profiles/), so this is the roofline figure;
     # the same for every mat-vec kind and for all 129 mat-vec launches of a token replayed together.
     rs = max(args.roofline_steps, 1)
+    roofline_ctx = int(sess.n_past)  # positions in the session's K/V: what the fused launch's attention reads per replay
     kinds = {"qkv": 0, "wo": 1, "gate_up": 2, "down": 3, "lm_head": 4}
     per_kind = {}
     if stat("plan_tokens") == h0["plan_tokens"]:  # e.g. GGML_HIP_PLAN_K=0: the node-by-node executor ran, nothing to replay
@@ -404,96 +406,98 @@ def run_single(args):
     oth_ms, oth_n, _ = ggml.bench_plan_class(ggml.KCLASS_OTHER, rs)
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token
     h1 = {k: stat(k) - v for k, v in h0.items()}
-    # the same steps through the reference's OWN call sequence: InferenceSession::compute builds the graph and then calls
-    # ggml_graph_compute synchronously (crates/llm-base/src/inference_session.rs:220-295) — no ggml_hip_graph_compute_begin / _end,
-    # nothing built ahead: what a rustformers/llm binary gets by linking this library with no source change at all
-    sess.set_speculate(False)
-    for _ in range(4):
-        sess.infer_next_token()
-    L.ggml_hip_synchronize()
-    n_ref = max(16, args.steps // 2)
-    sess.host_timing(reset=True)
-    tr = time.perf_counter()
-    for _ in range(n_ref):
-        sess.infer_next_token()
-    L.ggml_hip_synchronize()
-    ref_s = time.perf_counter() - tr
-    ht_ref = [x / n_ref / 1e3 for x in sess.host_timing()]
-    # ... and with the backend's own speculation (option speculate_next / GGML_HIP_SPECULATE_NEXT=1, off by default): behind every
-    # token the device samples the greedy token and runs the next token's plan at once; the caller's unchanged sequence finds its
-    # results on their way whenever it did take the first maximum (it does here: greedy decode)
-    ggml.set_option("speculate_next", 1)
-    for _ in range(4):
-        sess.infer_next_token()
-    L.ggml_hip_synchronize()
-    hits0 = stat("spec_hits")
-    tr = time.perf_counter()
-    for _ in range(n_ref):
-        sess.infer_next_token()
-    L.ggml_hip_synchronize()
-    spec_s = time.perf_counter() - tr
-    spec_hits = stat("spec_hits") - hits0
-    sess.set_speculate(True)
-    for _ in range(4):
-        sess.infer_next_token()
-    L.ggml_hip_synchronize()
-    tr = time.perf_counter()
-    for _ in range(n_ref):
-        sess.infer_next_token()
-    L.ggml_hip_synchronize()
-    spec2_s = time.perf_counter() - tr
-    ggml.set_option("speculate_next", 0)
-    sess.infer_next_token()
-    reference_sequence = {"tokens_per_s": round(n_ref / ref_s, 2), "ms_per_token": round(ref_s / n_ref * 1e3, 4), "tokens": n_ref,
-                          "with_backend_speculation": {"tokens_per_s": round(n_ref / spec_s, 2), "ms_per_token": round(spec_s / n_ref * 1e3, 4),
-                                                       "hits": int(spec_hits), "of": n_ref,
-                                                       "what": "the same unchanged call sequence with GGML_HIP_SPECULATE_NEXT=1 (the device runs the "
-                                                               "greedy next token behind every token; a caller that sampled another token waits for "
-                                                               "that run and then for its own)",
-                                                       "and_begin_end_sequence_tokens_per_s": round(n_ref / spec2_s, 2)},
-                          "graph_build_us_per_token": round(ht_ref[0], 1),
-                          "what": "build the token's graph, then ggml_graph_compute (synchronous): InferenceSession::compute as the reference "
-                                  "has it (inference_session.rs:220-295), zero caller-side changes"}
-    # the same greedy decode with the sampler on the device: ids identical to the loop above
-    # (tests/test_llama_gpu.py), no logits read-back / host sync per token.  Reported beside the metric, not as it.
-    sess.infer_next_token()
-    L.ggml_hip_synchronize()
-    td = time.perf_counter()
-    sess.infer_tokens_device(args.steps)
-    L.ggml_hip_synchronize()
-    dev_s = time.perf_counter() - td
-    # ... and with 8 tokens per hipGraph launch (option chain_k): what the graph-launch gap between tokens costs
-    dev8_s = None
-    if hasattr(ggml, "set_option"):
-        ggml.set_option("chain_k", 8)
-        try:
+    reference_sequence, dev_s, dev8_s, long_ctx = None, None, None, None
+    if not args.headline_only:
+        # the same steps through the reference's OWN call sequence: InferenceSession::compute builds the graph and then calls
+        # ggml_graph_compute synchronously (crates/llm-base/src/inference_session.rs:220-295) — no ggml_hip_graph_compute_begin / _end,
+        # nothing built ahead: what a rustformers/llm binary gets by linking this library with no source change at all
+        sess.set_speculate(False)
+        for _ in range(4):
             sess.infer_next_token()
-            sess.infer_tokens_device(8)  # captures the 8-token graph
-            L.ggml_hip_synchronize()
-            td = time.perf_counter()
-            sess.infer_tokens_device(args.steps)
-            L.ggml_hip_synchronize()
-            dev8_s = time.perf_counter() - td
-        finally:
-            ggml.set_option("chain_k", 0)
-    # the same decode deep into the context (n_past ~1800 of 2048): attention split over positions (decode_attn_split.h)
-    long_ctx = None
-    if args.model != "tiny":
-        ls = model.start_session(n_batch=512)
-        ls.feed_prompt(np.random.default_rng(43).integers(0, hp["n_vocab"], 1792).astype(np.int32))
-        for _ in range(8):
-            ls.infer_next_token()
         L.ggml_hip_synchronize()
-        tl0 = time.perf_counter()
-        for _ in range(32):
-            ls.infer_next_token()
+        n_ref = max(16, args.steps // 2)
+        sess.host_timing(reset=True)
+        tr = time.perf_counter()
+        for _ in range(n_ref):
+            sess.infer_next_token()
         L.ggml_hip_synchronize()
-        long_s = time.perf_counter() - tl0
-        long_ctx = {"n_past_at_start": 1800, "tokens": 32, "tokens_per_s": round(32 / long_s, 2),
-                    "ms_per_token": round(long_s / 32 * 1e3, 4)}
-        ls.free()  # freeing device tensors drops the cached plans: one more token rebuilds the main session's
+        ref_s = time.perf_counter() - tr
+        ht_ref = [x / n_ref / 1e3 for x in sess.host_timing()]
+        # ... and with the backend's own speculation (option speculate_next / GGML_HIP_SPECULATE_NEXT=1, off by default): behind every
+        # token the device samples the greedy token and runs the next token's plan at once; the caller's unchanged sequence finds its
+        # results on their way whenever it did take the first maximum (it does here: greedy decode)
+        ggml.set_option("speculate_next", 1)
+        for _ in range(4):
+            sess.infer_next_token()
+        L.ggml_hip_synchronize()
+        hits0 = stat("spec_hits")
+        tr = time.perf_counter()
+        for _ in range(n_ref):
+            sess.infer_next_token()
+        L.ggml_hip_synchronize()
+        spec_s = time.perf_counter() - tr
+        spec_hits = stat("spec_hits") - hits0
+        sess.set_speculate(True)
+        for _ in range(4):
+            sess.infer_next_token()
+        L.ggml_hip_synchronize()
+        tr = time.perf_counter()
+        for _ in range(n_ref):
+            sess.infer_next_token()
+        L.ggml_hip_synchronize()
+        spec2_s = time.perf_counter() - tr
+        ggml.set_option("speculate_next", 0)
+        sess.infer_next_token()
+        reference_sequence = {"tokens_per_s": round(n_ref / ref_s, 2), "ms_per_token": round(ref_s / n_ref * 1e3, 4), "tokens": n_ref,
+                              "with_backend_speculation": {"tokens_per_s": round(n_ref / spec_s, 2), "ms_per_token": round(spec_s / n_ref * 1e3, 4),
+                                                           "hits": int(spec_hits), "of": n_ref,
+                                                           "what": "the same unchanged call sequence with GGML_HIP_SPECULATE_NEXT=1 (the device runs the "
+                                                                   "greedy next token behind every token; a caller that sampled another token waits for "
+                                                                   "that run and then for its own)",
+                                                           "and_begin_end_sequence_tokens_per_s": round(n_ref / spec2_s, 2)},
+                              "graph_build_us_per_token": round(ht_ref[0], 1),
+                              "what": "build the token's graph, then ggml_graph_compute (synchronous): InferenceSession::compute as the reference "
+                                      "has it (inference_session.rs:220-295), zero caller-side changes"}
+        # the same greedy decode with the sampler on the device: ids identical to the loop above
+        # (tests/test_llama_gpu.py), no logits read-back / host sync per token.  Reported beside the metric, not as it.
         sess.infer_next_token()
         L.ggml_hip_synchronize()
+        td = time.perf_counter()
+        sess.infer_tokens_device(args.steps)
+        L.ggml_hip_synchronize()
+        dev_s = time.perf_counter() - td
+        # ... and with 8 tokens per hipGraph launch (option chain_k): what the graph-launch gap between tokens costs
+        dev8_s = None
+        if hasattr(ggml, "set_option"):
+            ggml.set_option("chain_k", 8)
+            try:
+                sess.infer_next_token()
+                sess.infer_tokens_device(8)  # captures the 8-token graph
+                L.ggml_hip_synchronize()
+                td = time.perf_counter()
+                sess.infer_tokens_device(args.steps)
+                L.ggml_hip_synchronize()
+                dev8_s = time.perf_counter() - td
+            finally:
+                ggml.set_option("chain_k", 0)
+        # the same decode deep into the context (n_past ~1800 of 2048): attention split over positions (decode_attn_split.h)
+        long_ctx = None
+        if args.model != "tiny":
+            ls = model.start_session(n_batch=512)
+            ls.feed_prompt(np.random.default_rng(43).integers(0, hp["n_vocab"], 1792).astype(np.int32))
+            for _ in range(8):
+                ls.infer_next_token()
+            L.ggml_hip_synchronize()
+            tl0 = time.perf_counter()
+            for _ in range(32):
+                ls.infer_next_token()
+            L.ggml_hip_synchronize()
+            long_s = time.perf_counter() - tl0
+            long_ctx = {"n_past_at_start": 1800, "tokens": 32, "tokens_per_s": round(32 / long_s, 2),
+                        "ms_per_token": round(long_s / 32 * 1e3, 4)}
+            ls.free()  # freeing device tensors drops the cached plans: one more token rebuilds the main session's
+            sess.infer_next_token()
+            L.ggml_hip_synchronize()
     host_split = {"plan_tokens": h1["plan_tokens"],
                   "graph_build_and_sampling_ms": round((elapsed * 1e9 - h1["ns_compute"]) / args.steps / 1e6, 4),
                   "match_ms": round(h1["ns_match"] / args.steps / 1e6, 4),
@@ -545,6 +549,7 @@ def run_single(args):
                 "traffic_over_algo": round(traffic / dom["bytes_per_launch"], 4) if traffic else None,
                 "traffic_per_kind": traffic_all,
                 "avg_launch_us": dom["us_per_launch"], "algo_bytes_per_launch": dom["bytes_per_launch"],
+                "context_positions": roofline_ctx,
                 "method": f"{rs} replays of a hipGraph with that launch of every layer between two HIP events on the "
                           "backend stream: launch period incl. the kernel boundary (= rocprofv3's per-kernel duration)",
                 "per_kind": per_kind,
@@ -595,7 +600,8 @@ def run_single(args):
                                           "note": "roofline.per_kind.qkv is the fused launch when it ran: its bytes include the K/V read of the "
                                                   "attention, its time the hand-off wait and the attention tail"},
                       "long_context": long_ctx,
-                      "device_sampling": {"tokens_per_s": round(args.steps / dev_s, 2), "ms_per_token": round(dev_s / args.steps * 1e3, 4),
+                      "device_sampling": None if not dev_s else
+                                         {"tokens_per_s": round(args.steps / dev_s, 2), "ms_per_token": round(dev_s / args.steps * 1e3, 4),
                                           "note": "same greedy tokens via llm_infer_tokens_greedy_device (argmax kernel feeds the next "
                                                   "replay; logits stay in HBM until the last token)",
                                           "eight_tokens_per_graph_launch": None if not dev8_s else

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM traffic per launch of the decode mat-vec kinds from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE collected
 separately, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE is doubled: the gfx950 counter reports
-64-byte units as 32):   pmc_traffic.py <fetch_dir> <write_dir> > profiles/rNN_pmc_traffic.json"""
+64-byte units as 32):   pmc_traffic.py <fetch_dir> <write_dir> ["what the run was"] > profiles/rNN_pmc_traffic.json"""
 import glob
 import json
 import os
@@ -32,4 +32,6 @@ for kind, like in KINDS.items():
                  "hbm_bytes_per_launch": int(round(f * 2 * 1024 + (w or 0.0) * 1024))}
 out["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over a LLaMA-7B Q4_0 decode (GGML_HIP_GRAPH=0); "
                  "bytes = FETCH_SIZE x 2 (gfx950 correction) x 1 KiB + WRITE_SIZE x 1 KiB, per launch")
+if len(sys.argv) > 3:  # what the profiled run was, e.g. the context range its dispatches ran at
+    out["run"] = sys.argv[3]
 print(json.dumps(out, indent=1))
