@@ -102,3 +102,33 @@ def test_two_sessions_alternating_on_one_slot(G):
         model.free()
     for (ta, la), (tb, lb) in zip(ref, got):
         assert ta == tb and np.array_equal(la, lb)
+
+
+def test_speculation_on_the_k_plan(G):
+    """K-quant models run the same speculation (k_argmax_next feeds the K plan's replay exactly as it feeds the device-sampled chain)"""
+    from llm_amd import ggml, llama, synth
+    hp0 = dict(n_vocab=512, n_embd=512, n_head=8, n_head_kv=2, n_layer=3, n_rot=64, n_ff=768, n_mult=32)
+    hp, w = synth.make_llama_fast(hp0, ggml.TYPE_Q4_K, seed=5)
+    model = llama.Llama(hp, w, context_size=128)
+    toks = np.random.default_rng(8).integers(0, hp["n_vocab"], 16).astype(np.int32)
+    script = [("greedy", 10), ("token", 7), ("greedy", 6), ("rewind", 2), ("greedy", 5), ("chunk", [3, 1, 4]), ("greedy", 6)]
+
+    def run(spec):
+        G.set_option("speculate_next", spec)
+        h0, k0 = _stat(G, "spec_hits"), _stat(G, "kplan_tokens")
+        s = model.start_session(n_batch=8)
+        s.set_speculate(False)
+        s.free()
+        out, k, v, n_past = _walk(model, toks, script)
+        return out, k, v, n_past, _stat(G, "spec_hits") - h0, _stat(G, "kplan_tokens") - k0
+
+    try:
+        ref, k0, v0, np0, h_ref, kp_ref = run(0)
+        got, k1, v1, np1, hits, kp = run(1)
+    finally:
+        G.set_option("speculate_next", 0)
+        model.free()
+    assert h_ref == 0 and hits >= 10 and kp_ref > 0 and kp > 0  # (a miss pauses the guessing for eight tokens)
+    assert np0 == np1
+    for (ta, la), (tb, lb) in zip(ref, got):
+        assert ta == tb and np.array_equal(la, lb)
