@@ -21,11 +21,20 @@
 
 template <bool F16_D>
 __device__ __forceinline__ void p_requant4_store(const f32x4 v, int64_t i4, bool valid, _Float16 *__restrict__ out);
+__device__ __forceinline__ void p_requant4_store_k(const f32x4 v, int64_t i4, bool valid, _Float16 *__restrict__ out);
+// K8: the operand of a K-quant weight's GEMM — the row after its Q8_K round trip (k_quant_act_f16_k) instead of Q8_0 / Q8_1
+template <bool F16_D, bool K8>
+__device__ __forceinline__ void p_requant4(const f32x4 v, int64_t i4, bool valid, _Float16 *__restrict__ out) {
+    if constexpr (K8)
+        p_requant4_store_k(v, i4, valid, out);
+    else
+        p_requant4_store<F16_D>(v, i4, valid, out);
+}
 
 // one 256-thread workgroup per token row.  ADD: xs = (x [+ x2]) + r first (written to xsum: the residual stream of the
 // layer; x2 = the second partial of a K-split GEMM, only with ADD).
 // E % 32 == 0 (a block never straddles two rows of threads).
-template <bool F16_D, bool ADD>
+template <bool F16_D, bool ADD, bool K8 = false>
 __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ x, const float *__restrict__ x2 /*nullable*/,
                                                       const float *__restrict__ r, float *xsum, const float *__restrict__ w,
                                                       float eps, int E, float *y_f32 /*nullable*/, _Float16 *__restrict__ out) {
@@ -106,7 +115,7 @@ __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ 
                 y[k] = t;
             }
             if (y_f32 && j < E4) ((f32x4 *)(y_f32 + row * E))[j] = y;
-            p_requant4_store<F16_D>(y, j, j < E4, orow);
+            p_requant4<F16_D, K8>(y, j, j < E4, orow);
         }
     }
 }
@@ -140,18 +149,52 @@ __device__ __forceinline__ void p_requant4_store(const f32x4 v, int64_t i4 /* in
     }
 }
 
+// The same for a K-quant weight's GEMM: the Q8_K round trip of k_quant_act_f16_k (quantize_row_q8_K: the FIRST value of largest
+// magnitude gives iscale = -128 / max, q = min(127, nearest_int(iscale x)), value = (1 / iscale) q).  A super-block of 256 values is
+// the four values of each of a wave's 64 lanes (i4 = 64 x super-block + lane: rows are multiples of 256 wide and every caller
+// indexes 4-vectors by 256 x block + thread), so the extreme and its index are wave reductions (kquant_big.h q8k_wave_block).
+__device__ __forceinline__ void p_requant4_store_k(const f32x4 v, int64_t i4, bool valid, _Float16 *__restrict__ out) {
+    const int lane = (int)(threadIdx.x & 63);
+    const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
+    const float am = wave_max_f32(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    int idx = a0 == am ? 4 * lane : a1 == am ? 4 * lane + 1 : a2 == am ? 4 * lane + 2 : a3 == am ? 4 * lane + 3 : 256;
+    idx = wave_min_i32(idx);  // wave-uniform: the first index holding the extreme
+    const int k = idx & 3;
+    const float cand = k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3];
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), (idx >> 2) & 63));
+    _Float16 h[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float r = 0.0f;
+        if (am != 0.0f) {  // uniform
+            const float iscale = -128.0f / mx;
+            const int q = min(127, __float2int_rn(iscale * v[i]));
+            r = (1.0f / iscale) * (float)q;
+        }
+        r = fminf(fmaxf(r, -65504.0f), 65504.0f);
+        h[i] = (_Float16)r;
+    }
+    if (valid) {
+        const int l8 = (int)(i4 & 7);
+        const int64_t base = (i4 >> 3) * 32 + 8 * (l8 & 3) + 4 * (l8 >> 2);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 o = {h[0], h[2], h[1], h[3]};
+        *(f16x4 *)(out + base) = o;
+    }
+}
+
 // f32 rows (contiguous, n4 4-vectors in total) -> re-quantized f16 operand: k_quant_act_f16 with four values per lane
-template <bool F16_D>
+template <bool F16_D, bool K8 = false>
 __global__ void __launch_bounds__(256) k_p_quant4(const f32x4 *__restrict__ a, int64_t n4, _Float16 *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n4;
     const f32x4 v = valid ? a[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    p_requant4_store<F16_D>(v, i, valid, out);
+    p_requant4<F16_D, K8>(v, i, valid, out);
 }
 
 // silu(a) * b (ggml's f16-table SiLU) -> re-quantization; four values per lane, n4 = number of 4-vectors (rows are
 // multiples of 32 wide, so a block never straddles rows)
-template <bool F16_D>
+template <bool F16_D, bool K8 = false>
 __global__ void __launch_bounds__(256) k_p_silu_mul_quant(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, int64_t n4,
                                                           int64_t part4 /* != 0: second partials this many 4-vectors on */,
                                                           _Float16 *__restrict__ out) {
@@ -171,7 +214,7 @@ __global__ void __launch_bounds__(256) k_p_silu_mul_quant(const f32x4 *__restric
             v[k] = t;
         }
     }
-    p_requant4_store<F16_D>(v, i, valid, out);
+    p_requant4<F16_D, K8>(v, i, valid, out);
 }
 
 // RoPE + K/V store of a prompt batch.  q [N][E] f32 is rotated in place; kf [N][Egqa], vf [N][Egqa] f32 are the wk / wv

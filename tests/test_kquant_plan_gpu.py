@@ -294,6 +294,8 @@ def test_k_plan_at_long_context_uses_the_split_attention(G, O):
     for plan_k in (1, 0):
         G.set_option("plan_k", plan_k)
         G.set_option("attn_split", 512)  # the split path from 512 positions on (default: 768)
+        G.set_option("attn_fused", 0)    # the prompts' attention as the executor's three launches: the same K/V on both sides (the
+                                         # prompt plan of a K-quant model is then bit-identical to the executor, see below)
         try:
             s = model.start_session(n_batch=512)
             outs = []
@@ -307,6 +309,7 @@ def test_k_plan_at_long_context_uses_the_split_attention(G, O):
         finally:
             G.set_option("plan_k", 1)
             G.set_option("attn_split", 1)
+            G.set_option("attn_fused", 1)
         res[plan_k] = (outs, split)
     assert res[1][1] == 10 and res[0][1] == 0
     assert _stat(G, "fused_attn_timeouts") == 0
@@ -349,3 +352,100 @@ def test_mixed_k_quant_file_loads_and_decodes_on_the_k_plan(G, O, tmp_path):
     fil.free()
     assert a[2] == 21 + 10 and b[2] == 21 + 10  # chunks of 8, 8, 5 and ten single tokens: all on the K plan
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+# ---- prompt batches of a K-quant model on the prompt plan (llama_plan.inc plan_launch_prompt with k_prompt_weights) -----------------
+KP_GQA = dict(n_vocab=512, n_embd=512, n_head=8, n_head_kv=2, n_layer=2, n_rot=64, n_ff=768, n_mult=32)
+KP_SPLITK = dict(n_vocab=256, n_embd=1024, n_head=8, n_head_kv=4, n_layer=2, n_rot=128, n_ff=2048, n_mult=32)  # every GEMM splits K in two
+
+
+def _k_m_types(hp):
+    from llm_amd import synth
+    t = {}
+    for name in synth.tensor_shapes(hp):
+        if name == "output.weight" or name.endswith("attention.wv.weight") or name.endswith("feed_forward.w2.weight"):
+            t[name] = 14
+    return t
+
+
+def _run_prompt(G, model, chunks, plan):
+    G.set_option("plan_prompt", plan)
+    try:
+        sess = model.start_session(n_batch=192)
+        outs = []
+        for c in chunks:
+            p0, g0, k0 = _stat(G, "prompt_plan_tokens"), _stat(G, "generic_graphs"), _stat(G, "kplan_tokens")
+            r = sess.evaluate(c, want_embeddings=True)
+            dp, dg, dk = _stat(G, "prompt_plan_tokens") - p0, _stat(G, "generic_graphs") - g0, _stat(G, "kplan_tokens") - k0
+            if len(c) >= 32:
+                assert (dp, dg) == ((len(c), 0) if plan else (0, 1)), (len(c), plan, dp, dg)
+            else:
+                assert dk == len(c)  # chunks of up to 31 tokens: the K plan's multi-token form, whatever plan_prompt says
+            outs.append(r)
+        k, v = sess.get_kv()
+        sess.free()
+    finally:
+        G.set_option("plan_prompt", 1)
+    return outs, k, v
+
+
+@pytest.mark.parametrize("wtype", KTYPES + ["k_m"])
+@pytest.mark.parametrize("cfg", ["gqa", "splitk"])
+def test_k_prompt_plan_is_bit_identical_to_the_node_by_node_executor(G, O, wtype, cfg):
+    """Batches of 32 and more tokens of a K-quant model: the prompt plan (13 launches per layer; token operand = the Q8_K round trip
+    of k_quant_act_f16_k inside k_p_norm_quant / k_p_silu_mul_quant / k_p_quant4, weights = their resident f16 copies) against the
+    node-by-node executor (mul_mat_k_gemm per matrix): logits of every token, the final-norm rows and the K/V, bit for bit (the
+    three-launch attention on both sides, as in test_prompt_plan_gpu.py)."""
+    from llm_amd import llama
+    if cfg == "splitk" and wtype not in (12, "k_m"):
+        pytest.skip("the K-split paths do not depend on the block format")
+    hp0 = {"gqa": KP_GQA, "splitk": KP_SPLITK}[cfg]
+    base = 12 if wtype == "k_m" else wtype
+    hp, w = _model(O, hp0, base, 91, wtypes=_k_m_types(hp0) if wtype == "k_m" else None)
+    model = llama.Llama(hp, w, context_size=512)
+    toks = np.random.default_rng([base, len(cfg)]).integers(0, hp["n_vocab"], 400).astype(np.int32)
+    # 64 at n_past 0 (makes the f16 copies); 33 (ragged; below W16_MIN_TOKENS: runs because the copies exist); 3 and 20 (K plan's
+    # multi-token form in between); 110 at n_past 120; 128 at n_past 230
+    chunks = [toks[0:64], toks[64:97], toks[97:100], toks[100:120], toks[120:230], toks[230:358]]
+    G.set_option("attn_fused", 0)
+    try:
+        a, ka, va = _run_prompt(G, model, chunks, 1)
+        b, kb, vb = _run_prompt(G, model, chunks, 0)
+    finally:
+        G.set_option("attn_fused", 1)
+        model.free()
+    for i, ((la, ea), (lb, eb)) in enumerate(zip(a, b)):
+        assert la.shape == (len(chunks[i]), hp["n_vocab"])
+        assert np.array_equal(la, lb), (cfg, wtype, i, float(np.max(np.abs(la - lb))))
+        assert np.array_equal(ea, eb), (cfg, wtype, i)
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+
+
+@pytest.mark.parametrize("wtype", [12, 14])
+def test_k_prompt_plan_matches_the_oracle(G, O, wtype):
+    """... and against the CPU oracle with the fused attention kernel (the default): the f16 GEMM's bound of the other formats
+    (tests/test_prompt_plan_gpu.py)."""
+    from llm_amd import llama
+    hp, w = _model(O, KP_GQA, wtype, 17)
+    model = llama.Llama(hp, w, context_size=160)
+    orc = O.Llama(hp, w, 160)
+    toks = np.random.default_rng(3).integers(0, hp["n_vocab"], 128).astype(np.int32)
+    sess = model.start_session(n_batch=96)
+    try:
+        for c in (toks[:96], toks[96:128]):
+            p0 = _stat(G, "prompt_plan_tokens")
+            got = sess.evaluate(c)
+            assert _stat(G, "prompt_plan_tokens") - p0 == len(c)
+            ref = orc.evaluate(c, mode=O.ref_mode())
+            std = float(ref.std())
+            rms = float(np.sqrt(np.mean((got - ref) ** 2))) / std
+            mx = float(np.max(np.abs(got - ref))) / std
+            print(f"K prompt plan type {wtype}, {len(c)} tokens: rms {rms:.2e} max {mx:.2e} of std(logits)")
+            assert rms <= 2e-2, rms
+            assert mx <= 1e-1
+            k, v = sess.get_kv()
+            orc.memory_k[:] = k[:orc.memory_k.size]
+            orc.memory_v[:] = v[:orc.memory_v.size]
+    finally:
+        sess.free()
+        model.free()
