@@ -800,6 +800,8 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         g.opt_mmvq_rows = value;
     else if (!strcmp(key, "mmq_min"))
         g.opt_mmq_min = value;
+    else if (!strcmp(key, "k_prompt_min"))  // K-quant models: batch size from which the prompt plan (f16 copies) replaces the K plan's chunks
+        g.opt_k_prompt_min = value;
     else if (!strcmp(key, "mmq_splitk"))
         g.opt_mmq_splitk = value;
     else if (!strcmp(key, "mmq_i8"))

@@ -240,6 +240,7 @@ def test_k_plan_takes_prompt_chunks_of_up_to_31_tokens(G, O, wtype):
 
     def run(plan_k):
         G.set_option("plan_k", plan_k)
+        G.set_option("k_prompt_min", 32)  # (by default chunks of 12 and more tokens take the prompt plan on f16 copies: tests below)
         try:
             sess = model.start_session(n_batch=32)
             outs, ran = [], []
@@ -251,6 +252,7 @@ def test_k_plan_takes_prompt_chunks_of_up_to_31_tokens(G, O, wtype):
             sess.free()
         finally:
             G.set_option("plan_k", 1)
+            G.set_option("k_prompt_min", 12)
         return outs, ran, k, v
 
     a, ran_a, ka, va = run(1)
@@ -370,6 +372,7 @@ def _k_m_types(hp):
 
 def _run_prompt(G, model, chunks, plan):
     G.set_option("plan_prompt", plan)
+    G.set_option("mmq_min", 12)  # the executor takes the f16 GEMM from 12 tokens on too (the plan does by itself: option k_prompt_min)
     try:
         sess = model.start_session(n_batch=192)
         outs = []
@@ -377,22 +380,23 @@ def _run_prompt(G, model, chunks, plan):
             p0, g0, k0 = _stat(G, "prompt_plan_tokens"), _stat(G, "generic_graphs"), _stat(G, "kplan_tokens")
             r = sess.evaluate(c, want_embeddings=True)
             dp, dg, dk = _stat(G, "prompt_plan_tokens") - p0, _stat(G, "generic_graphs") - g0, _stat(G, "kplan_tokens") - k0
-            if len(c) >= 32:
+            if len(c) >= 12:
                 assert (dp, dg) == ((len(c), 0) if plan else (0, 1)), (len(c), plan, dp, dg)
             else:
-                assert dk == len(c)  # chunks of up to 31 tokens: the K plan's multi-token form, whatever plan_prompt says
+                assert dk == len(c)  # chunks of up to 11 tokens: the K plan's multi-token form, whatever plan_prompt says
             outs.append(r)
         k, v = sess.get_kv()
         sess.free()
     finally:
         G.set_option("plan_prompt", 1)
+        G.set_option("mmq_min", 32)
     return outs, k, v
 
 
 @pytest.mark.parametrize("wtype", KTYPES + ["k_m"])
 @pytest.mark.parametrize("cfg", ["gqa", "splitk"])
 def test_k_prompt_plan_is_bit_identical_to_the_node_by_node_executor(G, O, wtype, cfg):
-    """Batches of 32 and more tokens of a K-quant model: the prompt plan (13 launches per layer; token operand = the Q8_K round trip
+    """Batches of 12 and more tokens of a K-quant model: the prompt plan (13 launches per layer; token operand = the Q8_K round trip
     of k_quant_act_f16_k inside k_p_norm_quant / k_p_silu_mul_quant / k_p_quant4, weights = their resident f16 copies) against the
     node-by-node executor (mul_mat_k_gemm per matrix): logits of every token, the final-norm rows and the K/V, bit for bit (the
     three-launch attention on both sides, as in test_prompt_plan_gpu.py)."""
@@ -404,8 +408,8 @@ def test_k_prompt_plan_is_bit_identical_to_the_node_by_node_executor(G, O, wtype
     hp, w = _model(O, hp0, base, 91, wtypes=_k_m_types(hp0) if wtype == "k_m" else None)
     model = llama.Llama(hp, w, context_size=512)
     toks = np.random.default_rng([base, len(cfg)]).integers(0, hp["n_vocab"], 400).astype(np.int32)
-    # 64 at n_past 0 (makes the f16 copies); 33 (ragged; below W16_MIN_TOKENS: runs because the copies exist); 3 and 20 (K plan's
-    # multi-token form in between); 110 at n_past 120; 128 at n_past 230
+    # 64 at n_past 0 (makes the f16 copies); 33 (ragged); 3 (the K plan's multi-token form in between); 20 (the prompt plan from 12
+    # tokens on for a K-quant model); 110 at n_past 120; 128 at n_past 230
     chunks = [toks[0:64], toks[64:97], toks[97:100], toks[100:120], toks[120:230], toks[230:358]]
     G.set_option("attn_fused", 0)
     try:
@@ -429,10 +433,10 @@ def test_k_prompt_plan_matches_the_oracle(G, O, wtype):
     hp, w = _model(O, KP_GQA, wtype, 17)
     model = llama.Llama(hp, w, context_size=160)
     orc = O.Llama(hp, w, 160)
-    toks = np.random.default_rng(3).integers(0, hp["n_vocab"], 128).astype(np.int32)
+    toks = np.random.default_rng(3).integers(0, hp["n_vocab"], 144).astype(np.int32)
     sess = model.start_session(n_batch=96)
     try:
-        for c in (toks[:96], toks[96:128]):
+        for c in (toks[:96], toks[96:128], toks[128:144]):  # (16 tokens: the prompt plan from 12 on for a K-quant model)
             p0 = _stat(G, "prompt_plan_tokens")
             got = sess.evaluate(c)
             assert _stat(G, "prompt_plan_tokens") - p0 == len(c)
