@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(256) k_quantize_act(const char *__restrict__ x
 #define SDOT4(a, b, c) __builtin_amdgcn_sdot4((int)(a), (int)(b), (c), false)
 
 // bits i..i+3 of `h` → byte i bit 4 (the position of the fifth quant bit above a nibble)
+// (the compiler folds the << 4 into the constant and multiplies with v_mul_lo_u32; forcing v_mul_u32_u24 + a separate shift was
+// measured: one instruction more per dword and the 13B Q5_1 w1|w3 launch 4 % slower — the 32-bit multiply is not the slow one here)
 __device__ __forceinline__ uint32_t spread_hi4(uint32_t h4) { return ((h4 * 0x00204081u) & 0x01010101u) << 4; }
 
 template <int QT>
