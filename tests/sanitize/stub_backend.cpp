@@ -12,7 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "ggml_hip.h"
@@ -21,12 +23,15 @@
 namespace {
 int g_main_device = 0;
 float g_split = 0.0f;
+// the driver runs two sessions on two threads: the real backend serialises these behind its slot / arena locks, the stand-in
+// needs its own (an unguarded std::map here made the sanitizer job fail about once in fifty runs)
+std::mutex g_mu;
 std::map<void *, size_t> g_arenas;
-uint64_t g_graphs = 0;
-ggml_cgraph *g_pending = nullptr;
+std::atomic<uint64_t> g_graphs{0};
+thread_local ggml_cgraph *g_pending = nullptr;  // begin / end are called by the same thread
 
 void fake_compute(ggml_cgraph *gr) {
-    g_graphs++;
+    const uint64_t graphs = ++g_graphs;
     for (int i = 0; i < gr->n_nodes; i++) {
         ggml_tensor *t = gr->nodes[i];
         // touch every operand header the executor would read: a dangling src pointer trips ASan here
@@ -37,7 +42,7 @@ void fake_compute(ggml_cgraph *gr) {
         float *d = (float *)t->data;
         const int64_t n = ggml_nelements(t);
         for (int64_t k = 0; k < n; k++) {  // deterministic, position-dependent "logits": the argmax moves from graph to graph
-            uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull + g_graphs * 0xD1B54A32D192ED03ull;
+            uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull + graphs * 0xD1B54A32D192ED03ull;
             x ^= x >> 29;
             d[k] = (float)(int32_t)(x & 0xFFFF) / 65536.0f;
         }
@@ -46,8 +51,14 @@ void fake_compute(ggml_cgraph *gr) {
 }  // namespace
 
 extern "C" {
-void ggml_hip_internal_register_arena(void *host_base, size_t size, int) { g_arenas[host_base] = size; }
-void ggml_hip_internal_unregister_arena(void *host_base) { g_arenas.erase(host_base); }
+void ggml_hip_internal_register_arena(void *host_base, size_t size, int) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_arenas[host_base] = size;
+}
+void ggml_hip_internal_unregister_arena(void *host_base) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_arenas.erase(host_base);
+}
 void ggml_hip_internal_graph_compute(struct ggml_cgraph *cgraph) { fake_compute(cgraph); }
 
 void ggml_init_hipblas(void) {}
