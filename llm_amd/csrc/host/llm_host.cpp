@@ -12,6 +12,7 @@
 #endif
 #include "llm_host.h"
 
+#include <atomic>
 #include <chrono>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -134,7 +135,9 @@ class InferenceSession {
     using Builder = std::function<std::pair<ComputationGraph, GraphOutputs>(BuildContext &)>;
     // host time per phase of compute(), ns, accumulated (llm_host_timing): [0] adopt/build, [1] token write + plan,
     // [2] begin (match + enqueue), [3] speculative build of the next graph, [4] end (wait + result copy)
-    static inline double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (process-wide and updated by every session thread: relaxed atomics — a statistic, but not a data race)
+    static inline std::atomic<int64_t> host_ns[8] = {};
+    static inline void host_ns_add(int k, double ns) { host_ns[k].fetch_add((int64_t)ns, std::memory_order_relaxed); }
     static inline double now_ns() {
         return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
@@ -149,7 +152,7 @@ class InferenceSession {
                          const void *model_key = nullptr, size_t context_size = 0) {
         const bool single = input_tokens.size() == 1;
         double t0 = now_ns(), t1;
-        auto lap = [&](int k) { t1 = now_ns(); host_ns[k] += t1 - t0; t0 = t1; };
+        auto lap = [&](int k) { t1 = now_ns(); host_ns_add(k, t1 - t0); t0 = t1; };
         Built built;
         if (single && pre_.valid && pre_.n_past == n_past && pre_.model_key == model_key) {
             cur_ = pre_.slot;  // adopt the speculatively built graph
@@ -1091,8 +1094,8 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
     llm::OutputRequest req;
     const double t1 = llm::InferenceSession::now_ns();
     model_evaluate(m, s, std::vector<llm::TokenId>{next}, req);
-    llm::InferenceSession::host_ns[5] += t1 - t0;                                // argmax
-    llm::InferenceSession::host_ns[6] += llm::InferenceSession::now_ns() - t1;  // evaluate, all of it
+    llm::InferenceSession::host_ns_add(5, t1 - t0);                                // argmax
+    llm::InferenceSession::host_ns_add(6, llm::InferenceSession::now_ns() - t1);  // evaluate, all of it
     return next;
 }
 // n greedy tokens with the sampler on the device (ggml_hip_decode_greedy_chain): the same ids and the
@@ -1121,8 +1124,8 @@ int llm_infer_tokens_greedy_device(llm_model *m, llm_session *s, int n, int32_t 
 // Accumulated host nanoseconds per phase (see InferenceSession::host_ns; [5] greedy argmax, [6] evaluate as a whole);
 // reset != 0 clears the accumulators after the read.
 void llm_host_timing(double *out8, int reset) {
-    for (int i = 0; i < 8; i++) out8[i] = llm::InferenceSession::host_ns[i];
-    if (reset) for (int i = 0; i < 8; i++) llm::InferenceSession::host_ns[i] = 0;
+    for (int i = 0; i < 8; i++) out8[i] = (double)llm::InferenceSession::host_ns[i].load(std::memory_order_relaxed);
+    if (reset) for (int i = 0; i < 8; i++) llm::InferenceSession::host_ns[i].store(0, std::memory_order_relaxed);
 }
 int llm_session_rewind(llm_session *s, int num) {
     if ((size_t)num >= s->s->n_past) return -1;  // RewindError::NotEnoughTokens

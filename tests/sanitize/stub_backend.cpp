@@ -21,8 +21,8 @@
 #include "internal.h"
 
 namespace {
-int g_main_device = 0;
-float g_split = 0.0f;
+std::atomic<int> g_main_device{0};
+std::atomic<float> g_split{0.0f};
 // the driver runs two sessions on two threads: the real backend serialises these behind its slot / arena locks, the stand-in
 // needs its own (an unguarded std::map here made the sanitizer job fail about once in fifty runs)
 std::mutex g_mu;

@@ -41,3 +41,29 @@ def test_host_cpp_under_asan_and_ubsan(tmp_path):
     assert r.returncode == 0, tail
     assert "sanitize driver OK" in r.stdout
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, tail
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not installed")
+def test_host_cpp_under_tsan(tmp_path):
+    """The same driver under ThreadSanitizer: its two-sessions-on-two-threads walk (the reference's "several sessions for one
+    model on several threads", crates/llm-base/src/inference_session.rs:43-48) must not race in the host C++ — the shared model,
+    the process-wide host timers, the ggml arenas of the two sessions."""
+    from llm_amd import ggml, synth
+    exe = tmp_path / "tsan_driver"
+    srcs = ["llm_amd/csrc/ggml_core.cpp", "llm_amd/csrc/host/llm_host.cpp", "tests/sanitize/stub_backend.cpp",
+            "tests/sanitize/driver.cpp"]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-Iinclude", "-Illm_amd/csrc",
+           "-pthread"] + srcs + ["-o", str(exe)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    hp0 = dict(n_vocab=256, n_embd=128, n_head=4, n_head_kv=4, n_layer=2, n_rot=32, n_ff=384, n_mult=32)
+    hp, w = synth.make_llama(hp0, ggml.TYPE_Q4_0)
+    path = tmp_path / "tiny.ggjt"
+    synth.write_ggjt(str(path), hp, w)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0")
+    r = subprocess.run([str(exe), str(path)], capture_output=True, text=True, timeout=600, env=env)
+    tail = (r.stdout + r.stderr)[-4000:]
+    if "FATAL: ThreadSanitizer" in tail:  # a sandbox whose memory layout the runtime does not support
+        pytest.skip("ThreadSanitizer cannot run here: " + tail.strip().splitlines()[-1])
+    assert "WARNING: ThreadSanitizer" not in r.stderr, tail
+    assert r.returncode == 0 and "sanitize driver OK" in r.stdout, tail
