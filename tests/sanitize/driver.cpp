@@ -88,6 +88,21 @@ static void session_walk(llm_model *m, int seed) {
     CHECK(llm_session_last_logits(s) != nullptr);
     std::vector<float> node(1 << 16);
     (void)llm_session_read_node(s, 0, nullptr, 0, node.data(), node.size() * 4);
+    // round-5 entry points: the reference's own call order per token (no graph built ahead), a session on a named device slot,
+    // a seek behind K/V the caller has put in place, the host mirror of a node
+    llm_session_set_speculate(s, 0);
+    for (int i = 0; i < 3; i++) (void)llm_infer_next_token_greedy(m, s);
+    llm_session_set_speculate(s, 1);
+    (void)llm_infer_next_token_greedy(m, s);
+    (void)llm_session_read_node_host(s, 1, node.data(), node.size() * 4);
+    (void)llm_session_read_node_host(s, 1 << 20, node.data(), 16);  // far beyond the graph: nothing copied
+    llm_session *s3 = llm_start_session_on(m, &cfg, 0);
+    CHECK(s3);
+    llm_feed_prompt(m, s3, toks.data(), 5);
+    llm_session_seek(s3, 9);
+    CHECK(llm_session_n_past(s3) == 9);
+    (void)llm_infer_next_token_greedy(m, s3);
+    llm_session_free(s3);
     llm_session_free(s2);
     llm_session_free(s);
 }
