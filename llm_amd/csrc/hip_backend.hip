@@ -780,6 +780,18 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_fuse_wo != value) drop_all_plans();
         g.opt_fuse_wo = value;
     }
+    else if (k == "warm_rows") {
+        if (g.opt_warm_rows != value) drop_all_plans();
+        g.opt_warm_rows = value;
+    }
+    else if (k == "warm_norm") {
+        if (g.opt_warm_norm != value) drop_all_plans();
+        g.opt_warm_norm = value;
+    }
+    else if (k == "warm_wave") {
+        if (g.opt_warm_wave != value) drop_all_plans();
+        g.opt_warm_wave = value & 15;
+    }
     else if (k == "big") {
         if (g.opt_big != value) drop_all_plans();
         g.opt_big = value;

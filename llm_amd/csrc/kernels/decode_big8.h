@@ -116,8 +116,8 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big8(const Big8Args ba) {
             st.q[k] = __builtin_nontemporal_load((const u32x4 *)(qs + (size_t)o * 16));
             if constexpr (QT == QT_Q8_0) st.p[k] = __builtin_nontemporal_load((const u32x4 *)(qs2 + (size_t)o * 16));
             if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) st.h[k] = __builtin_nontemporal_load(qh + o);
-            st.dw[k] = wd[o];
-            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) st.mw[k] = wm[o];
+            st.dw[k] = ((const unsigned short *)wd)[o];  // raw f16 bits, zero-extended (BigStep)
+            if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) st.mw[k] = ((const unsigned short *)wm)[o];
         }
     };
 
@@ -196,8 +196,8 @@ __global__ void __launch_bounds__(BIG_T) k_mmvq_big8(const Big8Args ba) {
                     mwf[r] = 0.0f;
                     if constexpr (QT == QT_Q8_0) p2 = st.p[r];
                     if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) hh = st.h[r];
-                    if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mwf[r] = __half2float(st.mw[r]);
-                    dwf[r] = __half2float(st.dw[r]);
+                    if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mwf[r] = big_h2f(st.mw[r]);
+                    dwf[r] = big_h2f(st.dw[r]);
                     block_unpack<QT>(st.q[r], p2, hh, wl[r], wh[r]);
                 }
 #pragma unroll

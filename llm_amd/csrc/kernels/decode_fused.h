@@ -61,6 +61,61 @@ struct FusedAttnArgs {
 // attention): the launcher takes it only while this slot has the GPU's CUs to itself (fused_qkv_shape).
 // ---------------------------------------------------------------------------------------------------
 #define OGRAN 10  // granules per Q8 block of the attention output: 4 words of quants 0..15, 4 of quants 16..31, d, sum
+
+// ---------------------------------------------------------------------------------------------------
+// L2 warm-up of the NEXT launch from the window in which HBM idles.  Between a mat-vec workgroup's last wq|wk|wv row pair and the
+// first head output it can gather (7.4 -> 13.7 us of a 17 us launch at 7B, profiles/r05_wo_timeline_128.txt) nothing streams but
+// 42 KB of wo per workgroup.  One wave per workgroup spends that window touching the first rows of w1|w3 — one 4-byte LDS-DMA
+// load per 128-byte line, no VGPR, nothing waits for the data — so that the next launch finds them in the L2 OF THE XCD THAT
+// READS THEM: k_mmvq_big deals row m to workgroup m mod G, workgroups go to XCDs round robin (observed, never relied on for
+// anything but speed: MI355X_MICROARCH.md "Workgroup dispatch"), so rows = x mod 8 belong to XCD x, and the warming workgroup
+// reads its own XCD id from the hardware register.  An XCD's L2 keeps its lines across the kernel boundary
+// (tests/tools/overlap_probe3.hip).  Round 2 tried this from the spare workgroups of the then separate attention launch and lost
+// what it won (the heads' K/V round trips queued behind the warm-up, and the launch ended when the warm-up did); here the heads'
+// K/V are requested at kernel entry, the warming wave's own polls are the only thing behind its requests, and the launch cannot
+// end before the gather.  Nothing is computed from the warmed bytes: results cannot change.
+// ---------------------------------------------------------------------------------------------------
+constexpr int WARM_MAX = 10;  // arrays: qs, d (+ qs2 | qh | m) of w1 and of w3
+struct NextWarm {
+    const uint8_t *base[WARM_MAX];
+    uint32_t row_bytes[WARM_MAX];  // bytes of one matrix row in that array
+    int n;                         // arrays in use
+    int rows;                      // rows 0 .. rows - 1 of every array are warmed; 0 = off
+    const uint8_t *bcast;          // a small array EVERY workgroup of the next launch reads (the norm weights): one workgroup per XCD takes it
+    int bcast_bytes;
+};
+__device__ __forceinline__ int xcc_id() {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x & 7;
+}
+// called by ONE wave of mat-vec workgroup `bid` of `G`; `junk` = 256 bytes of LDS nobody reads
+__device__ __forceinline__ void warm_next(const NextWarm &nw, const int bid, const int G, const int lane, unsigned *junk) {
+    typedef const __attribute__((address_space(1))) void *wg_ptr;
+    typedef __attribute__((address_space(3))) void *wl_ptr;
+    const int x = xcc_id();
+    const int j = bid >> 3, nj = (G + 7) >> 3;   // this workgroup among its XCD's (round-robin placement assumed, for speed only)
+    const int K = (nw.rows + 7 - x) >> 3;        // rows x, x + 8, ... of the first nw.rows
+    const int c = (K + nj - 1) / nj;
+    const int k0 = j * c, cnt = K - k0 < c ? K - k0 : c;
+    for (int a = 0; a < nw.n; a++) {
+        const uint32_t rb = nw.row_bytes[a];
+        const int lpr = (int)((rb + 127) >> 7);  // samples per row, 128 bytes apart + the row's last word: every line it touches
+        const uint8_t *base = nw.base[a];
+        const float inv = 1.0f / (float)lpr;
+        for (int i = lane; i < cnt * lpr; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * inv), l = i - r * lpr;  // exact: i < 2^16, lpr <= 2^8
+            uint32_t off = (uint32_t)l << 7;
+            off = off + 4 > rb ? rb - 4 : off;
+            const uint8_t *p = base + (size_t)(uint32_t)(x + 8 * (k0 + r)) * rb + off;
+            __builtin_amdgcn_global_load_lds((wg_ptr)p, (wl_ptr)junk, 4, 0, 0);
+        }
+    }
+    if (j == 0 && nw.bcast)
+        for (int i = lane * 128; i < nw.bcast_bytes; i += 64 * 128)
+            __builtin_amdgcn_global_load_lds((wg_ptr)(nw.bcast + i), (wl_ptr)junk, 4, 0, 0);
+}
+
 struct WoTailArgs {
     QWeight w;            // wo
     const float *res;     // residual (the layer's input row)
@@ -68,6 +123,8 @@ struct WoTailArgs {
     int cap;              // (unused)
     long long *ts;        // optional timeline slot (option "timeline"): 8 x int64 per sampled workgroup, as big_body's
     int ts_wgs;
+    NextWarm warm;        // the next launch's first rows (w1|w3), warmed into L2 while the attention runs
+    int warm_wave;        // the wave that issues the warm-up
 };
 constexpr int WO_NG_MAX = 2;  // granules per thread it may gather (E / 32 * OGRAN <= 2048)
 
@@ -164,6 +221,11 @@ __device__ __forceinline__ void wo_tail(const WoTailArgs &t, const FusedAttnArgs
             block_unpack<QT>(q[r][j], p2, hh, wl[r][j], wh[r][j]);
         }
     const long long t2 = t.ts ? (long long)wall_clock64() : 0;
+    // ---- HBM is idle from here until the heads are done: one wave warms the next launch's first rows (see NextWarm)
+    if (t.warm.rows > 0 && wave == t.warm_wave) {
+        __shared__ unsigned s_junk[64];
+        warm_next(t.warm, bid, G, lane, s_junk);
+    }
     // ---- the heads' outputs: nb * OGRAN granules, swept by all threads until every tag is this token's epoch
     const int ngran = nb * OGRAN;
 #pragma unroll
