@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the token after the timed loop")
+    ap.add_argument("--no-per-layer-check", action="store_true", help="... keep the whole-model check, skip the one-layer-at-a-time one")
     ap.add_argument("--roofline-steps", type=int, default=20)
     ap.add_argument("--headline-only", action="store_true", help="stop the decode run behind the timed steps + roofline replays: no call-sequence, device-sampling or long-context legs (the PMC passes: every dispatch then runs at the context the roofline bytes are stated for)")
     ap.add_argument("--split", type=int, default=2, help="--mode split: device slots ONE session is layer-split over (one process)")
@@ -218,7 +219,8 @@ def parity_check(args, hp, w, sess):
     assert sess.infer_next_token() == int(tok[0])  # InferenceSession::infer_next_token: argmax of the last logits, evaluated
     got = sess.last_logits()
     t = time.perf_counter()
-    ref = orcs[0].evaluate(tok, mode=mode)[-1]
+    ref_all, taps = orcs[0].evaluate(tok, mode=mode, taps=True)
+    ref = ref_all[-1]
     ref_s = time.perf_counter() - t
     rev = orcs[1].evaluate(tok, mode=mode, reverse_blocks=True)[-1]
     mth = orcs[2].evaluate(tok, mode=1)[-1]
@@ -264,7 +266,94 @@ def parity_check(args, hp, w, sess):
     if not ok:
         print(json.dumps({"parity_check": out}), flush=True)
         raise SystemExit(f"bench.py: parity check failed: max |dlogit| = {d:.3e} std > bound {bound:.3e} (band {band:.3e}, floor {floor:.3e})")
+    if not args.no_per_layer_check:
+        out["per_layer"] = per_layer_check(hp, w, k, v, n_past, tok, ctx, taps, ref, std)
+        sess.infer_next_token()  # freeing the stage models' device tensors dropped the cached plans: one more token rebuilds the session's
+        out["whole_model_note"] = ("max_over_std / bound_over_std above compare LOGITS behind the whole stack: information (the bound is the "
+                                   "oracle's own two-order band, which a deep random-init stack makes wide); per_layer is the check")
+        if not out["per_layer"]["passed"]:
+            print(json.dumps({"parity_check": out}), flush=True)
+            raise SystemExit(f"bench.py: per-layer parity check failed: worst {out['per_layer']['worst_max']} > bound {out['per_layer']['bound_max']}")
     return out
+
+
+LAYER_STRICT, LAYER_CAP = 2e-5, 1e-1  # tests/test_ref_branch_gpu.py: an evaluation without a flipped quant; the cap on any layer
+
+
+def per_layer_check(hp, w, k, v, n_past, tok, ctx, taps, ref_logits, logit_std):
+    """EVERY layer of the bench's model, alone, at the bench's own operating point (the session's n_past, the kernels the timed
+    steps ran): layer il is a one-layer stage on the device (crates/models/llama/src/lib.rs:174-338 for that layer; the last one
+    with the final norm and lm_head, :340-352) fed with the ORACLE's input row of that layer and the session's K/V of the positions
+    before the token, its output row held against the oracle's.  Yardstick per layer = the oracle against itself with its block
+    sums in reverse order on the same row (tests/test_ref_branch_gpu.py _layers_alone: the same method on five layers of a
+    six-layer stack at position 21).  A 32-layer stack of gaussian weights amplifies one flipped int8 quant chaotically — the
+    whole-model number above is information; ONE layer cannot hide behind that."""
+    import ctypes as C
+    from oracle import oracle
+    from llm_amd import ggml, llama, synth
+    L, E = hp["n_layer"], hp["n_embd"]
+    Eg = E // (hp["n_head"] // hp["n_head_kv"])
+    per = ctx * Eg
+    mode = oracle.ref_mode()
+    rows, worst, band_mx, band_rms, n_strict = [], 0.0, 0.0, 0.0, 0
+    fw0 = int(ggml.lib().ggml_hip_get_stat(b"fused_wo_tokens"))
+    fa0 = int(ggml.lib().ggml_hip_get_stat(b"fused_attn_tokens"))
+    t0 = time.perf_counter()
+    for il in range(L):
+        last = il == L - 1
+        rows_in = taps["inpL0"] if il == 0 else taps["layer_out_all"][il - 1]
+        want = ref_logits[None, :] if last else taps["layer_out_all"][il]
+        kl, vl = k[il * per:(il + 1) * per], v[il * per:(il + 1) * per]
+        # the oracle's second order on the same input: a one-layer model of layer il's weights (+ norm / lm_head for the last)
+        hp1 = dict(hp)
+        hp1["n_layer"] = 1
+        w1 = {kk: vv for kk, vv in w.items() if not kk.startswith("layers.")}
+        for kk, vv in w.items():
+            if kk.startswith(f"layers.{il}."):
+                w1["layers.0." + kk.split(".", 2)[2]] = vv
+        o = oracle.Llama(hp1, w1, ctx)
+        o.memory_k[:], o.memory_v[:], o.n_past = kl, vl, n_past
+        lg, tt = o.evaluate(tok, mode=mode, taps=True, reverse_blocks=True, inp=rows_in)
+        rev = lg[-1][None, :] if last else tt["layer_out_all"][0]
+        # the device: the same layer as a stage of a layer split
+        names = synth.stage_tensor_names(hp, il, il + 1)
+        stage = llama.Llama(hp, {kk: vv for kk, vv in w.items() if kk in names}, context_size=ctx, layer_range=(il, il + 1))
+        ss = stage.start_session(n_batch=8)
+        in_dev, out_dev, _ = ss.stage_buffers()
+        ss.set_kv(kl, vl)
+        ss.seek(n_past)
+        x = np.ascontiguousarray(rows_in, np.float32)
+        if il > 0:
+            ggml.lib().ggml_hip_memcpy(C.c_void_p(in_dev), C.c_void_p(x.ctypes.data), x.nbytes, 0)
+        lgd = ss.evaluate(tok, want_all_logits=last)
+        if last:
+            got = lgd[-1][None, :]
+        else:
+            got = np.zeros_like(x)
+            ggml.lib().ggml_hip_memcpy(C.c_void_p(got.ctypes.data), C.c_void_p(out_dev), got.nbytes, 1)
+        ss.free()
+        stage.free()
+        s_ = float(logit_std) if last else float((want - rows_in).std())  # the size of what the layer adds to the residual
+        d, dr = np.abs(got - want), np.abs(rev - want)
+        mx, rms = float(d.max()) / s_, float(np.sqrt(np.mean(d ** 2))) / s_
+        bmx, brms = float(dr.max()) / s_, float(np.sqrt(np.mean(dr ** 2))) / s_
+        rows.append({"layer": il, "max": float(f"{mx:.3e}"), "rms": float(f"{rms:.3e}"), "band_max": float(f"{bmx:.3e}"),
+                     "band_rms": float(f"{brms:.3e}")})
+        worst, band_mx, band_rms = max(worst, mx), max(band_mx, bmx), max(band_rms, brms)
+        n_strict += mx <= LAYER_STRICT
+    bound = max(2.0 * band_mx, 10.0 * LAYER_STRICT)
+    bound_rms = max(2.0 * band_rms, 10.0 * LAYER_STRICT)
+    ok = all(r["max"] <= min(bound, LAYER_CAP) * (1 + 1e-3) and r["rms"] <= bound_rms * (1 + 1e-3) for r in rows)
+    return {"layers": rows, "worst_max": float(f"{worst:.3e}"), "band_max": float(f"{band_mx:.3e}"), "band_rms": float(f"{band_rms:.3e}"),
+            "bound_max": float(f"{min(bound, LAYER_CAP):.3e}"), "bound_rms": float(f"{bound_rms:.3e}"),
+            "layers_within_strict_2e-5": int(n_strict), "passed": bool(ok), "n_past": int(n_past),
+            "stage_tokens_on_the_fused_wo_launch": int(ggml.lib().ggml_hip_get_stat(b"fused_wo_tokens")) - fw0,
+            "stage_tokens_on_a_fused_attention_launch": int(ggml.lib().ggml_hip_get_stat(b"fused_attn_tokens")) - fa0,
+            "seconds": round(time.perf_counter() - t0, 1),
+            "what": "every layer ALONE as a one-layer stage on the device, on the oracle's input row of that layer and the session's "
+                    "K/V, at the timed steps' n_past; max / rms of (device - oracle) over the std of the layer's update (the last "
+                    "entry: final norm + lm_head, over the std of the logits); band = the oracle with its block sums in reverse "
+                    "order on the same row; fails above max(2 x worst band, 10 x 2e-5) or above 1e-1"}
 
 
 def prefill_leg(L, ggml, model, hp, n, steps, warmup, wname):
