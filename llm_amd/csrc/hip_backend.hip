@@ -780,6 +780,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_fuse_wo != value) drop_all_plans();
         g.opt_fuse_wo = value;
     }
+    else if (k == "warm_mb") {
+        if (g.opt_warm_mb != value) drop_all_plans();
+        g.opt_warm_mb = value;
+    }
     else if (k == "warm_rows") {
         if (g.opt_warm_rows != value) drop_all_plans();
         g.opt_warm_rows = value;

@@ -255,7 +255,10 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
     constexpr bool F16_D = QT == QT_Q4_0 || QT == QT_Q5_0 || QT == QT_Q8_0;
     constexpr int RU = EPI == EPI_QKV ? 2 : 1, NW = EPI == EPI_GATE ? 2 : 1, NR = RU * NW;
     constexpr int PF = big_pf<QT>(NR);
-    constexpr int PF0 = PF < 2 ? PF : 2;  // steps requested before x is staged (see step 2)
+#ifndef BIG_PF0
+#define BIG_PF0 2
+#endif
+    constexpr int PF0 = PF < BIG_PF0 ? PF : BIG_PF0;  // steps requested before x is staged (see step 2)
     // all index arithmetic is 32-bit (rows <= 2^17, blocks per matrix < 2^27): 64-bit divides and multiplies in
     // the prologue cost ~1 us of VALU time per launch
     const int nb = (int)a.nb;

@@ -22,6 +22,9 @@
 #pragma once
 #include "decode_big.h"
 #include "decode_attn_split.h"  // attn_one_wait and the hand-off protocol of k_attn_split_one
+#ifndef GRAN_SLEEP
+#define GRAN_SLEEP 2  // s_sleep between two polls of a granule sweep (64-cycle units)
+#endif
 
 struct FusedAttnArgs {
     const __half *mem_k, *mem_v;  // + layer offset, layouts of DecMmvqArgs
@@ -203,6 +206,12 @@ __device__ __forceinline__ void wo_tail(const WoTailArgs &t, const FusedAttnArgs
     const float res_pre = t.res[lane < nrw ? bid + G * (wave + 16 * lane) : 0];
     const long long t1 = t.ts ? (long long)wall_clock64() : 0;
     __syncthreads();  // every wave is done with the staged activation of wq|wk|wv: its LDS is re-used from here on
+    // ---- this workgroup's share of HBM is idle from here until the heads are done: one wave warms the next launch's first rows
+    //      (see NextWarm) — behind its own rows of wo in its queue, ahead of its polls by microseconds
+    if (t.warm.rows > 0 && wave == t.warm_wave) {
+        __shared__ unsigned s_junk[64];
+        warm_next(t.warm, bid, G, lane, s_junk);
+    }
     for (int i = nb + tid; i < nbp; i += 1024) {  // padded blocks (a row that does not fill its last 64-block step) stay zero
         s_lo[i] = i32x4{0, 0, 0, 0};
         s_hi[i] = i32x4{0, 0, 0, 0};
@@ -221,11 +230,6 @@ __device__ __forceinline__ void wo_tail(const WoTailArgs &t, const FusedAttnArgs
             block_unpack<QT>(q[r][j], p2, hh, wl[r][j], wh[r][j]);
         }
     const long long t2 = t.ts ? (long long)wall_clock64() : 0;
-    // ---- HBM is idle from here until the heads are done: one wave warms the next launch's first rows (see NextWarm)
-    if (t.warm.rows > 0 && wave == t.warm_wave) {
-        __shared__ unsigned s_junk[64];
-        warm_next(t.warm, bid, G, lane, s_junk);
-    }
     // ---- the heads' outputs: nb * OGRAN granules, swept by all threads until every tag is this token's epoch
     const int ngran = nb * OGRAN;
 #pragma unroll
@@ -238,7 +242,7 @@ __device__ __forceinline__ void wo_tail(const WoTailArgs &t, const FusedAttnArgs
             x = gran_load(gp);
             const bool ok = (unsigned)(x >> 32) == epoch;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(GRAN_SLEEP);
             if (spin > GRAN_SPIN_MAX) {
                 if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -346,7 +350,7 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
             x = gran_load(gp);
             const bool ok = (unsigned)(x >> 32) == epoch;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(GRAN_SLEEP);
             if (spin > GRAN_SPIN_MAX) {  // a producer never arrived (see GRAN_SPIN_MAX, kernels/common.h)
                 if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -572,7 +576,7 @@ __device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, cons
             x = gran_load(gp);
             const bool ok = (unsigned)(x >> 32) == epoch;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(GRAN_SLEEP);
             if (spin > GRAN_SPIN_MAX) {
                 if (lane == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
