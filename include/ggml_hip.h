@@ -453,6 +453,8 @@ GGML_API bool ggml_cuda_compute_forward(struct ggml_compute_params *params, stru
 /* ---- HIP-backend extensions (no reference counterpart; measurement and multi-GPU plumbing) ---- */
 /* Number of visible devices (0 when no GPU / HIP runtime unusable). Never aborts. */
 GGML_API int ggml_hip_device_count(void);
+/* The physical GPU a device slot drives (slot s -> (GGML_HIP_DEVICE + s) mod visible GPUs), -1 for a slot that does not exist. */
+GGML_API int ggml_hip_slot_physical_device(int slot);
 /* Several devices in one process (the ggml-style layer split of one InferenceSession).  A device
  * "slot" owns a stream, the device shadows of the host arenas, the weights uploaded while it was current and its plan cache;
  * ggml_hip_set_main_device (cuda.rs:62) makes a slot current for every following call.  GGML_HIP_VIRTUAL_DEVICES=n maps n

@@ -543,6 +543,13 @@ bool ggml_cuda_compute_forward(struct ggml_compute_params *p, struct ggml_tensor
 // exported: extensions
 // ===================================================================================================
 int ggml_hip_device_count(void) { return slot_count(); }
+int ggml_hip_slot_physical_device(int slot) {  // the GPU a slot drives (ensure_init's rule), without initialising it; -1: no such slot
+    int n = 0;
+    if (slot < 0 || slot >= slot_count() || hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
+    int base = 0;
+    if (const char *lr = getenv("GGML_HIP_DEVICE")) base = atoi(lr);
+    return (base + slot) % n;
+}
 int ggml_hip_get_main_device(void) {  // the calling thread's slot
     if (!tl_pinned) g_cur = &g_backends[g_default_slot.load(std::memory_order_relaxed)];
     return (int)(g_cur - g_backends);

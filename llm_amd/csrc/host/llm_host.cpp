@@ -965,6 +965,12 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
 // (GGML_HIP_VIRTUAL_DEVICES=n provides n slots on a 1-GPU box; slot = -1: the model's own).  Unsplit models only.
 llm_session *llm_start_session_on(llm_model *m, const llm_session_config *cfg, int slot) {
     if (slot < 0 || !m->stages.empty() || slot == m->device) return llm_start_session(m, cfg);
+    // a sibling slot reads the model's ONE copy of the weights: it must drive the GPU that holds them (checked here, before any
+    // K/V memory is allocated on the wrong one; the backend would only notice at the first evaluation)
+    if (ggml_hip_slot_physical_device(slot) < 0 || ggml_hip_slot_physical_device(slot) != ggml_hip_slot_physical_device(m->device)) {
+        fprintf(stderr, "llm_start_session_on: slot %d does not drive the GPU of the model's slot %d\n", slot, m->device);
+        return nullptr;
+    }
     llm::InferenceSessionConfig c;
     if (cfg) {
         c.memory_k_type = (ggml_type)cfg->memory_k_type;

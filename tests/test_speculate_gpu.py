@@ -132,3 +132,37 @@ def test_speculation_on_the_k_plan(G):
     assert np0 == np1
     for (ta, la), (tb, lb) in zip(ref, got):
         assert ta == tb and np.array_equal(la, lb)
+
+
+def test_device_side_readers_see_the_evaluated_token_not_the_speculated_one(G):
+    """the speculative run used to write its logits / embedding row into the graph's device mirrors, so a top-k
+    prefilter (llm_session_topk) or a node read on the device, queued behind it, returned the NEXT token's values.  It writes
+    plan-private alternates now (DecodePlan::logits_alt): after every token — hit or miss — the device-side top-k and the logits
+    node read on the device equal the host logits the evaluation returned."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(HP, 2, seed=43)
+    model = llama.Llama(hp, w, context_size=128)
+    toks = np.random.default_rng(7).integers(0, hp["n_vocab"], 12).astype(np.int32)
+    try:
+        G.set_option("speculate_next", 1)
+        h0, m0 = _stat(G, "spec_hits"), _stat(G, "spec_misses")
+        s = model.start_session(n_batch=8)
+        s.set_speculate(False)
+        s.feed_prompt(toks)
+        forced = {4: 17, 9: 3}  # two misses among the greedy tokens
+        for i in range(14):
+            if i in forced:
+                lg = s.evaluate(np.array([forced[i]], np.int32))[-1].copy()
+            else:
+                s.infer_next_token()
+                lg = s.last_logits()
+            vals, ids = s.top_k(5)
+            order = np.lexsort((np.arange(lg.size), -lg))[:5]  # best first, lower id first on ties
+            assert np.array_equal(ids, order.astype(np.int32)) and np.array_equal(vals, lg[order]), i
+            dev = s.read_node(index=s.graph_stats()[0] - 1)  # the logits node (the graph's last), read on the device
+            assert np.array_equal(dev[-lg.size:], lg), i
+        assert _stat(G, "spec_hits") - h0 >= 3 and _stat(G, "spec_misses") - m0 >= 1  # (a miss stops the guessing for 8 tokens)
+        s.free()
+    finally:
+        G.set_option("speculate_next", 0)
+        model.free()
