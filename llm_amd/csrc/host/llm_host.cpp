@@ -12,6 +12,7 @@
 #endif
 #include "llm_host.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <fcntl.h>
@@ -70,6 +71,9 @@ struct InferenceSessionConfig {
 struct OutputRequest {
     std::vector<float> *all_logits = nullptr;
     std::vector<float> *embeddings = nullptr;
+    // extension (no reference counterpart): the caller samples from a device-side top-k (llm_session_topk) — the logits node stays
+    // in HBM like every other node and last_logits is NOT refreshed: 40 pairs cross the bus instead of n_vocab floats
+    bool logits_on_device = false;
 };
 
 struct GraphOutputs {  // inference_session.rs:31-37
@@ -506,11 +510,11 @@ class Llama {
 
         InferenceSession *sp = &session;
         GraphOutputs outputs = session.compute(
-            input_tokens, make_builder(sp, input_len, session_len, input_len > 1 && !output_request.all_logits),
+            input_tokens, make_builder(sp, input_len, session_len, (input_len > 1 && !output_request.all_logits) || output_request.logits_on_device),
             [this, sp](size_t next_len) { return make_builder(sp, 1, next_len); }, this, ctx_size);
         if (!is_last()) return;
         // finish evaluation (:364-367)
-        common::read_last_token(session, outputs.result, n_vocab, input_len);
+        if (!output_request.logits_on_device) common::read_last_token(session, outputs.result, n_vocab, input_len);
         common::extract_logits(output_request, outputs.result, n_vocab, input_len);
         common::extract_embeddings(output_request, outputs.embedding_result, n_embd, input_len);
     }
@@ -1102,6 +1106,71 @@ int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s) {
     model_evaluate(m, s, std::vector<llm::TokenId>{next}, req);
     llm::InferenceSession::host_ns_add(5, t1 - t0);                                // argmax
     llm::InferenceSession::host_ns_add(6, llm::InferenceSession::now_ns() - t1);  // evaluate, all of it
+    return next;
+}
+// The reference's token step with the SHAPE of its default sampler (crates/llm-base/src/samplers.rs:97-188: repetition penalty
+// 1.30 over the last 64 tokens, top-k 40, [tail-free, typical, top-p: act on the <= 40 survivors], temperature 0.80) instead of
+// greedy argmax: what a caller that samples gets from the unchanged sequence sample -> evaluate (inference_session.rs:381-424).
+//   device_topk = 0: as the reference does it — all n_vocab logits are read back by the evaluation (model/common.rs:6-19), the
+//                    candidates are found on the host (std::partial_sort);
+//   device_topk = 1: the evaluation leaves the logits in HBM (OutputRequest::logits_on_device) and the k best + the raw logits of
+//                    the penalty window come from llm_session_topk: k + 64 pairs instead of 128 KB per token.
+// Same candidates, same arithmetic, same generator: both settings draw the same tokens (tests/test_device_tools_gpu.py).
+// `rng`: the caller's xorshift64* state.  Not llm-samplers' chain itself — a measurement of what the read-back costs a sampler.
+int32_t llm_infer_next_token_topk(llm_model *m, llm_session *s, int k, float temperature, uint64_t *rng, int device_topk) {
+    if (s->s->n_past + 1 >= m->llama->params.context_size) {
+        fprintf(stderr, "llm_infer_next_token_topk: InferenceError::ContextFull\n");
+        abort();
+    }
+    const size_t V = s->s->last_logits.size();
+    if (k < 1 || (size_t)k > V || !rng) return -1;
+    const std::vector<llm::TokenId> &hist = s->s->tokens;
+    std::vector<int32_t> window;  // the last 64 tokens, each once
+    for (size_t i = hist.size() > 64 ? hist.size() - 64 : 0; i < hist.size(); i++)
+        if (std::find(window.begin(), window.end(), (int32_t)hist[i]) == window.end()) window.push_back((int32_t)hist[i]);
+    std::vector<float> vals(k + window.size());
+    std::vector<int32_t> ids(k + window.size());
+    if (device_topk) {
+        if (llm_session_topk(s, k, window.empty() ? nullptr : window.data(), (int)window.size(), vals.data(), ids.data()) != 0) return -1;
+    } else {
+        const std::vector<float> &l = s->s->last_logits;
+        std::vector<int32_t> order(V);
+        for (size_t i = 0; i < V; i++) order[i] = (int32_t)i;
+        std::partial_sort(order.begin(), order.begin() + k, order.end(),
+                          [&](int32_t a, int32_t b) { return l[a] > l[b] || (l[a] == l[b] && a < b); });
+        for (int i = 0; i < k; i++) { ids[i] = order[i]; vals[i] = l[order[i]]; }
+        for (size_t i = 0; i < window.size(); i++) { ids[k + i] = window[i]; vals[k + i] = l[window[i]]; }
+    }
+    // candidates = top-k and the window's tokens (each once), penalised, the k best of them kept
+    struct Cand { float v; int32_t id; };
+    std::vector<Cand> c;
+    for (size_t i = 0; i < ids.size(); i++) {
+        bool dup = false;
+        for (auto &x : c) dup = dup || x.id == ids[i];
+        if (dup) continue;
+        float v = vals[i];
+        if (std::find(window.begin(), window.end(), ids[i]) != window.end()) v = v > 0.0f ? v / 1.30f : v * 1.30f;
+        c.push_back({v, ids[i]});
+    }
+    std::sort(c.begin(), c.end(), [](const Cand &a, const Cand &b) { return a.v > b.v || (a.v == b.v && a.id < b.id); });
+    if (c.size() > (size_t)k) c.resize(k);
+    double sum = 0.0;
+    std::vector<double> pr(c.size());
+    for (size_t i = 0; i < c.size(); i++) sum += (pr[i] = std::exp((double)(c[i].v - c[0].v) / (double)temperature));
+    uint64_t x = *rng;  // xorshift64*
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    *rng = x;
+    const double u = (double)((x * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0 * sum;
+    double acc = 0.0;
+    llm::TokenId next = (llm::TokenId)c.back().id;
+    for (size_t i = 0; i < c.size(); i++) {
+        acc += pr[i];
+        if (u < acc) { next = (llm::TokenId)c[i].id; break; }
+    }
+    s->s->tokens.push_back(next);
+    llm::OutputRequest req;
+    req.logits_on_device = device_topk != 0;
+    model_evaluate(m, s, std::vector<llm::TokenId>{next}, req);
     return next;
 }
 // n greedy tokens with the sampler on the device (ggml_hip_decode_greedy_chain): the same ids and the

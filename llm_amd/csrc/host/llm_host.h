@@ -99,6 +99,10 @@ GGML_API void llm_evaluate(llm_model *m, llm_session *s, const int32_t *tokens, 
 GGML_API void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *tokens, int n);
 /* InferenceSession::infer_next_token with a greedy (argmax) sampler; returns the sampled token id */
 GGML_API int32_t llm_infer_next_token_greedy(llm_model *m, llm_session *s);
+/* The same step with the shape of the reference's DEFAULT sampler (samplers.rs:97-188: repetition penalty over the last 64 tokens,
+ * top-k, temperature) instead of argmax; device_topk = 1 leaves the logits in HBM and reads k + 64 pairs (llm_session_topk),
+ * 0 reads all n_vocab logits back as the reference does.  Both draw the same tokens from the same xorshift64* state. */
+GGML_API int32_t llm_infer_next_token_topk(llm_model *m, llm_session *s, int k, float temperature, uint64_t *rng, int device_topk);
 /* InferenceSession::rewind (inference_session.rs:352-378) */
 /* n greedy tokens with the argmax on the device (ggml_hip_decode_greedy_chain): same ids and final logits as n calls
  * of llm_infer_next_token_greedy, no per-token logits read-back; falls back to that loop when chaining is impossible */

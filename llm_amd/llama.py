@@ -65,6 +65,8 @@ def _lib():
         L.llm_feed_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.llm_infer_next_token_greedy.restype = C.c_int32
         L.llm_infer_next_token_greedy.argtypes = [C.c_void_p, C.c_void_p]
+        L.llm_infer_next_token_topk.restype = C.c_int32
+        L.llm_infer_next_token_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_uint64), C.c_int]
         L.llm_session_snapshot.restype = C.c_size_t
         L.llm_session_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.llm_session_from_snapshot.restype = C.c_void_p
@@ -256,6 +258,10 @@ class Session:
 
     def infer_next_token(self):
         return int(_lib().llm_infer_next_token_greedy(self.model.ptr, self.ptr))
+
+    def infer_next_token_topk(self, rng, k=40, temperature=0.8, device_topk=True):
+        """One token step with the shape of the reference's default sampler (llm_infer_next_token_topk); rng: ctypes c_uint64 state."""
+        return int(_lib().llm_infer_next_token_topk(self.model.ptr, self.ptr, k, temperature, C.byref(rng), 1 if device_topk else 0))
 
     def snapshot(self):
         """InferenceSession::get_snapshot as bytes (npast, config, tokens, last_logits, memory_k, memory_v)."""

@@ -138,3 +138,28 @@ def test_session_topk_gives_the_head_of_the_logits(G, O):
         assert np.array_equal(vals[40:], logits[toks[:hi][-4:]])
     sess.free()
     model.free()
+
+
+def test_sampled_token_step_draws_the_same_tokens_from_device_topk_and_from_all_logits(G):
+    """llm_infer_next_token_topk: the reference's token step with its default sampler's shape (samplers.rs:97-188) — candidates from
+    all n_vocab logits on the host (what model/common.rs:6-19 reads back) or from the device's top-k + the penalty window
+    (llm_session_topk, the logits never leave HBM): same candidates, same generator, same tokens."""
+    import ctypes
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=4, n_layer=2, n_rot=64, n_ff=704, n_mult=32), 2, seed=77)
+    model = llama.Llama(hp, w, context_size=128)
+    toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 11).astype(np.int32)
+    drawn = []
+    try:
+        for dev in (False, True):
+            s = model.start_session(n_batch=8)
+            s.set_speculate(False)
+            s.feed_prompt(toks)
+            rng = ctypes.c_uint64(0x1234567887654321)
+            drawn.append([s.infer_next_token_topk(rng, 40, 0.8, dev) for _ in range(40)])
+            assert s.n_past == 11 + 40
+            s.free()
+    finally:
+        model.free()
+    assert drawn[0] == drawn[1]
+    assert len(set(drawn[0])) > 5  # (it does sample: not one token forever)
