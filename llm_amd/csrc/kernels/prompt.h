@@ -34,89 +34,86 @@ __device__ __forceinline__ void p_requant4(const f32x4 v, int64_t i4, bool valid
 // one 256-thread workgroup per token row.  ADD: xs = (x [+ x2]) + r first (written to xsum: the residual stream of the
 // layer; x2 = the second partial of a K-split GEMM, only with ADD).
 // E % 32 == 0 (a block never straddles two rows of threads).
+// Round 6: ONE pass over HBM.  The row (E <= 8192: 8 x f32x4 per thread) is loaded with 16-byte loads into registers, summed with its
+// residual there, and stays there for the second half; the sum of squares keeps k_rms_norm's order — thread t adds elements
+// t, t + 256, ... in f64 — by reading the row back from an LDS copy in that order (bank-conflict-free), so the result is bit for bit
+// what the two-pass version (4-byte strided loads, then a re-read of the sums through L2: 10.9 us for 28 MB at 7B) gave.
+// Dynamic LDS: E floats.
 template <bool F16_D, bool ADD, bool K8 = false>
 __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ x, const float *__restrict__ x2 /*nullable*/,
                                                       const float *__restrict__ r, float *xsum, const float *__restrict__ w,
                                                       float eps, int E, float *y_f32 /*nullable*/, _Float16 *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];
     __shared__ double s_part[4];
+    constexpr int MAXU = 8;  // rows up to 8192 wide (launcher)
     const int64_t row = blockIdx.x;
-    const float *xr = x + row * E;
-    const float *x2r = x2 ? x2 + row * E : nullptr;  // second partial of a K-split GEMM: x = x + x2 (what the atomics computed)
-    const float *rr = ADD ? r + row * E : nullptr;
-    float *xs = ADD ? xsum + row * E : nullptr;
-    const float *src = ADD ? xs : xr;  // pass 2 re-reads what pass 1 wrote (L2)
-    constexpr int U = 8;  // loads of a chunk are independent: 8 (16 with the residual) in flight per thread
-    // pass 1: thread t sums elements t, t + 256, ... in ascending order, like k_rms_norm (f64 accumulation)
-    double s = 0.0;
-    for (int i0 = threadIdx.x; i0 < E; i0 += 256 * U) {
-        float v[U];
+    const int tid = threadIdx.x, E4 = E >> 2;
+    const f32x4 *xr = (const f32x4 *)(x + row * E);
+    const f32x4 *x2r = x2 ? (const f32x4 *)(x2 + row * E) : nullptr;  // second partial of a K-split GEMM: x = x + x2 (what the atomics computed)
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 v[MAXU];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * 256;
-            v[u] = i < E ? xr[i] : 0.0f;
-        }
-        if constexpr (ADD) {
-            float t[U];
-            if (x2r) {  // uniform
+    for (int u = 0; u < MAXU; u++) {
+        const int j = u * 256 + tid;
+        v[u] = j < E4 ? xr[j] : zero4;
+    }
+    if constexpr (ADD) {
+        const f32x4 *rr = (const f32x4 *)(r + row * E);
+        f32x4 t[MAXU];
+        if (x2r) {  // uniform
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int i = i0 + u * 256;
-                    t[u] = i < E ? x2r[i] : 0.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) v[u] = v[u] + t[u];
+            for (int u = 0; u < MAXU; u++) {
+                const int j = u * 256 + tid;
+                t[u] = j < E4 ? x2r[j] : zero4;
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = i0 + u * 256;
-                t[u] = i < E ? rr[i] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) v[u] = v[u] + t[u];
+            for (int u = 0; u < MAXU; u++) v[u] = v[u] + t[u];
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * 256;
-            if (i < E) {
-                if constexpr (ADD) xs[i] = v[u];
-                s += (double)(v[u] * v[u]);
-            }
+        for (int u = 0; u < MAXU; u++) {
+            const int j = u * 256 + tid;
+            t[u] = j < E4 ? rr[j] : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXU; u++) v[u] = v[u] + t[u];
+        f32x4 *xs = (f32x4 *)(xsum + row * E);
+#pragma unroll
+        for (int u = 0; u < MAXU; u++) {
+            const int j = u * 256 + tid;
+            if (j < E4) xs[j] = v[u];  // the residual stream of the layer
         }
     }
+#pragma unroll
+    for (int u = 0; u < MAXU; u++) {
+        const int j = u * 256 + tid;
+        if (j < E4) ((f32x4 *)s_row)[j] = v[u];
+    }
+    __syncthreads();
+    double s = 0.0;
+    for (int i = tid; i < E; i += 256) s += (double)(s_row[i] * s_row[i]);  // thread t: elements t, t + 256, ... ascending (k_rms_norm)
     s = wave_sum_f64(s);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    if ((tid & 63) == 0) s_part[tid >> 6] = s;
     __syncthreads();
     const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
     const float mean = (float)(tot / (double)E);
     const float scale = 1.0f / sqrtf(mean + eps);
-    // pass 2 is element-wise apart from the block maximum (order-free): four consecutive values per lane, a block = 8 lanes,
-    // so the maximum needs three DPP steps instead of an LDS round trip per value (16 dependent ds_bpermute per thread
-    // made this kernel 13 us for 28 MB).  The values of pass 1 come back from L2 (written by other threads of this
-    // workgroup before the barrier above).
+    // element-wise apart from the block maximum (order-free): four consecutive values per lane, a block = 8 lanes, so the maximum
+    // needs three DPP steps instead of an LDS round trip per value
     _Float16 *orow = out + row * E;
-    const int E4 = E >> 2;
-    for (int j0 = 0; j0 < E4; j0 += 256 * 2) {  // uniform trip count: whole 8-lane groups take part in the reduction
-        f32x4 v[2], ww[2];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int j = j0 + u * 256 + threadIdx.x;
-            v[u] = j < E4 ? ((const f32x4 *)src)[j] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            ww[u] = j < E4 ? ((const f32x4 *)w)[j] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int u = 0; u < MAXU; u++) {
+        if (u * 256 >= E4) break;  // uniform: whole 8-lane groups take part in the reduction
+        const int j = u * 256 + tid;
+        const f32x4 ww = j < E4 ? ((const f32x4 *)w)[j] : zero4;
+        f32x4 y;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float t = v[u][k] * scale;
+            t = t * ww[k];
+            y[k] = t;
         }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int j = j0 + u * 256 + threadIdx.x;
-            if (j0 + u * 256 >= E4) break;  // uniform
-            f32x4 y;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float t = v[u][k] * scale;
-                t = t * ww[u][k];
-                y[k] = t;
-            }
-            if (y_f32 && j < E4) ((f32x4 *)(y_f32 + row * E))[j] = y;
-            p_requant4<F16_D, K8>(y, j, j < E4, orow);
-        }
+        if (y_f32 && j < E4) ((f32x4 *)(y_f32 + row * E))[j] = y;
+        p_requant4<F16_D, K8>(y, j, j < E4, orow);
     }
 }
 
