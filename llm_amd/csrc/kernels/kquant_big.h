@@ -41,6 +41,7 @@ struct KBigArgs {
     // one {epoch, f16 x 2} granule (index = the pair's index over wq|wk|wv), exactly as k_mmvq_big does inside k_qkv_attn
     unsigned long long *gran;
     const unsigned *epoch;
+    const void *hot;  // 256 bytes the dummy ring steps read (BigArgs::hot, decode_big.h); nullptr = the first bytes of the scales
 };
 
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -105,7 +106,7 @@ __device__ __forceinline__ float kbig_chunk(const KStep<KT> &cur, const int c, c
         const int n2 = c >> 2, o = 16 * (c & 3);
         const uint32_t wa = n2 ? cur.sc[2] : cur.sc[0], wb = n2 ? cur.sc[3] : cur.sc[1];
         const int sc_a = (int)(int8_t)((wa >> (8 * (c & 3))) & 0xFF), sc_b = (int)(int8_t)((wb >> (8 * (c & 3))) & 0xFF);
-        const float d = __half2float(__ushort_as_half((unsigned short)cur.dm));
+        const float d = __half2float(__ushort_as_half((unsigned short)(cur.dm >> ((sb & 1) * 16))));  // (the word holds super-blocks 2i, 2i + 1)
         u32x4 lo, hi;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -255,24 +256,34 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
             l_d = w.d + g0 * (KT == KT_Q4_K ? 2 : 1);
         }
     };
-    auto load = [&](RingT &st) {
+    // A step past the wave's last real one is a DUMMY (see k_mmvq_big's `issue`, decode_big.h): every slot of the ring is refilled
+    // unconditionally, so the number of loads in flight is a compile-time constant at every wait.  Round 5's form — refills under
+    // `if (k + PF < S)`, a 16-bit scale load, a store that might be pending (the embedding tap) — compiled to an
+    // s_waitcnt vmcnt(0) in front of EVERY step: a wave never had a second step in flight (tests/tools/disasm.py, round 6).
+    const uint8_t *const hotp = ka.hot ? (const uint8_t *)ka.hot : (const uint8_t *)a.w.sc;
+    auto load = [&](RingT &st, const bool dummy) {
         int sb = ls * SBS + sbl;
-        sb = sb < nsb ? sb : nsb - 1;  // lanes past the row end re-read the last super-block and are masked below
+        sb = dummy ? 0 : sb < nsb ? sb : nsb - 1;  // lanes past the row end re-read the last super-block and are masked below
+        const int cc = dummy ? 0 : c;
+        const uint8_t *p_qs = dummy ? hotp : l_qs, *p_sc = dummy ? hotp : l_sc;
+        const uint32_t *p_aux = dummy ? (const uint32_t *)hotp : l_aux;
+        const __half *p_d = dummy ? (const __half *)hotp : l_d;
         if constexpr (K2) {
-            k2_issue<KT>(st, l_qs, (const uint8_t *)l_aux, l_sc, l_d, sb, c);
+            k2_issue<KT>(st, p_qs, (const uint8_t *)p_aux, p_sc, p_d, sb, cc);
         } else {
-            st.q = __builtin_nontemporal_load((const u32x4 *)(l_qs + sb * 128 + c * 16));
-            st.sc = *(const u32x4 *)(l_sc + sb * 16);
+            st.q = __builtin_nontemporal_load((const u32x4 *)(p_qs + sb * 128 + cc * 16));
+            st.sc = *(const u32x4 *)(p_sc + sb * 16);
             if constexpr (KT == KT_Q4_K) {
-                st.dm = *(const uint32_t *)(l_d + sb * 2);
+                st.dm = *(const uint32_t *)(p_d + sb * 2);
             } else {
-                const u32x2 h = __builtin_nontemporal_load((const u32x2 *)(l_aux + (sb * 8 + c) * 2));
+                const u32x2 h = __builtin_nontemporal_load((const u32x2 *)(p_aux + (sb * 8 + cc) * 2));
                 st.hA = h[0];
                 st.hB = h[1];
-                st.dm = (uint32_t) * (const uint16_t *)(l_d + sb);
+                // the f16 scale as the aligned 32-bit word that holds it (super-blocks 2i, 2i + 1), picked by parity at its use
+                st.dm = *(const uint32_t *)(p_d + (sb & ~1));
             }
         }
-        if (++ls == nsteps) {
+        if (!dummy && ++ls == nsteps) {
             ls = 0;
             if (++li < nhr) set_row(li);
         }
@@ -305,8 +316,7 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
     RingT ring[KBIG_PF];
     if (nhr > 0) set_row(0);
 #pragma unroll
-    for (int k = 0; k < KBIG_PF; k++)
-        if (k < S) load(ring[k]);
+    for (int k = 0; k < KBIG_PF; k++) load(ring[k], k >= S);
 
     // ---- 3. stage x as Q8_K: wave w takes super-blocks w, w + 16, ...; lane l the values 4l .. 4l + 3 of the super-block
     if constexpr (XSRC == KX_Q8K) {
@@ -352,7 +362,9 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
                     float t = v[k] * scale;
                     v[k] = t * xw4[u][k];
                 }
-                if (ka.y_out && bid == 0) ((f32x4 *)ka.y_out)[i4] = v;
+                // (only the lm_head launch has the tap: a store that MAY be pending turns every later wait into vmcnt(0))
+                if constexpr (EPI == KE_ROW)
+                    if (ka.y_out && bid == 0) ((f32x4 *)ka.y_out)[i4] = v;
             } else if constexpr (XSRC == KX_SILU_MUL) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -368,36 +380,42 @@ __device__ __forceinline__ void kbig_body(const KBigArgs &ka, const int bid, con
     // ---- rows
     float acc = 0.0f, myv = 0.0f, myv3 = 0.0f;
     int ri = 0, rs = 0;  // row index of the wave, step inside the row
-    for (int k0 = 0; k0 < S; k0 += KBIG_PF) {
+    auto step = [&](const RingT &st) {
+        const int sb = rs * SBS + sbl;
+        if (sb < nsb) {
+            if constexpr (K2)
+                acc += k2_chunk<KT>(st, c, sb, s_q, s_d, s_b);
+            else
+                acc += kbig_chunk<KT>(st, c, sb, s_q, s_d, s_b);
+        }
+        if (++rs == nsteps) {
+            rs = 0;
+            const float v = wave_sum_f32(acc);
+            if constexpr (PAIR) {
+                if (ri & 1)
+                    myv3 = lane == (ri >> 1) ? v : myv3;
+                else
+                    myv = lane == (ri >> 1) ? v : myv;
+            } else {
+                myv = lane == ri ? v : myv;
+            }
+            acc = 0.0f;
+            ri++;
+        }
+    };
+    // full passes over the ring while a pass still has a step to request (every slot: dots, then its refill, unconditionally),
+    // then a pass that drains the last PF steps and requests nothing: static wait counts throughout (k_mmvq_big, decode_big.h)
+    int k0 = 0;
+    for (; k0 + KBIG_PF < S; k0 += KBIG_PF) {
 #pragma unroll
         for (int u = 0; u < KBIG_PF; u++) {
-            const int k = k0 + u;
-            if (k < S) {  // uniform
-                const int sb = rs * SBS + sbl;
-                if (sb < nsb) {
-                    if constexpr (K2)
-                        acc += k2_chunk<KT>(ring[u], c, sb, s_q, s_d, s_b);
-                    else
-                        acc += kbig_chunk<KT>(ring[u], c, sb, s_q, s_d, s_b);
-                }
-                if (++rs == nsteps) {
-                    rs = 0;
-                    const float v = wave_sum_f32(acc);
-                    if constexpr (PAIR) {
-                        if (ri & 1)
-                            myv3 = lane == (ri >> 1) ? v : myv3;
-                        else
-                            myv = lane == (ri >> 1) ? v : myv;
-                    } else {
-                        myv = lane == ri ? v : myv;
-                    }
-                    acc = 0.0f;
-                    ri++;
-                }
-                if (k + KBIG_PF < S) load(ring[u]);
-            }
+            step(ring[u]);
+            load(ring[u], k0 + u + KBIG_PF >= S);
         }
     }
+#pragma unroll
+    for (int u = 0; u < KBIG_PF; u++)
+        if (k0 + u < S) step(ring[u]);  // uniform
     if constexpr (GATE) {
         if (lane < nrw) a.dst[r_first + r_stride * lane] = silu_table(myv) * myv3;
         return;
