@@ -193,7 +193,12 @@ struct KBigRing<KT_Q5_K> {
 };
 
 #define KBIG_T 1024
-#define KBIG_PF 4  // steps (8 super-blocks of one row) a wave keeps requested ahead
+// steps (8 super-blocks of one row) a wave keeps requested ahead.  With counted waits the depth is real (round 5's 4 was drained in
+// front of every step): LLaMA-7B, -DKBIG_PF builds on one box (gpurun_out/r6/run24), tok/s Q4_K | Q6_K: 2: 678 | 585, 3: 676 | 579,
+// 4: 666 | 517-562, 6: 624 | 518 — the K dots are VALU-bound, two steps in flight per wave x 16 waves keep the stream going
+#ifndef KBIG_PF
+#define KBIG_PF 2
+#endif
 
 // EPI = KE_GATE: the launch computes silu(w1 x) * (w3 x) (a.w = w1, a.wb = w3, same shape and type; dst = the product row): a wave's
 // unit = row m of w1 followed by row m of w3, the epilogue lane of the unit applies ggml's f16-table SiLU and the multiply — the
