@@ -157,7 +157,7 @@ struct BigX<XSRC_NORM> {
 // registers -> LDS as padded planar Q8 (nbp = nbl*64 blocks; blocks >= nb are zero so tail steps contribute 0)
 template <bool F16_D, int XSRC, bool YOUT = false>
 __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &xr, int nb, int nbp, int tid, int T,
-                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part, long long *stp = nullptr) {
+                                            i32x4 *s_lo, i32x4 *s_hi, float *s_d, int *s_sum, double *s_part, f32x4 *y_keep = nullptr) {
     const DecMmvqArgs &d = a.d;
     (void)s_part;
     for (int i = nb + tid; i < nbp; i += T) {
@@ -196,16 +196,10 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
                     ss += (double)(xr.v[it][3] * xr.v[it][3]);
                 }
             }
-#ifdef STAGE_PROBE
-            if (stp) { asm volatile("" ::"v"(ss)); stp[0] = (long long)wall_clock64(); }
-#endif
             ss = wave_sum_f64(ss);
             if ((tid & 63) == 0) s_part[tid >> 6] = ss;
         }
         __syncthreads();
-#ifdef STAGE_PROBE
-        if (stp) stp[1] = (long long)wall_clock64();
-#endif
         {
             double tot = 0.0;
 #pragma unroll
@@ -216,9 +210,6 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
             const bool pow2 = (n_el & (n_el - 1)) == 0;  // uniform
             const float mean = pow2 ? (float)__builtin_ldexp(tot, -(31 - __builtin_clz((unsigned)n_el))) : (float)(tot / (double)n_el);
             const float scale = 1.0f / sqrtf(mean + d.eps);
-#ifdef STAGE_PROBE
-            if (stp) { asm volatile("" ::"v"(scale)); stp[2] = (long long)wall_clock64(); }
-#endif
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
                 const int i4 = it * NT + tid;
@@ -229,10 +220,10 @@ __device__ __forceinline__ void big_stage_x(const BigArgs &a, const BigX<XSRC> &
                     y[1] = (xr.v[it][1] * scale) * xr.w[it][1];
                     y[2] = (xr.v[it][2] * scale) * xr.w[it][2];
                     y[3] = (xr.v[it][3] * scale) * xr.w[it][3];
-                    // (only the lm_head launch has the tap; a store that MAY be pending makes every later wait of the kernel a
-                    // vmcnt(0): gfx9 counts loads and stores in one counter and they return out of order with respect to each other)
-                    if constexpr (YOUT)
-                        if (a.y_out && blockIdx.x == 0) ((f32x4 *)a.y_out)[i4] = y;
+                    // (only the lm_head launch has the tap, and it stores the row at the END of the kernel: a store that MAY be pending
+                    // makes every later wait a vmcnt(0) — gfx9 counts loads and stores in one counter and they return out of order
+                    // with respect to each other)
+                    if constexpr (YOUT) y_keep[it] = y;
                 }
                 quant4_to_lds<F16_D>(y, i4, nb, tid, s_lo, s_hi, s_d, s_sum);
             }
@@ -425,12 +416,8 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
             s_rope[2 * kk + 1] = rope_pre[1];
         }
     }
-#ifdef STAGE_PROBE
-    long long stp[3] = {0, 0, 0};
-    big_stage_x<F16_D, XSRC, EPI == EPI_STORE>(ba, xr, nb, nbp, tid, T, s_lo, s_hi, s_d, s_sum, s_part, ts ? stp : nullptr);
-#else
-    big_stage_x<F16_D, XSRC, EPI == EPI_STORE>(ba, xr, nb, nbp, tid, T, s_lo, s_hi, s_d, s_sum, s_part);
-#endif
+    f32x4 y_keep[XSRC == XSRC_NORM && EPI == EPI_STORE ? BigX<XSRC_NORM>::MAXIT : 1];  // the normed row for the embedding tap (stored in the epilogue)
+    big_stage_x<F16_D, XSRC, XSRC == XSRC_NORM && EPI == EPI_STORE>(ba, xr, nb, nbp, tid, T, s_lo, s_hi, s_d, s_sum, s_part, y_keep);
     const long long t_staged = ts ? big_now() : 0;
     // ---- 2b. the rest of the ring
 #pragma unroll
@@ -543,6 +530,15 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
             }
         }
     }
+    if constexpr (XSRC == XSRC_NORM && EPI == EPI_STORE) {  // the embedding tap: workgroup 0's copy of the normed row
+        if (ba.y_out && bid == 0) {
+#pragma unroll
+            for (int it = 0; it < BigX<XSRC_NORM>::MAXIT; it++) {
+                const int i4 = it * BigX<XSRC_NORM>::NT + tid;
+                if (i4 < nb * 8) ((f32x4 *)ba.y_out)[i4] = y_keep[it];
+            }
+        }
+    }
     if (warm_v == 0x7fc0dead && nb < 0) a.dst[0] = 0.0f;  // (never: keeps the warm-up load alive; its wait falls here, long after it landed)
     if (ts && wave == 0 && lane == 0) {
         const int q = G / ba.ts_wgs;
@@ -550,9 +546,6 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
             long long *o = ts + (bid / q) * 8;
             o[0] = t_entry; o[1] = t_issued; o[2] = t_staged; o[3] = t_barrier; o[4] = t_first; o[5] = big_now();
             o[6] = S | ((long long)(t_dots - t_entry) << 32); o[7] = bid;
-#ifdef STAGE_PROBE
-            if (stp[0]) { o[3] = stp[0]; o[4] = stp[1]; o[6] = S | ((long long)(stp[2] - t_entry) << 32); }  // x landed | partial-sum barrier | scale known
-#endif
         }
     }
 }
