@@ -778,6 +778,7 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
     else if (k == "fuse_attn") {
         if (g.opt_fuse_attn != value) drop_all_plans();
         g.opt_fuse_attn = value;
+        g.fused_rearm_at = 0;  // an explicit choice outlives a pending re-arm
     }
     else if (k == "speculate_next") {  // 1 = run the greedy next token speculatively behind every single-token plan run (llama_plan.inc)
         spec_cancel();
@@ -806,6 +807,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
     else if (k == "big") {
         if (g.opt_big != value) drop_all_plans();
         g.opt_big = value;
+    }
+    else if (k == "fused_rearm_tokens") {  // clean tokens on the two-launch forms after which the fused forms are taken back (0 = never)
+        g.opt_fused_rearm_tokens = value;
+        g.fused_rearm_stretch = 0;
     }
     else if (k == "fused_fallback")  // 1 = a token whose in-launch hand-off gave up is re-run on the two-launch forms; 0 = abort
         g.opt_fused_fallback = value;

@@ -85,3 +85,41 @@ def test_with_the_fallback_off_the_compute_call_aborts_with_a_message():
     assert "BEFORE" in r.stdout and "SURVIVED" not in r.stdout
     assert r.returncode != 0
     assert "gave up waiting for rows of its own launch" in r.stderr
+
+
+def test_the_fused_forms_come_back_after_a_clean_stretch(G):
+    """one give-up used to leave the slot on the two-launch forms for the rest of its life.  After
+    fused_rearm_tokens clean tokens (256 by default, 6 here) the fused launch is taken again — and the tokens stay what the
+    two-launch pair gives."""
+    from llm_amd import llama, synth
+    hp, w = synth.make_llama(HP, 2, seed=78)
+    model = llama.Llama(hp, w, context_size=96)
+    toks = np.random.default_rng(5).integers(0, hp["n_vocab"], 11).astype(np.int32)
+    try:
+        G.set_option("fuse_attn", 0)
+        ref, _, _ = _run(G, model, toks, 24)
+        G.set_option("fuse_attn", 2)
+        G.set_option("fused_rearm_tokens", 6)
+        r0, t0 = _stat(G, "fused_rearms"), _stat(G, "fused_attn_timeouts")
+        G.set_option("test_fused_timeout", 1)
+        s = model.start_session(n_batch=8)
+        s.feed_prompt(toks)
+        got, fused_after = [], []
+        for i in range(24):
+            f0 = _stat(G, "fused_attn_tokens")
+            t = s.infer_next_token()
+            got.append((t, s.last_logits()))
+            fused_after.append(_stat(G, "fused_attn_tokens") - f0)
+        s.free()
+        assert _stat(G, "fused_attn_timeouts") - t0 == 1  # the first token's hand-off gave up once (the fallback switches the hook off)
+        assert _stat(G, "fused_rearms") - r0 == 1
+        assert sum(fused_after[1:7]) == 0 and sum(fused_after[10:]) >= 10  # two-launch forms for the stretch, fused again behind it
+    finally:
+        G.set_option("fused_rearm_tokens", 256)
+        G.set_option("test_fused_timeout", 1)
+        G.set_option("test_fused_timeout", 0)
+        G.set_option("fuse_attn", 1)
+        G.set_option("attn_one", 1)
+        model.free()
+    for (ta, la), (tb, lb) in zip(ref, got):
+        assert ta == tb and np.array_equal(la, lb)
