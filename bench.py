@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="stop the decode run behind the timed steps + roofline replays: no call-sequence, device-sampling or long-context legs (the PMC passes: every dispatch then runs at the context the roofline bytes are stated for)")
     ap.add_argument("--split", type=int, default=2, help="--mode split: device slots ONE session is layer-split over (one process)")
     ap.add_argument("--sessions", default="1,2,4", help="--mode sessions: session counts to run, comma-separated")
+    ap.add_argument("--sessions-unchanged-caller", action="store_true",
+                    help="--mode sessions: every thread only calls start_session() / infer; slots are assigned by the backend under GGML_HIP_SESSION_SLOTS")
     ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "feed", "split", "sessions"],
                     help="decode = BASELINE configs[1] (the metric); prefill = configs[2], 512-token prompt batch on MFMA; "
                          "feed = InferenceSession::feed_prompt in chunks of --n-batch (profiling leg)")
@@ -906,6 +908,66 @@ def run_split(args):
         raise SystemExit("bench.py --mode split: the split session produced different tokens")
 
 
+def run_sessions_unchanged(args, counts):
+    """The same measurement for a caller that CHANGES NOTHING: every thread calls model.start_session() and infer — no slot argument,
+    no bind call (crates/llm-base/src/inference_session.rs:43-48) — and the one opt-in is the environment variable
+    GGML_HIP_SESSION_SLOTS=n, under which the backend assigns a thread its own sibling slot of the GPU when it creates its first
+    K/V memory (include/ggml_hip.h ggml_hip_thread_session_slot)."""
+    import threading
+    os.environ["GGML_HIP_SESSION_SLOTS"] = str(max(counts))
+    from llm_amd import ggml
+    L = ggml.lib()
+    hp, w, model, prep = build_model(args)
+    prompt = np.random.default_rng(42).integers(0, hp["n_vocab"], args.prompt).astype(np.int32)
+    runs = []
+    for n in counts:
+        ready, start = threading.Barrier(n + 1), threading.Barrier(n + 1)
+        lat, ids, slots = [None] * n, [None] * n, [None] * n
+
+        def run(i):
+            s = model.start_session(n_batch=8)
+            slots[i] = int(L.ggml_hip_thread_session_slot())
+            s.feed_prompt(prompt)
+            for _ in range(args.warmup):
+                s.infer_next_token()
+            L.ggml_hip_synchronize()
+            ready.wait()
+            start.wait()
+            t0 = time.perf_counter()
+            ids[i] = [s.infer_next_token() for _ in range(args.steps)]
+            lat[i] = (time.perf_counter() - t0) / args.steps
+            s.free()
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+        for t in th:
+            t.start()
+        ready.wait()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        timeouts = int(L.ggml_hip_get_stat(b"fused_attn_timeouts"))
+        runs.append({"sessions": n, "aggregate_tokens_per_s": round(n * args.steps / el, 1),
+                     "per_session_ms_per_token": [round(x * 1e3, 4) for x in lat], "slot_of_each_thread": slots,
+                     "all_sessions_same_ids": all(x == ids[0] for x in ids), "fused_attn_timeouts": timeouts})
+        if not runs[-1]["all_sessions_same_ids"]:
+            print(json.dumps(runs[-1]), flush=True)
+            raise SystemExit("bench.py --mode sessions: a session diverged")
+    one = runs[0]["aggregate_tokens_per_s"] if runs[0]["sessions"] == 1 else None
+    for r in runs:
+        r["vs_one_session"] = round(r["aggregate_tokens_per_s"] / one, 3) if one else None
+    best = runs[-1]
+    print(json.dumps({"metric": f"aggregate decode tokens/s LLaMA-{args.model.upper()} {args.wtype.upper()}, {best['sessions']} concurrent sessions of one model on one GPU",
+                      "value": best["aggregate_tokens_per_s"], "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(1e3 / best["aggregate_tokens_per_s"], 4), "higher_is_better": True, "scaling": "weak",
+                      "data": "synthetic", "runs": runs,
+                      "config": {"workload": f"LLaMA-{args.model.upper()} {args.wtype.upper()} greedy decode, {args.prompt}-token prompt per session, ctx 2048, "
+                                             "one thread per session, each thread only calls start_session() / infer (no extension call); "
+                                             f"GGML_HIP_SESSION_SLOTS={max(counts)} in the environment; one resident copy of the weights"}}), flush=True)
+    model.free()
+
+
 def run_sessions(args):
     """Several InferenceSessions of ONE model decoding concurrently on one GPU, one thread each (the reference's contract:
     crates/llm-base/src/inference_session.rs:43-48, model/mod.rs:275-276).  Every session lives on its own device slot of the
@@ -913,6 +975,8 @@ def run_sessions(args):
     weights; value = aggregate tokens/s of the largest session count, next to one session alone in the same process."""
     import threading
     counts = sorted({max(1, int(c)) for c in args.sessions.split(",")})
+    if args.sessions_unchanged_caller:
+        return run_sessions_unchanged(args, counts)
     os.environ["GGML_HIP_VIRTUAL_DEVICES"] = str(max(counts))
     from llm_amd import ggml
     L = ggml.lib()

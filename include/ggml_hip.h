@@ -455,6 +455,11 @@ GGML_API bool ggml_cuda_compute_forward(struct ggml_compute_params *params, stru
 GGML_API int ggml_hip_device_count(void);
 /* The physical GPU a device slot drives (slot s -> (GGML_HIP_DEVICE + s) mod visible GPUs), -1 for a slot that does not exist. */
 GGML_API int ggml_hip_slot_physical_device(int slot);
+/* GGML_HIP_SESSION_SLOTS=n (opt-in): the first K/V memory a thread creates (ggml_hip_assign_buffers_no_scratch, i.e.
+ * InferenceSession::new) assigns the thread one of the n sibling slots of the GPU and pins it there, so that sessions started on
+ * several threads by an UNCHANGED caller (model.start_session() / infer()) overlap instead of sharing one slot's stream and lock.
+ * Returns the calling thread's assignment, -1 before it has one. */
+GGML_API int ggml_hip_thread_session_slot(void);
 /* Several devices in one process (the ggml-style layer split of one InferenceSession).  A device
  * "slot" owns a stream, the device shadows of the host arenas, the weights uploaded while it was current and its plan cache;
  * ggml_hip_set_main_device (cuda.rs:62) makes a slot current for every following call.  GGML_HIP_VIRTUAL_DEVICES=n maps n

@@ -238,8 +238,33 @@ void ggml_hip_set_main_device(int main_device) {
     if (main_device < 0 || main_device >= std::max(1, slot_count()))
         die("ggml_hip_set_main_device(%d): %d device slot(s) available", main_device, slot_count());
     g_default_slot.store(main_device, std::memory_order_relaxed);
+    // a thread whose sessions were assigned a sibling slot of this GPU (GGML_HIP_SESSION_SLOTS) keeps it: the reference repeats
+    // set_main_device(0) in every InferenceSession::new
+    if (tl_auto_slot >= 0 && slot_physical_device(tl_auto_slot) == slot_physical_device(main_device)) {
+        ggml_hip_bind_thread_device(tl_auto_slot);
+        return;
+    }
     ggml_hip_bind_thread_device(main_device);
 }
+// see backend_state.inc (GGML_HIP_SESSION_SLOTS); called in front of the first K/V memory a thread creates
+static void auto_session_slot() {
+    const int n = std::min(session_slots_env(), slot_count());
+    if (n <= 1 || tl_auto_slot >= 0) return;
+    if (!tl_pinned) g_cur = &g_backends[g_default_slot.load(std::memory_order_relaxed)];
+    const int cur = (int)(g_cur - g_backends), phys = slot_physical_device(cur);
+    int best = cur;
+    {
+        std::lock_guard<std::recursive_mutex> lk(g_mu);
+        for (int i = 0; i < n; i++)
+            if (slot_physical_device(i) == phys && g_session_threads[i] < g_session_threads[best]) best = i;
+        g_session_threads[best]++;
+        tl_auto_slot = best;
+        (void)&tl_auto_release;  // (instantiates the thread's release object)
+    }
+    if (best != cur) ggml_hip_bind_thread_device(best);
+    else tl_pinned = true, g_cur = &g_backends[cur];
+}
+int ggml_hip_thread_session_slot(void) { return tl_auto_slot; }
 void ggml_hip_bind_thread_device(int device) {
     // the calling thread's slot only: sessions of one process driven from several threads bind their own model's slot
     if (device < 0 || device >= std::max(1, slot_count()))
@@ -468,6 +493,7 @@ void ggml_hip_assign_buffers(struct ggml_tensor *tensor) {
 }
 void ggml_hip_assign_buffers_force_inplace(struct ggml_tensor *tensor) { tensor->backend = GGML_BACKEND_GPU; }
 void ggml_hip_assign_buffers_no_scratch(struct ggml_tensor *tensor) {
+    if (tensor->op == GGML_OP_NONE && !tensor->extra) auto_session_slot();  // K/V memory of a new session (inference_session.rs:996-1021)
     SlotLock lk;
     tensor->backend = GGML_BACKEND_GPU;
     if (tensor->op != GGML_OP_NONE || extra_of(tensor)) return;

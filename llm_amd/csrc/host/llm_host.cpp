@@ -957,6 +957,12 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
     HomeDevice hd;
     hd.go(m->device);
     s->device = m->device;
+    struct AfterNew {  // GGML_HIP_SESSION_SLOTS: the backend may have assigned this thread a sibling slot while the K/V memory was created
+        llm_session *s;
+        ~AfterNew() {
+            if (s->s && ggml_hip_thread_session_slot() >= 0) s->device = ggml_hip_thread_session_slot();
+        }
+    } after_new{s};
     s->s = m->llama->start_session(c);
     return s;
 }

@@ -214,6 +214,7 @@ for _k, _v in _HOOKS.items():
 PROTOTYPES.update({
     "ggml_hip_device_count": (C.c_int, []),
     "ggml_hip_slot_physical_device": (C.c_int, [C.c_int]),
+    "ggml_hip_thread_session_slot": (C.c_int, []),
     "ggml_hip_synchronize": (None, []),
     "ggml_hip_tensor_get": (None, [TP, C.c_void_p, C.c_size_t, C.c_size_t]),
     "ggml_hip_tensor_set": (None, [TP, C.c_void_p, C.c_size_t, C.c_size_t]),

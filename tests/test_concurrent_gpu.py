@@ -167,3 +167,41 @@ def test_bind_thread_device_is_per_thread(G):
     finally:
         L.ggml_hip_set_main_device(0)
         os.environ.pop("GGML_HIP_VIRTUAL_DEVICES", None)
+
+
+def test_unchanged_callers_on_two_threads_get_a_slot_each():
+    """GGML_HIP_SESSION_SLOTS=2 (opt-in, environment only): two threads that only call start_session() / infer — the reference's
+    contract, inference_session.rs:43-48 — are assigned different sibling slots of the GPU when they create their K/V memory, decode
+    concurrently and produce the tokens a single session produces.  (Child process: the variable is read when the library starts.)"""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, threading
+        import numpy as np
+        sys.path.insert(0, %r)
+        from llm_amd import ggml as G, llama, synth
+        hp, w = synth.make_llama(dict(n_vocab=256, n_embd=512, n_head=8, n_head_kv=8, n_layer=3, n_rot=64, n_ff=704, n_mult=32), 2, seed=5)
+        model = llama.Llama(hp, w, context_size=96)
+        toks = np.random.default_rng(1).integers(0, 256, 9).astype(np.int32)
+        s0 = model.start_session(n_batch=8); s0.feed_prompt(toks); want = [s0.infer_next_token() for _ in range(20)]; s0.free()
+        out, slots, bar = [None, None], [None, None], threading.Barrier(2)
+        def run(i):
+            s = model.start_session(n_batch=8)
+            slots[i] = G.lib().ggml_hip_thread_session_slot()
+            bar.wait()  # both sessions alive at once
+            s.feed_prompt(toks)
+            out[i] = [s.infer_next_token() for _ in range(20)]
+            bar.wait()
+            s.free()
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert sorted(slots) == [0, 1], slots
+        assert out[0] == want and out[1] == want, (out, want)
+        print("OK", slots)
+    """ % root)
+    env = dict(os.environ, GGML_HIP_SESSION_SLOTS="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
