@@ -834,6 +834,9 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_big != value) drop_all_plans();
         g.opt_big = value;
     }
+    else if (k == "serial_stage_slots") {  // how many of this device's session slots are stages of ONE split session (see device_sharers)
+        if (g_dev_serial_stages[g.device & 63].exchange(value) != value) g_dev_gen[g.device & 63].fetch_add(1);  // captured graphs froze a choice of kernels
+    }
     else if (k == "fused_rearm_tokens") {  // clean tokens on the two-launch forms after which the fused forms are taken back (0 = never)
         g.opt_fused_rearm_tokens = value;
         g.fused_rearm_stretch = 0;

@@ -552,6 +552,7 @@ struct llm_session {
 };
 
 namespace {
+std::atomic<int> g_split_sessions{0};  // live sessions of layer-split models (see llm_start_session)
 // Model::evaluate for both kinds of model
 // Every entry point leaves the caller's main device as it found it: an unsplit model runs on the slot it was loaded on
 // (llm_model::device), a split one walks its stages' slots.
@@ -950,6 +951,9 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
             s->stage_sessions.push_back(m->stages[i]->start_session(c));
         }
         ggml_hip_bind_thread_device(home);
+        // the stages of ONE split session run one after the other: on a GPU that hosts several of them (virtual slots) they are one
+        // sharer of its compute units, not G (include/ggml_hip.h "serial_stage_slots"); with a second split session alive they are not
+        ggml_hip_set_option("serial_stage_slots", g_split_sessions.fetch_add(1) == 0 ? (int)m->stages.size() : 0);
         s->s = s->stage_sessions.back();
         s->devices = m->devices;
         return s;
@@ -1020,6 +1024,8 @@ void llm_session_free(llm_session *s) {
         }
         ggml_hip_bind_thread_device(home);
         s->s = nullptr;
+        g_split_sessions.fetch_sub(1);
+        ggml_hip_set_option("serial_stage_slots", 0);
     }
     if (s->s) {
         HomeDevice hd;
