@@ -645,18 +645,20 @@ def run_single(args):
         v["frac"] = round(v["GBps"] / HBM_PEAK_GBS, 4)
     achieved = dom["GBps"]
     wb, nparams = weight_bytes_per_token(hp, ggml.BLOCK_BYTES[hp["wtype"]], ggml.BLOCK_ELEMS[hp["wtype"]])
-    traffic, traffic_from, traffic_all = None, None, None
-    for tp in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    traffic, traffic_from, traffic_all, traffic_ctx = None, None, None, None
+    for tp in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tp)
         if os.path.exists(tpath) and args.model == "7b" and args.wtype == "q4_0":
             tj = json.load(open(tpath))
             traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
             traffic = traffic_all.get(dom_kind)
+            traffic_ctx = tj.get("context_positions")  # mean context of the profiled dispatches (tests/tools/pmc_traffic.py)
             traffic_from = ("profiles/" + tp + ": a COMMITTED figure from separate rocprofv3 --pmc passes of this kernel "
                             "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run"
                             + ("" if traffic is not None else "; it holds no entry for this launch kind"))
             break
     is_k = args.wtype.endswith("_k")
+    Egqa_b = hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])
     W = args.wtype.upper()
     labels = {"gate_up": f"k_mmvq_big<{W}, EPI_GATE, XSRC_NORM> (w1|w3 mat-vec, rms_norm + Q8 staging and silu(w1 x)*(w3 x) epilogue fused)",
               "qkv": ((f"k_qkv_attn_wo<{W}> (wq|wk|wv mat-vec with rms_norm + Q8 staging, RoPE and K/V store on G - n_head workgroups, the "
@@ -674,7 +676,10 @@ def run_single(args):
     roofline = {"bound": "hbm", "kernel": kernel_label, "kernel_kind": dom_kind,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_from": traffic_from,
-                "traffic_over_algo": round(traffic / dom["bytes_per_launch"], 4) if traffic else None,
+                # the PMC passes ran at their own context length: the ratio is taken against the algorithmic bytes AT THAT context (the
+                # fused launch's bytes hold the K/V the attention reads: 4 bytes x n_embd_gqa per position and launch)
+                "traffic_context_positions": traffic_ctx,
+                "traffic_over_algo": round(traffic / (dom["bytes_per_launch"] + ((traffic_ctx - roofline_ctx) * Egqa_b * 4 if (traffic_ctx and dom_kind == "qkv") else 0)), 4) if traffic else None,
                 "traffic_per_kind": traffic_all,
                 "avg_launch_us": dom["us_per_launch"], "algo_bytes_per_launch": dom["bytes_per_launch"],
                 "context_positions": roofline_ctx,

@@ -34,4 +34,6 @@ out["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "bytes = FETCH_SIZE x 2 (gfx950 correction) x 1 KiB + WRITE_SIZE x 1 KiB, per launch")
 if len(sys.argv) > 3:  # what the profiled run was, e.g. the context range its dispatches ran at
     out["run"] = sys.argv[3]
+if len(sys.argv) > 4:  # mean number of positions in the K/V cache over the profiled dispatches (bench.py takes traffic_over_algo at it)
+    out["context_positions"] = float(sys.argv[4])
 print(json.dumps(out, indent=1))

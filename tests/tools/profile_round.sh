@@ -30,7 +30,7 @@ timeout 200 python tests/tools/cols_timeline.py 64 8 > gpurun_out/${TAG}_cols_ti
 timeout 200 python tests/tools/pattn_timeline.py 512 0 > gpurun_out/${TAG}_pattn_timeline.txt 2>&1
 python tests/tools/kstats.py /tmp/prof_d > gpurun_out/${TAG}_decode7b_kernel_stats.txt 2>&1
 python tests/tools/kstats.py /tmp/prof_p > gpurun_out/${TAG}_prefill7b_kernel_stats.txt 2>&1
-python tests/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w "bench.py --prompt 248 --warmup 2 --steps 16 --headline-only --weights blocks: single-token decode dispatches at 248...266 positions of context (+ one roofline replay each)" > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/${TAG}_pmc_traffic.err
+python tests/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w "bench.py --prompt 248 --warmup 2 --steps 16 --headline-only --weights blocks: single-token decode dispatches at 248...266 positions of context (+ one roofline replay each)" 257 > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/${TAG}_pmc_traffic.err
 head -12 gpurun_out/${TAG}_decode7b_kernel_stats.txt
 head -12 gpurun_out/${TAG}_prefill7b_kernel_stats.txt
 cat gpurun_out/${TAG}_pmc_traffic.json | head -40

@@ -40,6 +40,17 @@ def main():
                      us(np.median(wv[:, 0]) - e0), us(np.median(wv[:, 1]) - e0), us(np.median(wv[:, 2]) - e0), us(np.median(wv[:, 3]) - e0),
                      us(wv[:, 3].max() - e0), us(np.median(wv[:, 4]) - e0), us(wv[:, 4].max() - e0), us(np.median(wv[:, 5]) - e0),
                      us(wv[:, 5].max() - e0), us(gv[:, 0].min() - e0) if len(gv) else float("nan")])
+    # spread of the mat-vec workgroups' exit from wq|wk|wv (= start of their wo phase) and of the attention workgroups' stamps
+    sp = []
+    for il in range(2, L):
+        a, wo = t[5 * il + 1], t[5 * il + 2]
+        av = a[:4][a[:4, 0] > 0]
+        wv = wo[wo[:, 0] > 0]
+        e0 = av[:, 0].min()
+        sp.append([us(np.percentile(wv[:, 0], q) - e0) for q in (0, 10, 50, 90, 99, 100)] + [us(av[:, 1].min() - e0), us(av[:, 1].max() - e0)])
+    sp = np.array(sp).mean(axis=0)
+    print("wq|wk|wv done per mat-vec workgroup, percentiles 0/10/50/90/99/100: " + " ".join("%.2f" % v for v in sp[:6]))
+    print("attention has its rows, earliest / latest sampled head: %.2f / %.2f" % (sp[6], sp[7]))
     r = np.array(rows).mean(axis=0)
     names = ["attention has its rows", "attention V.P done", "attention exit mean", "attention exit max", "wo phase starts (median)",
              "wo rows requested", "wo rows in LDS", "first head output seen (median)", "first head output seen (max)",
