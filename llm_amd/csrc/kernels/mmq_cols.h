@@ -39,6 +39,7 @@ struct ColsArgs {
     int gq, gr;        // ngroups / gridDim.x and ngroups % gridDim.x: workgroup b owns gq (+1 if b < gr) groups from b * gq + min(b, gr)
     long long *ts;     // INSTR build only (option "timeline"): 8 x int64 per sampled workgroup, as BigArgs::ts
     int ts_wgs;
+    const void *hot;   // 256 bytes the dummy ring steps read (BigArgs::hot, decode_big.h); nullptr = the first bytes of the scales
 };
 
 typedef int i32x4v __attribute__((ext_vector_type(4)));
@@ -191,13 +192,19 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
         }
         c.row_blk = (uint32_t)(m0 + jrow) * (uint32_t)nb;
     };
-    auto issue = [&](ColsStep<QT> &s, const Cursor &c) {
-        const uint32_t o = c.row_blk + (uint32_t)(4 * c.st + bg);
-        s.q = __builtin_nontemporal_load((const u32x4 *)(c.qs + (size_t)o * 16));
-        if constexpr (QT == QT_Q8_0) s.p = __builtin_nontemporal_load((const u32x4 *)(c.qs2 + (size_t)o * 16));
-        if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) s.h = __builtin_nontemporal_load(c.qh + o);
-        s.dw = c.wd[o];
-        if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) s.mw = c.wm[o];
+    // A step past the wave's last one is a DUMMY that reads ColsArgs::hot (one line, a cache hit): every ring slot is refilled
+    // unconditionally, so the loads in flight are a compile-time constant at every wait (k_mmvq_big's `issue`, decode_big.h).
+    // Round 3's form — refills under `if (pc.q < nu)` — compiled to ONE s_waitcnt vmcnt(0) at the head of every pass of PF
+    // steps: the whole ring drained, then PF steps of arithmetic with the next batch in flight (tests/tools/disasm.py, round 6).
+    const uint8_t *const hotp = ca.hot ? (const uint8_t *)ca.hot : (const uint8_t *)a.w[0].d;
+    auto issue = [&](ColsStep<QT> &s, const Cursor &c, const bool dummy) {
+        const uint32_t o = dummy ? 0u : c.row_blk + (uint32_t)(4 * c.st + bg);
+        const uint8_t *pq = dummy ? hotp : c.qs;
+        s.q = __builtin_nontemporal_load((const u32x4 *)(pq + (size_t)o * 16));
+        if constexpr (QT == QT_Q8_0) s.p = __builtin_nontemporal_load((const u32x4 *)((dummy ? hotp : c.qs2) + (size_t)o * 16));
+        if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) s.h = __builtin_nontemporal_load((dummy ? (const uint32_t *)hotp : c.qh) + o);
+        s.dw = (dummy ? (const __half *)hotp : c.wd)[o];
+        if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) s.mw = (dummy ? (const __half *)hotp : c.wm)[o];
     };
     auto advance = [&](Cursor &c) {
         if (++c.st >= st1) open_unit(c, c.q + 1);
@@ -208,17 +215,14 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
     open_unit(pc, 0);
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        if (pc.q < nu) {
-            issue(ring[k], pc);
-            advance(pc);
-        }
+        const bool more = pc.q < nu;
+        issue(ring[k], pc, !more);
+        if (more) advance(pc);
     }
     if constexpr (INSTR) t_issued = big_now();
-    // the DMA is older than the ring's loads: with a full ring in flight, "at most PF * LPS outstanding" means it has landed
-    if (nu * nst >= PF)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * LPS) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the DMA is older than the ring's loads, and the ring is always full (dummies where the wave has fewer steps): "at most
+    // PF * LPS outstanding" means the DMA has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * LPS) : "memory");
     __syncthreads();  // activations staged
     if constexpr (INSTR) t_staged = big_now();
 
@@ -226,64 +230,70 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
     float f[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) f[c] = 0.0f;
-    while (cq < nu) {
+    auto consume = [&](const ColsStep<QT> &st) {
+        const int bl = 4 * cst + bg;  // this lane's block (weights, scales, outputs)
+        uint32_t wl[4], wh[4];
+        block_unpack<QT>(st.q, st.p, st.h, wl, wh);
+        const i32x4v bwl = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]}, bwh = {(int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]};
+        const float dw = __half2float(st.dw);
+        float mw = 0.0f;
+        if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mw = __half2float(st.mw);
+        const i32x4v zero4 = {0, 0, 0, 0};
+        {
+            const i32x4v alo = act ? *(const i32x4v *)((const char *)s_lo + (acol * nb + bl) * 16) : zero4;
+            const i32x4v ahi = act ? *(const i32x4v *)((const char *)s_hi + (acol * nb + bl) * 16) : zero4;
+            i32x4v acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, bwl, zero4, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, bwh, acc, 0, 0, 0);
+            const f32x4 xd = *(const f32x4 *)(s_dx + bl * 8);
+            const i32x4v xs = *(const i32x4v *)(s_sx + bl * 8);
+#pragma unroll
+            for (int c = 0; c < 4; c++) f[c] += cols_scale<QT>(acc[c], dw, mw, xd[c], xs[c]);
+        }
+        if (ncols > 4) {  // uniform
+            const i32x4v alo = act ? *(const i32x4v *)((const char *)s_lo + ((acol + 4) * nb + bl) * 16) : zero4;
+            const i32x4v ahi = act ? *(const i32x4v *)((const char *)s_hi + ((acol + 4) * nb + bl) * 16) : zero4;
+            i32x4v acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, bwl, zero4, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, bwh, acc, 0, 0, 0);
+            const f32x4 xd = *(const f32x4 *)(s_dx + bl * 8 + 4);
+            const i32x4v xs = *(const i32x4v *)(s_sx + bl * 8 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; c++) f[4 + c] += cols_scale<QT>(acc[c], dw, mw, xd[c], xs[c]);
+        }
+        if (++cst >= st1) {  // the wave's part of the unit is complete: add the four block groups, park the 16 x 8 sums
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                float v = f[c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                f[c] = v;
+            }
+            if (lane < 16) {
+                float *o = s_part + ((size_t)(cq * COLS_W + wave) * 16 + lane) * 8;
+                *(f32x4 *)o = f32x4{f[0], f[1], f[2], f[3]};
+                *(f32x4 *)(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) f[c] = 0.0f;
+            cst = st0;
+            cq++;
+        }
+    };
+    // full passes over the ring while a pass still has a step to request (every slot: its refill goes out unconditionally, then its
+    // arithmetic), then a pass that drains the last PF steps and requests nothing: static wait counts throughout
+    const int Ttot = nu * nst;
+    int tdone = 0;
+    for (; tdone + PF < Ttot; tdone += PF) {
 #pragma unroll
         for (int k = 0; k < PF; k++) {
-            if (cq < nu) {  // wave-uniform
-                const ColsStep<QT> st = ring[k];
-                if (pc.q < nu) {
-                    issue(ring[k], pc);
-                    advance(pc);
-                }
-                const int bl = 4 * cst + bg;  // this lane's block (weights, scales, outputs)
-                uint32_t wl[4], wh[4];
-                block_unpack<QT>(st.q, st.p, st.h, wl, wh);
-                const i32x4v bwl = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]}, bwh = {(int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]};
-                const float dw = __half2float(st.dw);
-                float mw = 0.0f;
-                if constexpr (QT == QT_Q4_1 || QT == QT_Q5_1) mw = __half2float(st.mw);
-                const i32x4v zero4 = {0, 0, 0, 0};
-                {
-                    const i32x4v alo = act ? *(const i32x4v *)((const char *)s_lo + (acol * nb + bl) * 16) : zero4;
-                    const i32x4v ahi = act ? *(const i32x4v *)((const char *)s_hi + (acol * nb + bl) * 16) : zero4;
-                    i32x4v acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, bwl, zero4, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, bwh, acc, 0, 0, 0);
-                    const f32x4 xd = *(const f32x4 *)(s_dx + bl * 8);
-                    const i32x4v xs = *(const i32x4v *)(s_sx + bl * 8);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) f[c] += cols_scale<QT>(acc[c], dw, mw, xd[c], xs[c]);
-                }
-                if (ncols > 4) {  // uniform
-                    const i32x4v alo = act ? *(const i32x4v *)((const char *)s_lo + ((acol + 4) * nb + bl) * 16) : zero4;
-                    const i32x4v ahi = act ? *(const i32x4v *)((const char *)s_hi + ((acol + 4) * nb + bl) * 16) : zero4;
-                    i32x4v acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, bwl, zero4, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, bwh, acc, 0, 0, 0);
-                    const f32x4 xd = *(const f32x4 *)(s_dx + bl * 8 + 4);
-                    const i32x4v xs = *(const i32x4v *)(s_sx + bl * 8 + 4);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) f[4 + c] += cols_scale<QT>(acc[c], dw, mw, xd[c], xs[c]);
-                }
-                if (++cst >= st1) {  // the wave's part of the unit is complete: add the four block groups, park the 16 x 8 sums
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        float v = f[c];
-                        v += __shfl_xor(v, 16, 64);
-                        v += __shfl_xor(v, 32, 64);
-                        f[c] = v;
-                    }
-                    if (lane < 16) {
-                        float *o = s_part + ((size_t)(cq * COLS_W + wave) * 16 + lane) * 8;
-                        *(f32x4 *)o = f32x4{f[0], f[1], f[2], f[3]};
-                        *(f32x4 *)(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; c++) f[c] = 0.0f;
-                    cst = st0;
-                    cq++;
-                }
-            }
+            consume(ring[k]);  // (then the refill INTO the registers just consumed: a copy of the slot taken first makes the
+            const bool more = pc.q < nu;  //  loop's back edge a register shuffle behind an s_waitcnt vmcnt(0))
+            issue(ring[k], pc, !more);
+            if (more) advance(pc);
         }
     }
+#pragma unroll
+    for (int k = 0; k < PF; k++)
+        if (tdone + k < Ttot) consume(ring[k]);  // wave-uniform
     if constexpr (INSTR) t_loop = big_now();
     __syncthreads();
     if constexpr (INSTR) t_sync2 = big_now();
