@@ -209,22 +209,43 @@ __global__ void __launch_bounds__(COLS_T) k_mmq_cols(const ColsArgs ca) {
     auto advance = [&](Cursor &c) {
         if (++c.st >= st1) open_unit(c, c.q + 1);
     };
-    constexpr int PF = QT == QT_Q8_0 ? 4 : 6;
+    // ring depth: with counted waits the depth is real, and deeper is SLOWER here (8 waves x PF steps of 1 KB + the scales compete
+    // for the CU's request slots with each other): LLaMA-7B Q4_0 prompt feed at n_batch = 8, -DCOLS_PF / -DCOLS_PF0 builds on one
+    // box (gpurun_out/r6/run31, run32), tok/s: 12|2 2913, 10|2 2899, 8|2 3021, 6|2 3160, 5|2 3190, 4|2 3299, 4|1 3292, 3|2 3323,
+    // 3|1 3358, 2|2 3249 (round 5: 6 steps, all requested in front of the barrier, drained at every pass: 3100)
+#ifndef COLS_PF
+#define COLS_PF 3
+#endif
+    constexpr int PF = QT == QT_Q8_0 ? (COLS_PF * 2 + 2) / 3 : COLS_PF;
     ColsStep<QT> ring[PF];
     Cursor pc;  // producer
     open_unit(pc, 0);
+    // Only PF0 steps go out in front of the staging barrier.  A CU accepts only so many outstanding requests: with the whole ring
+    // (6 steps x 8 waves, ~100 KB) requested first, the last waves sat in ISSUE until the first HBM lines came back and reached
+    // the barrier 2 us after wave 0 had its activations (in-kernel probe, round 6: DMA landed 2.0 us after entry, barrier passed
+    // at 4.0) — the lesson of k_mmvq_big's PF0 (decode_big.h), learnt again.
+#ifndef COLS_PF0
+#define COLS_PF0 1
+#endif
+    constexpr int PF0 = PF < COLS_PF0 ? PF : COLS_PF0;
 #pragma unroll
-    for (int k = 0; k < PF; k++) {
+    for (int k = 0; k < PF0; k++) {
         const bool more = pc.q < nu;
         issue(ring[k], pc, !more);
         if (more) advance(pc);
     }
     if constexpr (INSTR) t_issued = big_now();
-    // the DMA is older than the ring's loads, and the ring is always full (dummies where the wave has fewer steps): "at most
-    // PF * LPS outstanding" means the DMA has landed
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * LPS) : "memory");
+    // the DMA is older than the ring's loads, and the ring steps requested so far are always PF0 (dummies where the wave has fewer):
+    // "at most PF0 * LPS outstanding" means the DMA has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF0 * LPS) : "memory");
     __syncthreads();  // activations staged
     if constexpr (INSTR) t_staged = big_now();
+#pragma unroll
+    for (int k = PF0; k < PF; k++) {
+        const bool more = pc.q < nu;
+        issue(ring[k], pc, !more);
+        if (more) advance(pc);
+    }
 
     int cq = 0, cst = st0;  // consumer
     float f[8];
