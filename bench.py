@@ -505,6 +505,15 @@ def run_single(args):
                           "us_per_launch": round(kms * 1e3 / max(kn * rs, 1), 3),
                           "GBps": round(kb * rs / 1e9 / (kms / 1e3), 1) if kms > 0 else 0.0}
     ms, launches, algo_bytes = ggml.bench_plan_class(ggml.KCLASS_MMVQ, rs)
+    # what each kind costs IN SEQUENCE: all mat-vec launches minus all but that kind.  A launch replayed alone does not show what
+    # it owes its predecessor (w1|w3 finds its first 24 MB in L2, warmed by the fused launch in front of it: kernels/decode_fused.h
+    # NextWarm) nor what it pays for its successor (that warm-up's 24 MB pass through the fused launch's window)
+    for name, kind in kinds.items():
+        if name in per_kind and per_kind[name]["launches"] > 0:
+            ms_wo, _, _ = ggml.bench_plan_class(ggml.KKIND_BASE + 8 + kind, rs)
+            us_seq = (ms - ms_wo) * 1e3 / rs / per_kind[name]["launches"]
+            per_kind[name]["in_sequence_us_per_launch"] = round(us_seq, 3)
+            per_kind[name]["in_sequence_frac"] = round(per_kind[name]["bytes_per_launch"] / 1e3 / us_seq / HBM_PEAK_GBS, 4) if us_seq > 0 else None
     att_ms, att_n, att_bytes = ggml.bench_plan_class(ggml.KCLASS_ATTN, rs)
     oth_ms, oth_n, _ = ggml.bench_plan_class(ggml.KCLASS_OTHER, rs)
     ht = [x / args.steps / 1e3 for x in sess.host_timing()]  # us per token

@@ -519,7 +519,8 @@ GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, d
 GGML_API void ggml_hip_set_option(const char *key, int value);
 /* Replays the launches of one kernel class of the most recent fused decode plan `replays` times from a
  * dedicated hipGraph between two HIP events on the backend stream (bench.py roofline leg). 0 on success.
- * kclass may also be GGML_HIP_KKIND_BASE + {0 wq|wk|wv, 1 wo, 2 w1|w3, 3 w2, 4 lm_head}: that mat-vec alone. */
+ * kclass may also be GGML_HIP_KKIND_BASE + {0 wq|wk|wv, 1 wo, 2 w1|w3, 3 w2, 4 lm_head}: that mat-vec alone; or
+ * GGML_HIP_KKIND_BASE + 8 + the same: every mat-vec launch BUT that kind (all - all_but_k = what kind k costs in sequence). */
 #define GGML_HIP_KKIND_BASE 16
 GGML_API int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t *launches_per_replay,
                                        double *algo_bytes_per_replay);

@@ -818,18 +818,6 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_warm_mb != value) drop_all_plans();
         g.opt_warm_mb = value;
     }
-    else if (k == "warm_rows") {
-        if (g.opt_warm_rows != value) drop_all_plans();
-        g.opt_warm_rows = value;
-    }
-    else if (k == "warm_norm") {
-        if (g.opt_warm_norm != value) drop_all_plans();
-        g.opt_warm_norm = value;
-    }
-    else if (k == "warm_wave") {
-        if (g.opt_warm_wave != value) drop_all_plans();
-        g.opt_warm_wave = value & 15;
-    }
     else if (k == "big") {
         if (g.opt_big != value) drop_all_plans();
         g.opt_big = value;
@@ -877,6 +865,9 @@ int ggml_hip_bench_plan_class(int kclass, int replays, double *ms_total, int64_t
     unsigned kind_mask = ~0u;
     if (kclass >= GGML_HIP_KKIND_BASE && kclass < GGML_HIP_KKIND_BASE + 5) {  // one kind of mat-vec launch alone
         kind_mask = 1u << (kclass - GGML_HIP_KKIND_BASE);
+        kclass = GGML_HIP_KCLASS_MMVQ;
+    } else if (kclass >= GGML_HIP_KKIND_BASE + 8 && kclass < GGML_HIP_KKIND_BASE + 13) {  // every mat-vec launch BUT one kind
+        kind_mask = ~(1u << (kclass - GGML_HIP_KKIND_BASE - 8));
         kclass = GGML_HIP_KCLASS_MMVQ;
     }
     if (g_plans.empty() || kclass < 0 || kclass >= GGML_HIP_KCLASS_COUNT || replays < 1) return -1;

@@ -85,15 +85,6 @@ struct BigArgs {
     unsigned long long *gran;
     const unsigned *epoch;  // device word, bumped once per token by k_rope_table: this token's tag
     int wdeal;              // waves of a workgroup that take units (0 = all of blockDim); the rest only help staging
-    // The norm weights the NEXT XSRC_NORM launch stages with (E floats).  Nothing touches them between two tokens while 3.7 GB
-    // stream past, so that launch used to find them in HBM: its activation was staged 3.1-3.7 us after entry where the plain
-    // re-quantization of w2's input (an L2 / MALL hit) is staged after 1.4 (in-kernel timeline, gpurun_out/r6/run2: the
-    // arithmetic is the same but for one barrier) — the first-byte latency of a cold HBM line after a kernel boundary is ~2.2 us.
-    // The first eight workgroups of THIS launch (one per XCD under the observed round-robin placement) touch every 128-byte line
-    // of them once: an L2 hit for the next launch on every XCD.  Every wave issues the one load (a dummy line where it has
-    // nothing to warm), so the number of loads in flight stays a compile-time constant (see `issue` below).  nullptr = none.
-    const unsigned *nwarm;
-    int nwarm_bytes;
     // 256 bytes that the DUMMY ring steps read (a wave's slots past its last real step): one line for the whole chip, fetched with
     // plain loads, so it sits in every CU's L1 — a dummy step costs its issue slots and nothing else (see `issue`).  nullptr = the
     // first line of the matrix's scales.
@@ -279,13 +270,7 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
     BigX<XSRC> xr;
     xr.load(ba, nb, tid, T);
     const uint8_t *hotp = ba.hot ? (const uint8_t *)ba.hot : (const uint8_t *)a.w[0].d;
-    unsigned warm_v;
-    {
-        const int li = (wave * 64 + lane) * 32;  // in words: one word per 128-byte line
-        const bool on = ba.nwarm && bid < 8 && li * 4 < ba.nwarm_bytes;
-        const unsigned *wp = on ? ba.nwarm + li : (const unsigned *)hotp;  // everybody else touches the dummies' line (BigArgs::hot)
-        warm_v = *wp;
-    }
+    const unsigned warm_v = *(const unsigned *)hotp;  // every wave touches the dummies' line with a plain load at entry: it stays cached
     // EPI_QKV: the last two waves fetch the token's RoPE table (k_rope_table); every wave issues the load so that all
     // load queues keep one compile-time shape
     f32x2 rope_pre = {0.0f, 0.0f};

@@ -86,8 +86,9 @@ constexpr int WARM_MAX = 10;  // arrays: qs, d (+ qs2 | qh | m) of w1 and of w3
 struct NextWarm {
     const uint8_t *base[WARM_MAX];
     uint32_t row_bytes[WARM_MAX];  // bytes of one matrix row in that array
+    int rows_of[WARM_MAX];         // rows 0 .. rows_of[a] - 1 of array a are warmed (w1|w3: the next launch; w2: the one behind it)
     int n;                         // arrays in use
-    int rows;                      // rows 0 .. rows - 1 of every array are warmed; 0 = off
+    int rows;                      // > 0: the warm-up is on
     const uint8_t *bcast;          // a small array EVERY workgroup of the next launch reads (the norm weights): one workgroup per XCD takes it
     int bcast_bytes;
 };
@@ -97,10 +98,10 @@ __device__ __forceinline__ void warm_next(const NextWarm &nw, const int bid, con
     typedef __attribute__((address_space(3))) void *wl_ptr;
     const int x = (int)blockIdx.x & 7;  // this workgroup's place in the dispatcher's round robin = that of the workgroups it warms for
     const int j = bid >> 3, nj = (G + 7) >> 3;   // this workgroup among its XCD's (round-robin placement assumed, for speed only)
-    const int K = (nw.rows + 7 - x) >> 3;        // rows x, x + 8, ... of the first nw.rows
-    const int c = (K + nj - 1) / nj;
-    const int k0 = j * c, cnt = K - k0 < c ? K - k0 : c;
     for (int a = 0; a < nw.n; a++) {
+        const int K = (nw.rows_of[a] + 7 - x) >> 3;  // rows x, x + 8, ... of the first rows_of[a]
+        const int c = (K + nj - 1) / nj;
+        const int k0 = j * c, cnt = K - k0 < c ? K - k0 : c;
         const uint32_t rb = nw.row_bytes[a];
         const int lpr = (int)((rb + 127) >> 7);  // samples per row, 128 bytes apart + the row's last word: every line it touches
         const uint8_t *base = nw.base[a];
