@@ -668,6 +668,9 @@ def run_single(args):
             break
     is_k = args.wtype.endswith("_k")
     Egqa_b = hp["n_embd"] // (hp["n_head"] // hp["n_head_kv"])
+    warm_mb = int(os.environ.get("GGML_HIP_WARM_MB", "24"))  # the library's default (llm_amd/csrc/backend_state.inc opt_warm_mb)
+    row_b = hp["n_embd"] // 32 * ggml.BLOCK_BYTES[hp["wtype"]] if not args.wtype.endswith("_k") else 0
+    warm_bytes = (min((int(warm_mb * 1e6 / (2.0 * row_b)) & ~7), hp["n_ff"]) * 2 * row_b) if (row_b and fused_wo_tokens) else 0
     W = args.wtype.upper()
     labels = {"gate_up": f"k_mmvq_big<{W}, EPI_GATE, XSRC_NORM> (w1|w3 mat-vec, rms_norm + Q8 staging and silu(w1 x)*(w3 x) epilogue fused)",
               "qkv": ((f"k_qkv_attn_wo<{W}> (wq|wk|wv mat-vec with rms_norm + Q8 staging, RoPE and K/V store on G - n_head workgroups, the "
@@ -688,7 +691,13 @@ def run_single(args):
                 # the PMC passes ran at their own context length: the ratio is taken against the algorithmic bytes AT THAT context (the
                 # fused launch's bytes hold the K/V the attention reads: 4 bytes x n_embd_gqa per position and launch)
                 "traffic_context_positions": traffic_ctx,
-                "traffic_over_algo": round(traffic / (dom["bytes_per_launch"] + ((traffic_ctx - roofline_ctx) * Egqa_b * 4 if (traffic_ctx and dom_kind == "qkv") else 0)), 4) if traffic else None,
+                # ... and the fused launch also pulls the first warm_mb (24) MB of w1|w3 through its idle window for the NEXT launch
+                # (kernels/decode_fused.h NextWarm): bytes the memory side sees in THIS launch by design, not re-reads.  (Under the
+                # profiler's per-dispatch serialisation w1|w3 then fetches them again — its own figure stays at its algorithmic bytes;
+                # in a hipGraph replay it finds them in L2: in_sequence_us_per_launch below.)
+                "traffic_next_launch_warm_bytes": warm_bytes if dom_kind == "qkv" else 0,
+                "traffic_over_algo": round(traffic / (dom["bytes_per_launch"] + (warm_bytes if dom_kind == "qkv" else 0)
+                                                      + ((traffic_ctx - roofline_ctx) * Egqa_b * 4 if (traffic_ctx and dom_kind == "qkv") else 0)), 4) if traffic else None,
                 "traffic_per_kind": traffic_all,
                 "avg_launch_us": dom["us_per_launch"], "algo_bytes_per_launch": dom["bytes_per_launch"],
                 "context_positions": roofline_ctx,
