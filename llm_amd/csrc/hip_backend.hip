@@ -725,10 +725,6 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         g.opt_plan = value;
     else if (k == "graph")
         g.opt_graph = value;
-    else if (k == "xsrc") {
-        if (g.opt_xsrc != value) drop_all_plans();
-        g.opt_xsrc = value;
-    }
     else if (k == "timeline") {
         drop_all_plans();
         if (g.timeline && value && (value == 1 ? 4 : value) != g.timeline_wgs) {
@@ -762,8 +758,6 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
     }
     else if (k == "mmq_fuse")
         g.opt_mmq_fuse = value;
-    else if (k == "spin_wait")
-        g.opt_spin_wait = value;
     else if (k == "chain_k")
         g.opt_chain_k = std::min(64, std::max(0, value));
     else if (k == "mmq_t256") {
@@ -814,6 +808,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_fuse_wo != value) drop_all_plans();
         g.opt_fuse_wo = value;
     }
+    else if (k == "affine") {
+        if (g.opt_affine != value) drop_all_plans();
+        g.opt_affine = value;
+    }
     else if (k == "warm_mb") {
         if (g.opt_warm_mb != value) drop_all_plans();
         g.opt_warm_mb = value;
@@ -841,14 +839,10 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_probe != value) drop_all_plans();
         g.opt_probe = value;
     }
-    else if (k == "mmvq_rows")
-        g.opt_mmvq_rows = value;
     else if (!strcmp(key, "mmq_min"))
         g.opt_mmq_min = value;
     else if (!strcmp(key, "k_prompt_min"))  // K-quant models: batch size from which the prompt plan (f16 copies) replaces the K plan's chunks
         g.opt_k_prompt_min = value;
-    else if (!strcmp(key, "mmq_splitk"))
-        g.opt_mmq_splitk = value;
     else if (!strcmp(key, "mmq_i8"))
         g.opt_mmq_i8 = value;
     else

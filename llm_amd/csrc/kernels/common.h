@@ -175,6 +175,19 @@ __device__ __forceinline__ void gran_store(unsigned long long *g_, unsigned epoc
 __device__ __forceinline__ unsigned long long gran_load(const unsigned long long *g_) {
     return __hip_atomic_load((gu64 *)g_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same granule between two workgroups that share an XCD: a plain store lands in that XCD's L2, a non-temporal load is served by it
+// (a sc0 load would be answered by the reader's L1 for ever, tests/tools/handoff_probe.hip): 0.3 us per hand-off instead of 0.6 on an
+// idle chip, and — what matters inside a launch whose other workgroups keep the HBM queues full — no trip through the memory side
+// at all.  ONLY for a producer / consumer pair on one XCD: another XCD's L2 never sees the store before the kernel ends.
+__device__ __forceinline__ void gran_store_l2(unsigned long long *g_, unsigned epoch, unsigned value) {
+    const unsigned long long v = ((unsigned long long)epoch << 32) | value;
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g_), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned long long gran_load_l2(const unsigned long long *g_) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(g_) : "memory");
+    return v;
+}
 // Every in-launch wait is bounded, and bounded in POLLS, not in wall-clock time: a poll is an L2 round trip plus an s_sleep
 // (>= ~0.7 us), so 2^18 of them are >= ~0.2 s of the wave actually running.  A wave that is context-switched out (another
 // process's queue on the same GPU) does not poll, so time-slicing cannot trip the bound the way a wall-clock limit could; a peer

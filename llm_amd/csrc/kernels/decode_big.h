@@ -89,6 +89,10 @@ struct BigArgs {
     // plain loads, so it sits in every CU's L1 — a dummy step costs its issue slots and nothing else (see `issue`).  nullptr = the
     // first line of the matrix's scales.
     const void *hot;
+    // EPI_QKV inside k_qkv_attn, XCD-affine dealing (aff_hpl > 0): the row pairs of head h's Q / K / V go to the mat-vec workgroups
+    // whose blockIdx mod 8 equals h mod 8 — the XCD head h's attention workgroup (blockIdx h) runs on — and travel through that
+    // XCD's L2 (gran_store_l2).  aff_hpl = heads per XCD (n_head / 8), aff_shift = log2(D / 2).  MHA only (wk, wv as tall as wq).
+    int aff_hpl, aff_shift;
 };
 __device__ __forceinline__ long long big_now() { return (long long)wall_clock64(); }  // 100 MHz, chip-wide
 
@@ -285,8 +289,25 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
     const int Utot = (M0 + M1 + M2) / RU;
     // wave-major within a round: the units of the last, partial round go to waves 0..k of EVERY workgroup, so all CUs
     // stream the same number of rows (11008 w1|w3 rows: 43 per CU instead of 45 on 222 CUs and 30 on 34)
-    const int u_first = wave * G + bid, u_stride = G * W;
-    const int nu = (wave < W && u_first < Utot) ? (Utot - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
+    // XCD-affine dealing (BigArgs::aff_hpl): the same formula over the units of THIS workgroup's XCD label (blockIdx mod 8 = bid mod 8:
+    // the attention workgroups in front are a multiple of 8) dealt to the G / 8 workgroups that carry the label
+    bool affine = false;
+    if constexpr (EPI == EPI_QKV) affine = ba.aff_hpl > 0;
+    const int Gd = affine ? G >> 3 : G, bd = affine ? bid >> 3 : bid;
+    const int Ucnt = affine ? (ba.aff_hpl * 3) << ba.aff_shift : Utot;
+    const int u_first = wave * Gd + bd, u_stride = Gd * W;
+    const int nu = (wave < W && u_first < Ucnt) ? (Ucnt - u_first + u_stride - 1) / u_stride : 0;  // <= 64 (launcher)
+    // unit of the dealing -> unit of the launch (row pair index over wq|wk|wv): the identity unless the dealing is XCD-affine
+    auto unit_of = [&](int lu) -> int {
+        if constexpr (EPI == EPI_QKV) {
+            if (affine) {
+                const int q = lu >> ba.aff_shift, pr = lu & ((1 << ba.aff_shift) - 1);  // (head of the label, matrix), pair of the head
+                const int hh = q / 3, mat = q - 3 * hh;
+                return mat * (M0 >> 1) + (((bid & 7) + 8 * hh) << ba.aff_shift) + pr;
+            }
+        }
+        return lu;
+    };
     const int S = nu * nbl;
     // EPI_ADD: lane i preloads the residual of unit i (a load issued in the epilogue would drain the queue)
     float res_pre = 0.0f;
@@ -297,8 +318,8 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
 
     // unit -> (matrix, first row)
     auto resolve = [&](int i, int &sg, int &m0) {
-        int r = (u_first + u_stride * i) * RU;
-        if (r >= Utot * RU) r = 0;  // dummy prefetch steps of a wave without (enough) units: any valid row
+        const int lu = u_first + u_stride * i;
+        const int r = lu < Ucnt ? unit_of(lu) * RU : 0;  // (dummy prefetch steps of a wave without (enough) units: any valid row)
         sg = 0;
         m0 = r;
         if constexpr (EPI == EPI_QKV) {
@@ -511,7 +532,11 @@ __device__ __forceinline__ void big_body(const BigArgs &ba, const int bid, const
             }
             if (ba.gran) {  // one aligned 8-byte agent-scope (write-through) store: the data is the flag
                 const unsigned v2 = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
-                gran_store(ba.gran + (u_first + u_stride * lane), epoch, v2);
+                unsigned long long *gp = ba.gran + unit_of(u_first + u_stride * lane);
+                if (affine)
+                    gran_store_l2(gp, epoch, v2);
+                else
+                    gran_store(gp, epoch, v2);
             }
         }
     }

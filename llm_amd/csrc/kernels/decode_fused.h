@@ -39,6 +39,8 @@ struct FusedAttnArgs {
     float *dq;
     int *sumq;
     long long *ts;  // optional timeline slot (as k_attn_decode)
+    int ts_heads;   // heads the slot has room for: all of them (slot h) or four (every n_head / 4 th)
+    int local_rows; // 1: the token's rows come from mat-vec workgroups of this workgroup's own XCD through its L2 (BigArgs::aff_hpl)
     unsigned *err;  // raised when a wait gave up
     // S > 1: S attention workgroups per head, workgroup s takes positions [512 s, 512 (s + 1)) (attn_consumer_split below)
     int S, layer;
@@ -117,6 +119,15 @@ __device__ __forceinline__ void warm_next(const NextWarm &nw, const int bid, con
     if (j == 0 && nw.bcast)
         for (int i = lane * 128; i < nw.bcast_bytes; i += 64 * 128)
             __builtin_amdgcn_global_load_lds((wg_ptr)(nw.bcast + i), (wl_ptr)junk, 4, 0, 0);
+}
+
+// the XCD every workgroup of a num_cus x 1024-thread launch runs on (llama_plan.inc xcd_labels_ok: does blockIdx mod 8 name the XCD?)
+__global__ void __launch_bounds__(1024) k_xcc_ids(unsigned *out) {
+    if (threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.x] = v & 0xf;
+    }
 }
 
 struct WoTailArgs {
@@ -347,7 +358,7 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
         const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
         unsigned long long x;
         for (int spin = 0;; spin++) {
-            x = gran_load(gp);
+            x = f.local_rows ? gran_load_l2(gp) : gran_load(gp);
             const bool ok = (unsigned)(x >> 32) == epoch;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
             __builtin_amdgcn_s_sleep(GRAN_SLEEP);
@@ -497,10 +508,13 @@ __device__ __forceinline__ void attn_consumer(const FusedAttnArgs &f, const int 
     }
     if (f.ts && tid == 0) {
         const int q4 = f.n_head / 4;
-        if (q4 > 0 && h % q4 == 0 && h / q4 < 4) {
-            long long *o = f.ts + (h / q4) * 8;
+        const bool all = f.ts_heads >= f.n_head;
+        if (all || (q4 > 0 && h % q4 == 0 && h / q4 < 4)) {
+            long long *o = f.ts + (all ? h : h / q4) * 8;
             o[0] = t_entry; o[1] = t_loaded; o[2] = t_scores; o[3] = t_softmax; o[4] = t_vp;
-            o[5] = (long long)wall_clock64(); o[6] = T; o[7] = h;
+            o[5] = (long long)wall_clock64();
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's granule stores are acknowledged (write-through: by the memory side)
+            o[6] = (long long)wall_clock64(); o[7] = h;
         }
     }
 }

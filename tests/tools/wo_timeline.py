@@ -32,7 +32,7 @@ def main():
     rows = []
     for il in range(2, L):
         a, wo, gate = t[5 * il + 1], t[5 * il + 2], t[5 * il + 3]
-        av = a[:4][a[:4, 0] > 0]
+        av = a[:32][a[:32, 0] > 0]
         wv = wo[wo[:, 0] > 0]
         gv = gate[gate[:, 0] > 0]
         e0 = av[:, 0].min()
@@ -44,13 +44,37 @@ def main():
     sp = []
     for il in range(2, L):
         a, wo = t[5 * il + 1], t[5 * il + 2]
-        av = a[:4][a[:4, 0] > 0]
+        av = a[:32][a[:32, 0] > 0]
         wv = wo[wo[:, 0] > 0]
         e0 = av[:, 0].min()
         sp.append([us(np.percentile(wv[:, 0], q) - e0) for q in (0, 10, 50, 90, 99, 100)] + [us(av[:, 1].min() - e0), us(av[:, 1].max() - e0)])
     sp = np.array(sp).mean(axis=0)
     print("wq|wk|wv done per mat-vec workgroup, percentiles 0/10/50/90/99/100: " + " ".join("%.2f" % v for v in sp[:6]))
     print("attention has its rows, earliest / latest sampled head: %.2f / %.2f" % (sp[6], sp[7]))
+    # per head (all heads are sampled when the timeline has room for them): when it had its rows, when it had published, by XCD
+    hd = []
+    for il in range(2, L):
+        a = t[5 * il + 1]
+        av = a[:32]
+        if (av[:, 0] > 0).sum() < 32:
+            break
+        e0 = av[:, 0].min()
+        hd.append(np.stack([us(av[:, 1] - e0), us(av[:, 4] - e0), us(av[:, 5] - e0), us(av[:, 6] - e0)]))
+    lat = []
+    for il in range(2, L):
+        a, wo = t[5 * il + 1], t[5 * il + 2]
+        av = a[:32][a[:32, 0] > 0]
+        wv = wo[wo[:, 0] > 0]
+        last = av[:, 5].max()
+        lat.append([us(np.median(wv[:, 3]) - last), us(wv[:, 3].max() - last), us(np.median(wv[:, 4]) - last), us(wv[:, 4].max() - last)])
+    lat = np.array(lat).mean(axis=0)
+    print("after the LAST sampled head published: wave 0 of a mat-vec workgroup holds its granules %.2f (median) %.2f (max); whole workgroup %.2f / %.2f"
+          % tuple(lat))
+    if hd:
+        hd = np.array(hd).mean(axis=0)
+        for nm, row in zip(("has its rows", "V.P done", "published", "stores acked"), hd):
+            print(f"attention {nm:14s} per head: min %.2f  median %.2f  max %.2f   by head mod 8: " % (row.min(), np.median(row), row.max())
+                  + " ".join("%.2f" % row[x::8].mean() for x in range(8)))
     r = np.array(rows).mean(axis=0)
     names = ["attention has its rows", "attention V.P done", "attention exit mean", "attention exit max", "wo phase starts (median)",
              "wo rows requested", "wo rows in LDS", "first head output seen (median)", "first head output seen (max)",
