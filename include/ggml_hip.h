@@ -510,12 +510,13 @@ enum ggml_hip_kclass {
 GGML_API void ggml_hip_timing_begin(void);
 GGML_API void ggml_hip_timing_end(void);
 GGML_API void ggml_hip_timing_query(int kclass, double *ms, int64_t *launches, double *algo_bytes);
-/* Execution mode knobs: "fuse" (peephole fusion in the generic executor), "plan" (fused LLaMA decode plan),
- * "graph" (hipGraph replay of the plan), "mmvq_rows", "big", "mmq_min", "mmq_splitk", "mmq_dma", "plan_multi",
- * "xsrc", "probe" (measurement only: the decode mat-vec returns early), "attn_split" (decode attention split over positions: 0 off, 1 = from 512 positions on (default), n = from n on),
- * "timeline" (1 = 4 sampled workgroups per launch, n > 1 = n of them), "prefetch" (MB of w1|w3 that the idle
- * CUs of the decode attention launch pull into the Infinity Cache, 0 = off, measured slower: DESIGN.md section 4);
- * also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH / GGML_HIP_BIG / GGML_HIP_PREFETCH / GGML_HIP_MMQ_*. */
+/* Execution mode knobs (the full list with meanings: INTEGRATION.md section 4 "Runtime knobs"): "fuse" (peephole fusion in the
+ * generic executor), "plan" / "plan_k" / "plan_multi" / "plan_prompt" (fused LLaMA plans), "graph" (hipGraph replay of a plan),
+ * "big", "kbig", "fuse_attn", "fuse_wo", "fuse_heads", "warm_mb", "affine", "attn_split" (decode attention split over positions:
+ * from n positions on), "attn_one", "fused_fallback", "fused_rearm_tokens", "speculate_next", "act_quant", "mmq_min", "mmq_i8",
+ * "mmq_w16", "w16_headroom_gb", "w16_release", "serial_stage_slots", "probe" (measurement only: the decode mat-vec returns early),
+ * "timeline" (1 = 4 sampled workgroups per launch, n > 1 = n of them); an unknown key aborts with a message.
+ * Also env GGML_HIP_FUSE / GGML_HIP_PLAN / GGML_HIP_GRAPH / GGML_HIP_BIG / GGML_HIP_WARM_MB / GGML_HIP_AFFINE / GGML_HIP_MMQ_*. */
 GGML_API void ggml_hip_set_option(const char *key, int value);
 /* Replays the launches of one kernel class of the most recent fused decode plan `replays` times from a
  * dedicated hipGraph between two HIP events on the backend stream (bench.py roofline leg). 0 on success.

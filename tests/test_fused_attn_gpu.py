@@ -126,11 +126,12 @@ def test_fused_launch_is_the_default_at_7b_width_and_matches_the_pair(G, O):
     assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
 
 
-def test_wo_tail_and_next_launch_warm_up_leave_every_bit_alone(G):
-    """The WO form (option fuse_wo: wo + residual as the mat-vec workgroups' second phase, kernels/decode_fused.h wo_tail)
-    and the L2 warm-up of the next launch's w1|w3 rows from its idle window (option warm_mb, NextWarm) at the width they are
-    built for: logits, ids and K/V of fuse_wo = 0 / warm_mb = 0 and of the defaults must be the same bits, and the counters
-    must show that the WO form ran exactly when asked for."""
+def test_wo_tail_warm_up_and_affine_dealing_leave_every_bit_alone(G):
+    """The WO form (option fuse_wo: wo + residual as the mat-vec workgroups' second phase, kernels/decode_fused.h wo_tail), the L2
+    warm-up of the next launch's w1|w3 rows from its idle window (option warm_mb, NextWarm) and the XCD-affine dealing of
+    wq|wk|wv with its hand-off through the XCD's own L2 (option affine, BigArgs::aff_hpl) at the width they are built for:
+    logits, ids and K/V with each of them off and with the defaults must be the same bits, and the counters must show that
+    every form ran exactly when asked for."""
     from llm_amd import llama, synth
     hp0 = dict(synth.LLAMA_7B)
     hp0["n_layer"], hp0["n_vocab"] = 3, 512
@@ -139,22 +140,25 @@ def test_wo_tail_and_next_launch_warm_up_leave_every_bit_alone(G):
     toks = np.random.default_rng(4).integers(0, hp["n_vocab"], 150).astype(np.int32)
     res = {}
     try:
-        for wo, warm in ((0, 0), (1, 0), (1, 24), (1, 64)):
+        for wo, warm, aff in ((0, 0, 0), (0, 0, 1), (1, 0, 0), (1, 24, 1), (1, 64, 1), (1, 24, 0)):
             G.set_option("fuse_wo", wo)
             G.set_option("warm_mb", warm)
+            G.set_option("affine", aff)
             sess = model.start_session(n_batch=64)
-            w0 = _stat(G, "fused_wo_tokens")
+            w0, a0 = _stat(G, "fused_wo_tokens"), _stat(G, "fused_affine_tokens")
             sess.feed_prompt(toks)
             outs = [(sess.infer_next_token(), sess.last_logits()) for _ in range(6)]
-            res[(wo, warm)] = (outs, sess.get_kv(), _stat(G, "fused_wo_tokens") - w0)
+            res[(wo, warm, aff)] = (outs, sess.get_kv(), _stat(G, "fused_wo_tokens") - w0, _stat(G, "fused_affine_tokens") - a0)
             assert _stat(G, "fused_attn_timeouts") == 0
             sess.free()
     finally:
         G.set_option("fuse_wo", 1)
         G.set_option("warm_mb", 24)
+        G.set_option("affine", 1)
         model.free()
-    assert res[(0, 0)][2] == 0 and all(res[k][2] == 6 for k in res if k[0] == 1)
-    base = res[(0, 0)]
+    for (wo, warm, aff), got in res.items():
+        assert got[2] == (6 if wo else 0) and got[3] == (6 if aff else 0), (wo, warm, aff, got[2], got[3])
+    base = res[(0, 0, 0)]
     for key, got in res.items():
         for (ta, la), (tb, lb) in zip(base[0], got[0]):
             assert ta == tb and np.array_equal(la, lb), key
