@@ -65,6 +65,7 @@ void ggml_init_hipblas(void) {}
 int ggml_hip_device_count(void) { return 1; }
 int ggml_hip_slot_physical_device(int slot) { return slot >= 0 && slot < 4 ? 0 : -1; }
 int ggml_hip_thread_session_slot(void) { return -1; }
+void ggml_hip_set_option(const char *, int) {}
 void ggml_hip_set_main_device(int d) { g_main_device = d; }
 int ggml_hip_get_main_device(void) { return g_main_device; }
 void ggml_hip_bind_thread_device(int) {}
