@@ -553,6 +553,13 @@ GGML_API int64_t ggml_hip_get_stat(const char *key);
  * host-visible results (CPU-backend nodes).  No result may be read, and no other graph computed, in between. */
 GGML_API int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph);
 GGML_API void ggml_hip_graph_compute_end(void);
+/* Optional companion of the pair above: a caller that builds the NEXT token's graph between begin() and end() may hand it over
+ * right away; the structural match of that graph against the fused decode plan (~20 us of host work per token) then happens
+ * while the device runs instead of between two tokens' device work.  Returns 1 if the graph was recognised and remembered (its
+ * begin() then skips the match), 0 otherwise (nothing changes).  The remembered match is dropped by anything that could
+ * invalidate it (ggml_init / ggml_free / ggml_set_scratch on any thread, an option change, freed weights).  The token id itself
+ * is read at begin(), as always. */
+GGML_API int ggml_hip_graph_prepare(struct ggml_cgraph *cgraph);
 /* Greedy sampling on the device (the step after the path): decodes n more tokens — each the first
  * argmax of the previous logits, what `infer_next_token` with a greedy sampler yields (inference_session.rs:381-424,
  * samplers.rs:289-306) — without the per-token logits read-back and host sync.  `last` = the cgraph of the caller's

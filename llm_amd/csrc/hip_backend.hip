@@ -216,6 +216,11 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     g.ns_compute += now_ns() - t0;
     return async;
 }
+extern "C" int ggml_hip_graph_prepare(struct ggml_cgraph *cgraph) {
+    SlotLock lk;
+    ensure_init();
+    return prepare_decode_plan(cgraph) ? 1 : 0;  // host work only: nothing is enqueued, nothing is waited for
+}
 extern "C" void ggml_hip_graph_compute_end(void) {
     SlotLock lk;
     const uint64_t t0 = now_ns();
@@ -715,6 +720,7 @@ void ggml_hip_set_option(const char *key, int value) {
 }
 void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on the current slot
     const std::string k(key);
+    g.opt_gen++;
     if (k == "fuse")
         g.opt_fuse = value;
     else if (k == "act_quant") {  // 0 = ggml's AVX2 activation quantizer (what the reference's build runs), 1 = its scalar branch
@@ -808,6 +814,8 @@ void ggml_hip_internal_set_option_here(const char *key, int value) {  // acts on
         if (g.opt_fuse_wo != value) drop_all_plans();
         g.opt_fuse_wo = value;
     }
+    else if (k == "prepare")
+        g.opt_prepare = value;
     else if (k == "affine") {
         if (g.opt_affine != value) drop_all_plans();
         g.opt_affine = value;

@@ -394,6 +394,8 @@ class GraphExecutionPlan {
         return ggml_hip_graph_compute_begin(inner_graph_) != 0;
     }
     static void execute_end() { ggml_hip_graph_compute_end(); }
+    // the next token's graph, built while the device runs: let the backend match it against its decode plan now (hip backend extension)
+    static bool prepare(const ComputationGraph &next) { return ggml_hip_graph_prepare(next.raw()) != 0; }
 
    private:
     ggml_cplan inner_;

@@ -180,6 +180,7 @@ class InferenceSession {
                 pre_.n_past = n_past + 1;
                 pre_.model_key = model_key;
                 pre_.valid = true;
+                GraphExecutionPlan::prepare(pre_.b.gf);
             }
             lap(3);
             // a middle stage of an in-process layer split has nothing for the host to read: its wait is left to the slot's next

@@ -242,6 +242,7 @@ PROTOTYPES.update({
     "ggml_hip_quantize": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "ggml_hip_quantize_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ggml_hip_graph_compute_begin": (C.c_int, [C.c_void_p]),
+    "ggml_hip_graph_prepare": (C.c_int, [C.c_void_p]),
     "ggml_hip_graph_compute_end": (None, []),
     "ggml_hip_bench_plan_class": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_double)]),

@@ -104,6 +104,7 @@ int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     g_pending = cgraph;
     return 1;
 }
+int ggml_hip_graph_prepare(struct ggml_cgraph *) { return 0; }
 void ggml_hip_graph_compute_end(void) {
     if (g_pending) fake_compute(g_pending);
     g_pending = nullptr;

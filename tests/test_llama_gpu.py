@@ -277,6 +277,34 @@ def test_greedy_is_deterministic_and_matches_oracle_tokens(G, O):
     model.free()
 
 
+def test_graph_matched_ahead_of_time_changes_nothing_but_when_the_match_happens(G, O):
+    """ggml_hip_graph_prepare: the host mirror hands the NEXT token's graph over while the device still runs the current one, so its
+    structural match is off the path between two tokens' device work (inference_session.rs:220-295 rebuilds the graph inside
+    every evaluate).  Same tokens, logits and K/V as with option prepare = 0; the counter shows the remembered matches were used;
+    a rewind between prepare and the next evaluation (another n_past than the remembered graph assumed) must fall back cleanly."""
+    hp, w, model = _mk(G, 2, seed=11)
+    prompt = np.random.default_rng(11).integers(0, hp["n_vocab"], 9).astype(np.int32)
+    res = {}
+    try:
+        for prep in (0, 1):
+            G.set_option("prepare", prep)
+            s = model.start_session(n_batch=8)
+            c0 = int(G.lib().ggml_hip_get_stat(b"prepared_tokens"))
+            s.feed_prompt(prompt)
+            outs = [(s.infer_next_token(), s.last_logits()) for _ in range(10)]
+            assert s.rewind(3) == 0
+            outs += [(s.infer_next_token(), s.last_logits()) for _ in range(5)]
+            res[prep] = (outs, s.get_kv(), int(G.lib().ggml_hip_get_stat(b"prepared_tokens")) - c0)
+            s.free()
+    finally:
+        G.set_option("prepare", 1)
+        model.free()
+    assert res[0][2] == 0 and res[1][2] >= 10, (res[0][2], res[1][2])
+    for (ta, la), (tb, lb) in zip(res[0][0], res[1][0]):
+        assert ta == tb and np.array_equal(la, lb)
+    assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
+
+
 @pytest.mark.parametrize("wtype", [2, 3, 6, 7, 8])
 def test_device_sampled_chain_equals_token_by_token_greedy(G, O, wtype):
     """SURVEY 8f N3 (ggml_hip_decode_greedy_chain): n tokens with the argmax on the device are bit-identical to n
