@@ -201,7 +201,14 @@ extern "C" int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
     SlotLock lk;
     const uint64_t t0 = now_ns();
     ensure_init();
-    finish_pending();
+    if (g.pending_wait && g.pending_light && stg.pending.empty() && !g.results_ev_armed) {
+        // a prompt chunk / batch that was only enqueued (feed_prompt's chunks but the last): nothing of it is host-visible, and
+        // what this call enqueues runs behind it on the same stream — no wait
+        g.pending_wait = false;
+        g.ferr_plan = nullptr;
+    } else {
+        finish_pending();
+    }
     ws_reset();
     g_qact.valid = false;
     g_xf16.valid = false;

@@ -74,6 +74,9 @@ struct OutputRequest {
     // extension (no reference counterpart): the caller samples from a device-side top-k (llm_session_topk) — the logits node stays
     // in HBM like every other node and last_logits is NOT refreshed: 40 pairs cross the bus instead of n_vocab floats
     bool logits_on_device = false;
+    // extension: a chunk of feed_prompt that is not its last one — nobody can observe its last-token logits (the next chunk
+    // overwrites last_logits before feed_prompt returns), so they are not fetched and the evaluation need not be waited for
+    bool intermediate_chunk = false;
 };
 
 struct GraphOutputs {  // inference_session.rs:31-37
@@ -172,7 +175,10 @@ class InferenceSession {
         {
             GraphExecutionPlan plan(built.gf, config.n_threads);
             lap(1);
-            const bool running = single && speculate ? plan.execute_begin(ctx0) : (plan.execute(ctx0), false);
+            // (pipeline_chunk: a chunk of feed_prompt behind which another one follows at once — begin without end: the next
+            //  evaluation's begin, or any other entry point of the backend, completes it; the stream keeps the order)
+            const bool pipe = !single && pipeline_chunk && speculate && !defer_end;
+            const bool running = (single && speculate) || pipe ? plan.execute_begin(ctx0) : (plan.execute(ctx0), false);
             lap(2);
             if (running && next_builder && n_past + 2 <= context_size) {
                 pre_.b = build_into(cur_ ^ 1, 1, next_builder(n_past + 1));
@@ -286,6 +292,7 @@ class InferenceSession {
    public:
     bool speculate = true;  // build the next single-token graph while the device runs (LLM_HOST_SPECULATE=0 disables)
     bool defer_end = false;  // set for the stages of an in-process split that produce no logits (Llama::start_session)
+    bool pipeline_chunk = false;  // set by feed_prompt around every chunk but its last (see compute)
 };
 
 // crates/llm-base/src/model/common.rs:6-59
@@ -515,6 +522,7 @@ class Llama {
             [this, sp](size_t next_len) { return make_builder(sp, 1, next_len); }, this, ctx_size);
         if (!is_last()) return;
         // finish evaluation (:364-367)
+        if (output_request.intermediate_chunk) return;  // (feed_prompt: only the last chunk's logits can be observed)
         if (!output_request.logits_on_device) common::read_last_token(session, outputs.result, n_vocab, input_len);
         common::extract_logits(output_request, outputs.result, n_vocab, input_len);
         common::extract_embeddings(output_request, outputs.embedding_result, n_embd, input_len);
@@ -1052,11 +1060,18 @@ void llm_feed_prompt(llm_model *m, llm_session *s, const int32_t *tokens, int n)
         abort();
     }
     const size_t nb = s->s->config.n_batch;
-    llm::OutputRequest req;
     for (size_t i = 0; i < (size_t)n; i += nb) {
         const size_t len = std::min(nb, (size_t)n - i);
         std::vector<llm::TokenId> batch(tokens + i, tokens + i + len);
+        // every chunk but the last is only enqueued (unsplit models): the host builds and matches the next chunk's graph while the
+        // device runs this one, instead of waiting for it and for a row of logits nobody can see
+        llm::OutputRequest req;
+        static const bool pipeline_on = !(getenv("LLM_HOST_PIPELINE_CHUNKS") && atoi(getenv("LLM_HOST_PIPELINE_CHUNKS")) == 0);
+        const bool more = pipeline_on && i + len < (size_t)n && m->stages.empty() && len > 1;
+        req.intermediate_chunk = more;
+        s->s->pipeline_chunk = more;
         model_evaluate(m, s, batch, req);
+        s->s->pipeline_chunk = false;
         for (auto tk : batch) s->s->tokens.push_back(tk);
     }
 }

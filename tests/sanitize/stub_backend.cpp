@@ -101,6 +101,7 @@ void ggml_hip_tensor_set(struct ggml_tensor *t, const void *src, size_t off, siz
 }
 void ggml_hip_copy_between_devices(int, void *dst, int, const void *src, size_t n) { memcpy(dst, src, n); }
 int ggml_hip_graph_compute_begin(struct ggml_cgraph *cgraph) {
+    if (g_pending) fake_compute(g_pending);  // (a chunk of feed_prompt that was only enqueued: completed by the next begin)
     g_pending = cgraph;
     return 1;
 }
