@@ -587,7 +587,7 @@ __device__ __forceinline__ void attn_consumer_split(const FusedAttnArgs &f, cons
         const unsigned long long *gp = f.gran + base + (lane < half_d ? lane : 0);
         unsigned long long x;
         for (int spin = 0;; spin++) {
-            x = gran_load(gp);
+            x = f.local_rows ? gran_load_l2(gp) : gran_load(gp);  // (all S workgroups of head h sit at blockIdx = h mod n_head: one XCD)
             const bool ok = (unsigned)(x >> 32) == epoch;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
             __builtin_amdgcn_s_sleep(GRAN_SLEEP);
