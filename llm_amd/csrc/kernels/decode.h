@@ -108,11 +108,10 @@ __global__ void __launch_bounds__(128) k_rope_table(const DecParams *__restrict_
 // workgroup for the single activation row.
 // ---------------------------------------------------------------------------------------------------
 template <bool F16_D>
-__global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict__ x, const float *__restrict__ w,
-                                                        float eps, int E, float *y_f32 /*nullable*/, int8_t *lo,
-                                                        int8_t *hi, float *dq, int *sumq,
-                                                        float *dT = nullptr /* [E/32][8] copy of the scales, row r in column r */,
-                                                        int *sT = nullptr /* ... of the sums (k_mmq_cols stages them by DMA) */) {
+__device__ __forceinline__ void rmsnorm_quant_body(const float *__restrict__ x, const float *__restrict__ w, float eps, int E,
+                                                   float *y_f32 /*nullable*/, int8_t *lo, int8_t *hi, float *dq, int *sumq,
+                                                   float *dT /* [E/32][8] copy of the scales, row r in column r */,
+                                                   int *sT /* ... of the sums (k_mmq_cols stages them by DMA) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_y = (float *)smem;                 // E floats
     __shared__ double s_part[16];
@@ -197,6 +196,59 @@ __global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict_
             }
         }
     }
+}
+template <bool F16_D>
+__global__ void __launch_bounds__(1024) k_rmsnorm_quant(const float *__restrict__ x, const float *__restrict__ w, float eps, int E,
+                                                        float *y_f32, int8_t *lo, int8_t *hi, float *dq, int *sumq,
+                                                        float *dT = nullptr, int *sT = nullptr) {
+    rmsnorm_quant_body<F16_D>(x, w, eps, E, y_f32, lo, hi, dq, sumq, dT, sT);
+}
+
+// The norm of a prompt chunk keeps N (<= 8) of the chip's CUs busy for ~6 us.  The other workgroups of the launch — one per remaining
+// CU — spend it pulling the leading 16-row groups of every workgroup of the NEXT launch (k_mmq_cols: wq|wk|wv or w1|w3, dealt in
+// contiguous runs of groups: workgroup c owns gq (+1 if c < gr) groups from c * gq + min(c, gr)) into the L2 of the XCD that
+// workgroup will run on: workgroup b of a one-workgroup-per-CU launch sits on XCD b mod 8 (llama_plan.inc xcd_labels_probe), and an
+// XCD's L2 keeps its lines across the kernel boundary.  One 4-byte LDS-DMA load per 128-byte line (nothing to wait for but the
+// wave's end), as warm_next does for decode (kernels/decode_fused.h).
+constexpr int CW_MAX = 12;  // arrays: qs, d (+ qs2 | qh | m) of up to three matrices
+struct ColsWarm {
+    const uint8_t *base[CW_MAX];
+    uint32_t row_bytes[CW_MAX];
+    int row0[CW_MAX], rows[CW_MAX];  // the array's matrix in the next launch's row space: first row, row count (w1 and w3 both start at 0)
+    int n;                           // arrays in use; 0 = off
+    int G, gq, gr;                   // the next launch's grid and dealing
+    int wg;                          // leading groups of every workgroup to warm
+};
+__device__ __forceinline__ void cols_warm(const ColsWarm &cw, const int first /* first warming workgroup of the launch */, unsigned *junk) {
+    typedef const __attribute__((address_space(1))) void *wg_ptr;
+    typedef __attribute__((address_space(3))) void *wl_ptr;
+    const int b = (int)blockIdx.x, x = b & 7, tid = (int)threadIdx.x;
+    const int b0 = first + ((x - first) & 7);                                // the first warming workgroup with this label
+    const int j = (b - b0) >> 3, nj = ((int)gridDim.x - b0 + 7) >> 3;        // this one among them
+    for (int c = x + 8 * j; c < cw.G; c += 8 * nj) {                         // the next launch's workgroups on this XCD, dealt round robin
+        const int g0 = c * cw.gq + (c < cw.gr ? c : cw.gr), nlg = cw.gq + (c < cw.gr ? 1 : 0);
+        const int R0 = 16 * g0, R1 = 16 * (g0 + (nlg < cw.wg ? nlg : cw.wg));
+        for (int a = 0; a < cw.n; a++) {
+            const int lo_r = (R0 > cw.row0[a] ? R0 : cw.row0[a]) - cw.row0[a];
+            const int hi_r = (R1 < cw.row0[a] + cw.rows[a] ? R1 : cw.row0[a] + cw.rows[a]) - cw.row0[a];
+            if (lo_r >= hi_r) continue;
+            const uint8_t *p = cw.base[a] + (size_t)lo_r * cw.row_bytes[a];
+            const uint32_t bytes = (uint32_t)(hi_r - lo_r) * cw.row_bytes[a];
+            for (uint32_t off = (uint32_t)tid << 7; off < bytes; off += 1024u << 7)
+                __builtin_amdgcn_global_load_lds((wg_ptr)(p + off), (wl_ptr)junk, 4, 0, 0);
+        }
+    }
+}
+template <bool F16_D>
+__global__ void __launch_bounds__(1024) k_rmsnorm_quant_warm(const float *__restrict__ x, const float *__restrict__ w, float eps, int E,
+                                                             float *y_f32, int8_t *lo, int8_t *hi, float *dq, int *sumq, float *dT,
+                                                             int *sT, const int nrows, const ColsWarm cw) {
+    if ((int)blockIdx.x >= nrows) {
+        __shared__ unsigned s_junk[64];
+        cols_warm(cw, nrows, s_junk);
+        return;
+    }
+    rmsnorm_quant_body<F16_D>(x, w, eps, E, y_f32, lo, hi, dq, sumq, dT, sT);
 }
 
 // re-quantize a plain f32 row (the FFN gate before w2): 32 lanes per block
