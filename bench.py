@@ -528,7 +528,19 @@ def run_single(args):
         # the same steps through the reference's OWN call sequence: InferenceSession::compute builds the graph and then calls
         # ggml_graph_compute synchronously (crates/llm-base/src/inference_session.rs:220-295) — no ggml_hip_graph_compute_begin / _end,
         # nothing built ahead: what a rustformers/llm binary gets by linking this library with no source change at all
+        # Every leg below starts again at the position the timed steps started at (InferenceSession::rewind): a leg that simply went
+        # on from where the one before it stopped would decode against a longer context than the headline (the device-sampling
+        # leg of round 5 ran at ~700 positions, on the 2-workgroups-per-head attention) and the legs could not be held against
+        # each other.
+        leg_start = args.prompt + args.warmup
+
+        def back_to_start():
+            k = int(sess.n_past) - leg_start
+            if k > 0:
+                sess.rewind(k)
+
         sess.set_speculate(False)
+        back_to_start()
         for _ in range(4):
             sess.infer_next_token()
         L.ggml_hip_synchronize()
@@ -544,6 +556,7 @@ def run_single(args):
         # token the device samples the greedy token and runs the next token's plan at once; the caller's unchanged sequence finds its
         # results on their way whenever it did take the first maximum (it does here: greedy decode)
         ggml.set_option("speculate_next", 1)
+        back_to_start()
         for _ in range(4):
             sess.infer_next_token()
         L.ggml_hip_synchronize()
@@ -555,6 +568,7 @@ def run_single(args):
         spec_s = time.perf_counter() - tr
         spec_hits = stat("spec_hits") - hits0
         sess.set_speculate(True)
+        back_to_start()
         for _ in range(4):
             sess.infer_next_token()
         L.ggml_hip_synchronize()
@@ -571,8 +585,10 @@ def run_single(args):
         # (llm_session_topk: 104 pairs instead of 128 KB).  Both draw the same tokens (tests/test_device_tools_gpu.py).
         import ctypes
         sampler_legs = {}
+        sess.set_speculate(False)  # the UNCHANGED sequence: nothing built ahead between begin and end
         for dev_topk in (0, 1):
             rng = ctypes.c_uint64(0x9E3779B97F4A7C15)
+            back_to_start()
             for _ in range(4):
                 sess.infer_next_token_topk(rng, 40, 0.8, bool(dev_topk))
             L.ggml_hip_synchronize()
@@ -584,6 +600,7 @@ def run_single(args):
             sampler_legs["device_topk_40" if dev_topk else "full_logits_read_back"] = {
                 "tokens_per_s": round(n_ref / dt, 2), "ms_per_token": round(dt / n_ref * 1e3, 4), "tokens": n_ref,
                 "bytes_read_back_per_token": (40 + 64) * 8 if dev_topk else 4 * hp["n_vocab"]}
+        sess.set_speculate(True)
         sess.infer_next_token_topk(ctypes.c_uint64(1), 40, 0.8, False)  # (refreshes the host copy of the last logits for the legs below)
         sess.infer_next_token()
         reference_sequence = {"tokens_per_s": round(n_ref / ref_s, 2), "ms_per_token": round(ref_s / n_ref * 1e3, 4), "tokens": n_ref,
@@ -602,6 +619,7 @@ def run_single(args):
                                       "has it (inference_session.rs:220-295), zero caller-side changes"}
         # the same greedy decode with the sampler on the device: ids identical to the loop above
         # (tests/test_llama_gpu.py), no logits read-back / host sync per token.  Reported beside the metric, not as it.
+        back_to_start()
         sess.infer_next_token()
         L.ggml_hip_synchronize()
         td = time.perf_counter()
@@ -613,6 +631,7 @@ def run_single(args):
         if hasattr(ggml, "set_option"):
             ggml.set_option("chain_k", 8)
             try:
+                back_to_start()
                 sess.infer_next_token()
                 sess.infer_tokens_device(8)  # captures the 8-token graph
                 L.ggml_hip_synchronize()
@@ -739,7 +758,10 @@ def run_single(args):
                       "call_sequence": {"value_uses": "InferenceSession::compute of the host mirror with the next token's graph built between "
                                                       "ggml_hip_graph_compute_begin and _end while the device runs (two extension entry points; "
                                                       "a caller-side change of ~10 lines, INTEGRATION.md section 2)",
-                                        "reference_call_sequence": reference_sequence},
+                                        "reference_call_sequence": reference_sequence,
+                                        "legs_start_at_n_past": args.prompt + args.warmup,
+                                        "legs_note": "every leg of call_sequence and device_sampling rewinds the session to the position the timed "
+                                                     "steps started at and decodes from there (4 untimed tokens first): same context as `value`"},
                       "weights_in_hbm_before_timing": True, "host_split_per_token": host_split,
                       "decode_launches": {"qkv_and_attention_in_one_launch_tokens": int(fused_tokens), "of_timed_tokens": int(args.steps),
                                           "per_layer": "K plan on big workgroups, 4 launches: k_qkv_attn_k (norm + Q8_K staged, wq|wk|wv, RoPE + K/V store, the attention "
