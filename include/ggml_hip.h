@@ -600,6 +600,10 @@ GGML_API size_t ggml_hip_read_timeline(int64_t *dst, size_t max_records);
  * mem_v [Egqa][C] f16, out [N][E] f32.  0 on success, -1 if the shape is not accepted. */
 GGML_API int ggml_hip_debug_prompt_attention(const float *q, const uint16_t *mem_k, const uint16_t *mem_v, float *out, int N, int E,
                                              int Egqa, int H, int n_past, int64_t C, float scale, int fused);
+/* Test hook: the fused prompt attention's exponential against expf over ALL f16 arguments: out_fast[i] = f16(exp_le0(x_i)),
+ * out_ref[i] = f16(expf(x_i)) for the 65536 f16 bit patterns i (65536 f16 bit patterns each).  The softmax only ever passes
+ * x <= 0 or NaN (crates/models/llama/src/lib.rs:272-280: soft_max over masked, scaled scores).  Returns 0. */
+GGML_API int ggml_hip_debug_exp_le0(uint16_t *out_fast, uint16_t *out_ref);
 /* Test hook: w (quantized 2-D weight with a device copy) times N = 2..8 host rows x [N][K] through k_mmq_cols as the
  * multi-token plan launches it; out [N][M].  0, or -1 when that plan would not run this shape on k_mmq_cols. */
 GGML_API int ggml_hip_debug_mul_mat_cols(const struct ggml_tensor *w, const float *x, float *out, int N);

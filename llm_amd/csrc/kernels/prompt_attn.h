@@ -35,10 +35,29 @@ struct PAttnArgs {
     _Float16 *x16;       // != nullptr: the output goes out as wo's GEMM operand instead — every 32-channel block re-quantized to Q8
                          // and written as f16(d * q) in the GEMM's k order (what k_p_quant4 makes of `out`); `out` is not written
     int f16d;            // ... with the block scale rounded to f16 first (weight types whose vec_dot_type is Q8_0)
+    int r1;              // query-tile ranks (blockIdx / H) dealt longest-first; the ranks behind them go shortest-first (see the kernel)
     long long *ts;       // INSTR build (option "timeline"): 8 x int64 per workgroup, see tests/tools/pattn_timeline.py
 };
 
 #define PATTN_Q 32
+
+// expf for the softmax's arguments: x = f16(score - row maximum), so x <= 0 (or NaN for a masked column's garbage, which is selected
+// away).  The operations of the device library's expf (ph = x * log2e rounded; pl = its error by two fmas with log2e's head and tail;
+// e = rint(ph); 2^((ph - e) + pl) by v_exp_f32; ldexp by e) with ONE clamp in place of its two range checks (x < -103.28 -> 0,
+// x > 88.72 -> inf: two compares, two selects and their wait states per element): the second cannot fire; below -104 (f16's -inf
+// included: inf - inf inside the sequence would make a NaN of it) the argument is held at -104, whose result (7e-46) rounds to the
+// same f16 zero the library's branch returns.  A NaN stays a NaN.  Same f16 bits as f16(expf(x)) for every f16 x <= 0 and every
+// NaN: tests/test_prompt_plan_gpu.py checks all 2^15 + 1 of them on the device (ggml_hip_debug_exp_le0).
+__device__ __forceinline__ float exp_le0(const float x0) {
+    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;  // log2(e): head and tail
+    const float x = x0 < -104.0f ? -104.0f : x0;
+    const float ph = x * c;
+    float pl = __builtin_fmaf(x, c, -ph);
+    pl = __builtin_fmaf(x, cc, pl);
+    const float e = __builtin_rintf(ph);
+    const float a_ = (ph - e) + pl;
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a_), (int)e);
+}
 
 // QR = queries per workgroup: 32, or 16 for rows too long for 32 score rows in LDS (T up to ~2300 keys: the last chunks of a
 // 2048-token context; the MFMA tiles stay 32 rows high, their upper half computes on duplicated queries and is dropped)
@@ -53,7 +72,12 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const int ntile = (a.N + QR - 1) / QR;
-    const int h = (int)blockIdx.x % a.H, qt = ntile - 1 - (int)blockIdx.x / a.H;  // the longest rows first
+    // Which query tile: the longest rows first — but only for the workgroups that fill the CUs' FIRST slots (ranks < a.r1).  Two
+    // workgroups share a CU (66 KB of scores each at 512 keys) and the second slots fill in the same CU order, so the ranks behind
+    // them go SHORTEST first: the CU that got tile 15 gets tile 0, the one with tile 14 tile 1, ... — every CU holds the same number
+    // of keys (544 at 512 tokens instead of 768 on the first CUs and 320 on the last ones; the softmax is VALU-bound per CU).
+    const int h = (int)blockIdx.x % a.H, rank = (int)blockIdx.x / a.H;
+    const int qt = rank < a.r1 ? ntile - 1 - rank : rank - a.r1;
     const int hk = h / a.r;
     const int q0 = qt * QR;
     const int Ttot = a.n_past + a.N;                        // keys written so far
@@ -181,18 +205,37 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         double sum[RW];
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) sum[rr] = 0.0;
-        for (int i = lane; i <= lim_hi; i += 64) {
-            float x[RW], e[RW];
+        if (nrow == RW) {
+            // All rows exist (every tile but a ragged last one): no branch in the body.  A masked column's value (garbage, possibly
+            // NaN: a score against a key behind the row's last) is SELECTED away from the sum and may be stored — the third pass
+            // replaces masked columns by zero without reading them.  With a branch per row the compiler ran the eight dependent
+            // chains one after the other (softmax 12.9 of tile 15's 24.5 us: r06_pattn_timeline.txt).
+            for (int i = lane; i <= lim_hi; i += 64) {
+                float x[RW], e[RW];
 #pragma unroll
-            for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[i];
+                for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[i];
 #pragma unroll
-            for (int rr = 0; rr < RW; rr++) e[rr] = round_f16(expf(round_f16(x[rr] * a.scale - mx[rr])));
+                for (int rr = 0; rr < RW; rr++) e[rr] = round_f16(exp_le0(round_f16(x[rr] * a.scale - mx[rr])));
 #pragma unroll
-            for (int rr = 0; rr < RW; rr++)
-                if (rr < nrow && i <= lim0 + rr) {
-                    sum[rr] += (double)e[rr];
-                    ((float *)(lds + (row0 + rr) * rb))[i] = e[rr];
+                for (int rr = 0; rr < RW; rr++) {
+                    sum[rr] += (double)(i <= lim0 + rr ? e[rr] : 0.0f);
+                    ((float *)rp[rr])[i] = e[rr];
                 }
+            }
+        } else {
+            for (int i = lane; i <= lim_hi; i += 64) {
+                float x[RW], e[RW];
+#pragma unroll
+                for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[i];
+#pragma unroll
+                for (int rr = 0; rr < RW; rr++) e[rr] = round_f16(exp_le0(round_f16(x[rr] * a.scale - mx[rr])));
+#pragma unroll
+                for (int rr = 0; rr < RW; rr++)
+                    if (rr < nrow && i <= lim0 + rr) {
+                        sum[rr] += (double)e[rr];
+                        ((float *)(lds + (row0 + rr) * rb))[i] = e[rr];
+                    }
+            }
         }
         float inv[RW];
 #pragma unroll

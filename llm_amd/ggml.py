@@ -237,6 +237,7 @@ PROTOTYPES.update({
     "ggml_hip_debug_prompt_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   C.c_int, C.c_int64, C.c_float, C.c_int]),
     "ggml_hip_debug_mul_mat_cols": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ggml_hip_debug_exp_le0": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ggml_hip_decode_greedy_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ggml_hip_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ggml_hip_quantize": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

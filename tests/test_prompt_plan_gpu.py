@@ -222,6 +222,28 @@ def test_prompt_plan_with_a_k_split_on_wk_wv_only(G):
     model.free()
 
 
+def test_exp_le0_is_expf_for_every_f16_argument_the_softmax_can_pass(G):
+    """kernels/prompt_attn.h exp_le0 (expf's own operation sequence with one clamp in place of its two range checks) against the
+    device library's expf, both rounded to f16 as ggml's soft_max stores them, for ALL 65536 f16 bit patterns: identical for every
+    x <= 0 (both zeros, -inf included) and NaN for every NaN — the only arguments f16(score - row maximum) can be.  Against
+    numpy's exp in f64 the f16 results sit within one f16 ulp (correctly rounded or its neighbour)."""
+    fast = np.zeros(65536, np.uint16)
+    ref = np.zeros(65536, np.uint16)
+    assert G.lib().ggml_hip_debug_exp_le0(fast.ctypes.data, ref.ctypes.data) == 0
+    x = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    le0 = (x <= 0)  # -0, +0, negative normals / subnormals, -inf
+    assert le0.sum() == 2 ** 15 - 1024 + 1 + 1  # every pattern with the sign bit set that is not a NaN, and +0
+    assert np.array_equal(fast[le0], ref[le0]), np.flatnonzero(le0 & (fast != ref))[:8]
+    nan = np.isnan(x)
+    assert np.isnan(fast[nan].view(np.float16)).all() and np.isnan(ref[nan].view(np.float16)).all()
+    assert fast[x == 0].view(np.float16).tolist() == [1.0, 1.0] and float(fast.view(np.float16)[0xFC00]) == 0.0  # exp(+-0) = 1, exp(-inf) = 0
+    fin = le0 & np.isfinite(x)
+    want = np.exp(x[fin].astype(np.float64))
+    got = fast.view(np.float16)[fin].astype(np.float64)
+    ulp = np.maximum(np.spacing(want.astype(np.float16)).astype(np.float64), 2.0 ** -24)
+    assert np.all(np.abs(got - want) <= ulp)
+
+
 def test_fused_prompt_attention_kernel_matches_the_three_launch_path(G):
     """kernels/prompt_attn.h (K.Q, scale + mask + softmax and V.P in one launch, scores in LDS) against k_gemm_f16 ->
     k_p_soft_max -> k_gemm_f16_b16 on random Q / K / V through ggml_hip_debug_prompt_attention: head sizes 32 / 64 / 128,
