@@ -246,7 +246,8 @@ __device__ __forceinline__ void wo_tail(const WoTailArgs &t, const FusedAttnArgs
 #pragma unroll
     for (int k = 0; k < WO_NG_MAX; k++) {
         const int idx = tid + 1024 * k;
-        if (1024 * k >= ngran) break;  // uniform
+        if (1024 * k + 64 * wave >= ngran) break;  // wave-uniform: a wave with no granule of this batch polls nothing (clamped to granule 0,
+                                                   // twelve waves of every workgroup used to hammer the line head 0 publishes into)
         const unsigned long long *gp = f.ogran + (idx < ngran ? idx : 0);
         unsigned long long x;
         for (int spin = 0;; spin++) {
