@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ 
     const f32x4 *xr = (const f32x4 *)(x + row * E);
     const f32x4 *x2r = x2 ? (const f32x4 *)(x2 + row * E) : nullptr;  // second partial of a K-split GEMM: x = x + x2 (what the atomics computed)
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 v[MAXU];
+    f32x4 v[MAXU], wv[MAXU];
 #pragma unroll
     for (int u = 0; u < MAXU; u++) {
         const int j = u * 256 + tid;
@@ -83,6 +83,13 @@ __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ 
             if (j < E4) xs[j] = v[u];  // the residual stream of the layer
         }
     }
+    // the norm weights depend on nothing: requested here (behind the row's own loads in the wave's queue), they land during the
+    // two barriers and the sum instead of costing a second round trip behind them
+#pragma unroll
+    for (int u = 0; u < MAXU; u++) {
+        const int j = u * 256 + tid;
+        wv[u] = j < E4 ? ((const f32x4 *)w)[j] : zero4;
+    }
 #pragma unroll
     for (int u = 0; u < MAXU; u++) {
         const int j = u * 256 + tid;
@@ -104,7 +111,7 @@ __global__ void __launch_bounds__(256) k_p_norm_quant(const float *__restrict__ 
     for (int u = 0; u < MAXU; u++) {
         if (u * 256 >= E4) break;  // uniform: whole 8-lane groups take part in the reduction
         const int j = u * 256 + tid;
-        const f32x4 ww = j < E4 ? ((const f32x4 *)w)[j] : zero4;
+        const f32x4 ww = wv[u];
         f32x4 y;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -267,24 +274,52 @@ __global__ void __launch_bounds__(256) k_p_qkv_post(const PQkvPost a) {
         }
         return;
     }
+    // V: 64 tokens x 64 channels per workgroup through LDS.  In: four 16-byte loads per thread (four channels of one token; Egqa is a
+    // multiple of 4, so a vector lies inside the row or outside it).  Out: a lane holds two neighbouring tokens of one channel and
+    // stores them as one 4-byte pair when the cache position of the tile's first token is even (an odd n_past: one f16 at a time).
     const int t = b - a.nb_rope, tn = t % a.vt_n, tm = t / a.vt_n;
     const int n0 = tn * 64, m0 = tm * 64;
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    {
+        const int c4 = threadIdx.x & 15, r = threadIdx.x >> 4;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int n = n0 + ly + 4 * i, m = m0 + lx;
-        float v = 0.0f;
-        if (n < a.N && m < a.Egqa) {
-            v = a.vf[(int64_t)n * a.Egqa + m];
-            if (a.part) v = v + a.vf[a.part + (int64_t)n * a.Egqa + m];
+        for (int i = 0; i < 4; i++) {
+            const int n = n0 + r + 16 * i, m = m0 + 4 * c4;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (n < a.N && m < a.Egqa) {
+                v = *(const f32x4 *)(a.vf + (int64_t)n * a.Egqa + m);
+                if (a.part) v = v + *(const f32x4 *)(a.vf + a.part + (int64_t)n * a.Egqa + m);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_t[r + 16 * i][4 * c4 + k] = v[k];
         }
-        s_t[ly + 4 * i][lx] = v;
     }
     __syncthreads();
+    if ((((int64_t)a.n_past + n0) & 1) == 0 && (a.C & 1) == 0) {  // uniform (every channel's row of the cache starts 4-byte aligned)
+        const int np = threadIdx.x & 31, mg = threadIdx.x >> 5;
+        const int n = n0 + 2 * np;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int m = m0 + ly + 4 * i, n = n0 + lx;
-        if (n < a.N && m < a.Egqa) a.mem_v[(int64_t)m * a.C + a.n_past + n] = __float2half_rn(s_t[lx][ly + 4 * i]);
+        for (int i = 0; i < 8; i++) {
+            const int ml = mg + 8 * i, m = m0 + ml;
+            if (m < a.Egqa && n < a.N) {
+                __half *dst = a.mem_v + (int64_t)m * a.C + a.n_past + n;
+                const __half h0 = __float2half_rn(s_t[2 * np][ml]);
+                if (n + 1 < a.N) {
+                    __half2 h2;
+                    h2.x = h0;
+                    h2.y = __float2half_rn(s_t[2 * np + 1][ml]);
+                    *(__half2 *)dst = h2;
+                } else {
+                    *dst = h0;
+                }
+            }
+        }
+    } else {
+        const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = m0 + ly + 4 * i, n = n0 + lx;
+            if (n < a.N && m < a.Egqa) a.mem_v[(int64_t)m * a.C + a.n_past + n] = __float2half_rn(s_t[lx][ly + 4 * i]);
+        }
     }
 }
 
