@@ -245,17 +245,33 @@ __global__ void __launch_bounds__(256, 2) k_p_attn(const PAttnArgs a) {
         }
         // each row overwritten in place with its f16 probabilities: f16 element i lands on f32 element i / 2, which this wave
         // read in an earlier (or this) iteration — LDS operations of a wave execute in order
-        for (int i0 = 0; i0 < npad; i0 += 64) {
-            const int i = i0 + lane;
-            float x[RW];
+        if (nrow == RW) {  // all rows exist: one lane predicate around the eight stores instead of a branch per row
+            for (int i0 = 0; i0 < npad; i0 += 64) {
+                const int i = i0 + lane;
+                float x[RW];
 #pragma unroll
-            for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[min(i, npad - 1)];
+                for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[min(i, npad - 1)];
+                _Float16 pr[RW];
 #pragma unroll
-            for (int rr = 0; rr < RW; rr++)
-                if (rr < nrow && i < npad) {
-                    const float e = i <= lim0 + rr ? x[rr] : 0.0f;
-                    ((_Float16 *)(lds + (row0 + rr) * rb))[i] = (_Float16)(e * inv[rr]);
+                for (int rr = 0; rr < RW; rr++) pr[rr] = (_Float16)((i <= lim0 + rr ? x[rr] : 0.0f) * inv[rr]);
+                if (i < npad) {
+#pragma unroll
+                    for (int rr = 0; rr < RW; rr++) ((_Float16 *)rp[rr])[i] = pr[rr];
                 }
+            }
+        } else {
+            for (int i0 = 0; i0 < npad; i0 += 64) {
+                const int i = i0 + lane;
+                float x[RW];
+#pragma unroll
+                for (int rr = 0; rr < RW; rr++) x[rr] = ((const float *)rp[rr])[min(i, npad - 1)];
+#pragma unroll
+                for (int rr = 0; rr < RW; rr++)
+                    if (rr < nrow && i < npad) {
+                        const float e = i <= lim0 + rr ? x[rr] : 0.0f;
+                        ((_Float16 *)(lds + (row0 + rr) * rb))[i] = (_Float16)(e * inv[rr]);
+                    }
+            }
         }
     }
     __syncthreads();
