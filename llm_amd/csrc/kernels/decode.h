@@ -658,6 +658,35 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     __syncthreads();
     const long long t_scores = ts ? (long long)wall_clock64() : 0;
     // ---- softmax over T entries (ggml: max, f16-rounded exp of f16-rounded (x-max), f64 sum, scale by 1/sum) ----
+    // Up to 256 positions one wave does it alone (4 per lane, DPP reductions): no exchange through LDS, no barrier between the
+    // passes — attn_consumer's form (kernels/decode_fused.h).  The maximum and the f64 sum of f16-valued terms are exact, so
+    // their order is immaterial: the same bits as the 16-wave form below.
+    if (T <= 256) {
+        if (wave == 0) {
+            float sv[4], e[4];
+            float mx1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = lane + 64 * i;
+                sv[i] = t < T ? s_s[t] : -INFINITY;
+                mx1 = fmaxf(mx1, sv[i]);
+            }
+            mx1 = wave_max_f32(mx1);
+            double sum1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                e[i] = lane + 64 * i < T ? round_f16(expf(round_f16(sv[i] - mx1))) : 0.0f;
+                sum1 += (double)e[i];
+            }
+            sum1 = wave_sum_f64(sum1);
+            const float inv1 = (float)(1.0 / sum1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = lane + 64 * i;
+                if (t < T8) s_p[t] = t < T ? (_Float16)(e[i] * inv1) : (_Float16)0.0f;
+            }
+        }
+    } else {
     float mx = -INFINITY;
     for (int t = tid; t < T; t += 1024) mx = fmaxf(mx, s_s[t]);
     mx = wave_max_f32(mx);
@@ -681,6 +710,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float *__restrict__ 
     const float inv = (float)(1.0 / tot);
     for (int t = tid; t < T8; t += 1024)
         s_p[t] = t < T ? (_Float16)(s_s[t] * inv) : (_Float16)0.0f;  // probabilities as f16 (src1 of V·P); padding = 0
+    }
     __syncthreads();
     const long long t_softmax = ts ? (long long)wall_clock64() : 0;
     // ---- V·P ----
