@@ -126,6 +126,37 @@ def test_fused_launch_is_the_default_at_7b_width_and_matches_the_pair(G, O):
     assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
 
 
+def test_chunk_plan_norm_launches_that_warm_the_next_launch_leave_every_bit_alone(G):
+    """k_rmsnorm_quant_warm (kernels/decode.h ColsWarm): in a 2..8-token chunk the norm launches carry one more workgroup for every
+    other CU, which pulls the leading row groups of the next k_mmq_cols launch into the L2 that will read them — loads into a junk
+    LDS word, nothing else.  At the width it is built for (one k_mmq_cols workgroup per CU: 7B-wide rows) the logits of every chunk
+    and the K/V cache with warm_mb = 0 and with the default must be the same bits, and the counter must show that the warming
+    launches ran exactly when asked for."""
+    from llm_amd import llama, synth
+    hp0 = dict(synth.LLAMA_7B)
+    hp0["n_layer"], hp0["n_vocab"] = 2, 4096
+    hp, w = synth.make_llama_gaussian(hp0, 2)
+    model = llama.Llama(hp, w, context_size=256)
+    toks = np.random.default_rng(9).integers(0, hp["n_vocab"], 45).astype(np.int32)
+    chunks = [toks[0:8], toks[8:16], toks[16:21], toks[21:23], toks[23:31], toks[31:39], toks[39:45]]
+    res = {}
+    try:
+        for warm in (0, 24):
+            G.set_option("warm_mb", warm)
+            sess = model.start_session(n_batch=8)
+            c0 = _stat(G, "cols_warm_launches")
+            outs = [sess.evaluate(c) for c in chunks]
+            res[warm] = (outs, sess.get_kv(), _stat(G, "cols_warm_launches") - c0)
+            sess.free()
+    finally:
+        G.set_option("warm_mb", 24)
+        model.free()
+    assert res[0][2] == 0 and res[24][2] > 0, (res[0][2], res[24][2])
+    for a, b in zip(res[0][0], res[24][0]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.array_equal(res[0][1][0], res[24][1][0]) and np.array_equal(res[0][1][1], res[24][1][1])
+
+
 def test_wo_tail_warm_up_and_affine_dealing_leave_every_bit_alone(G):
     """The WO form (option fuse_wo: wo + residual as the mat-vec workgroups' second phase, kernels/decode_fused.h wo_tail), the L2
     warm-up of the next launch's w1|w3 rows from its idle window (option warm_mb, NextWarm) and the XCD-affine dealing of
