@@ -607,6 +607,11 @@ GGML_API int ggml_hip_debug_exp_le0(uint16_t *out_fast, uint16_t *out_ref);
 /* Test hook: w (quantized 2-D weight with a device copy) times N = 2..8 host rows x [N][K] through k_mmq_cols as the
  * multi-token plan launches it; out [N][M].  0, or -1 when that plan would not run this shape on k_mmq_cols. */
 GGML_API int ggml_hip_debug_mul_mat_cols(const struct ggml_tensor *w, const float *x, float *out, int N);
+/* Extension (layer split inside one process): slot `slot` enqueues on slot `with_slot`'s stream (with_slot < 0: on its own again).
+ * Only for slots of ONE physical GPU whose work never overlaps — the stages of one split session: a wait on another queue's event
+ * costs tens of microseconds per stage boundary on this runtime, the same wait inside one queue nothing.  1 = now shared, 0 = not
+ * (different GPUs, a slot not initialised).  The host mirror calls it from llm_start_session / llm_session_free. */
+GGML_API int ggml_hip_share_stream(int slot, int with_slot);
 GGML_API const char *ggml_hip_version(void);
 
 #ifdef __cplusplus

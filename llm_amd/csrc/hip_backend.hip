@@ -634,6 +634,41 @@ void ggml_hip_copy_between_devices(int dst_device, void *dst, int src_device, co
     g_cur = keep;
     if (g.inited) bind_device();
 }
+// Slot `slot` enqueues on slot `with_slot`'s stream from now on (with_slot < 0: on its own again).  For the stages of ONE layer-split
+// session that sit on one physical GPU (virtual slots; two stages of a split that has more stages than GPUs): they run strictly one
+// after the other, so a second hardware queue buys nothing — and a wait on an event of ANOTHER queue resolves tens of microseconds
+// late on this runtime (the hop of bench.py --mode split: 50-70 us per stage boundary, r06_sweeps.txt 6 / 20), where the same wait
+// inside one queue is free.  Returns 1 if the slot now shares (same physical device, both initialised), 0 if nothing changed.
+int ggml_hip_share_stream(int slot, int with_slot) {
+    if (slot < 0 || slot >= GGML_HIP_MAX_BACKENDS || with_slot >= GGML_HIP_MAX_BACKENDS) die("ggml_hip_share_stream: bad slot");
+    Backend &B = g_backends[slot];
+    if (with_slot < 0 || with_slot == slot) {
+        SlotLock lk(&B);
+        if (!B.own_stream) return 0;
+        Backend *keep = g_cur;
+        g_cur = &B;
+        bind_device();
+        HIP_CHECK(hipStreamSynchronize(B.stream));
+        B.stream = B.own_stream;
+        B.own_stream = nullptr;
+        g_cur = keep;
+        if (g.inited) bind_device();
+        return 0;
+    }
+    Backend &A = g_backends[with_slot];
+    SlotLock lk_a(&g_backends[std::min(slot, with_slot)]);
+    SlotLock lk_b(&g_backends[std::max(slot, with_slot)]);
+    if (!A.inited || !B.inited || A.device != B.device || B.own_stream || A.own_stream) return 0;
+    Backend *keep = g_cur;
+    g_cur = &B;
+    bind_device();
+    HIP_CHECK(hipStreamSynchronize(B.stream));
+    B.own_stream = B.stream;
+    B.stream = A.stream;
+    g_cur = keep;
+    if (g.inited) bind_device();
+    return 1;
+}
 void ggml_hip_synchronize(void) {
     SlotLock lk;
     if (g.inited) HIP_CHECK(hipStreamSynchronize(g.stream));

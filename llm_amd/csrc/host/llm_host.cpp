@@ -556,6 +556,7 @@ struct llm_model {
 struct llm_session {
     llm::InferenceSession *s;
     std::vector<llm::InferenceSession *> stage_sessions;  // parallel to llm_model::stages
+    bool shares_streams = false;  // its stages of one GPU enqueue on one stream (ggml_hip_share_stream), undone when the session goes
     std::vector<int> devices;
     int device = 0;  // unsplit: the model's slot (K/V, shadows and plans of the session live there)
 };
@@ -962,7 +963,15 @@ llm_session *llm_start_session(llm_model *m, const llm_session_config *cfg) {
         ggml_hip_bind_thread_device(home);
         // the stages of ONE split session run one after the other: on a GPU that hosts several of them (virtual slots) they are one
         // sharer of its compute units, not G (include/ggml_hip.h "serial_stage_slots"); with a second split session alive they are not
-        ggml_hip_set_option("serial_stage_slots", g_split_sessions.fetch_add(1) == 0 ? (int)m->stages.size() : 0);
+        const bool only_split_session = g_split_sessions.fetch_add(1) == 0;
+        ggml_hip_set_option("serial_stage_slots", only_split_session ? (int)m->stages.size() : 0);
+        // ... and stages that share a physical GPU share its queue too: the residual then crosses a stage boundary inside one stream
+        // instead of through an event of another queue (ggml_hip_share_stream; it declines slots of different GPUs)
+        if (only_split_session)
+            for (size_t i = 1; i < m->devices.size(); i++)
+                for (size_t j = 0; j < i; j++)
+                    if (ggml_hip_share_stream(m->devices[i], m->devices[j])) break;
+        s->shares_streams = only_split_session;
         s->s = s->stage_sessions.back();
         s->devices = m->devices;
         return s;
@@ -1033,6 +1042,8 @@ void llm_session_free(llm_session *s) {
         }
         ggml_hip_bind_thread_device(home);
         s->s = nullptr;
+        if (s->shares_streams)
+            for (size_t i = 1; i < s->devices.size(); i++) ggml_hip_share_stream(s->devices[i], -1);
         g_split_sessions.fetch_sub(1);
         ggml_hip_set_option("serial_stage_slots", 0);
     }

@@ -234,6 +234,7 @@ PROTOTYPES.update({
     "ggml_hip_set_layer_split": (None, [C.c_void_p, C.c_int]),
     "ggml_hip_get_layer_split": (C.c_int, [C.c_void_p, C.c_int]),
     "ggml_hip_copy_between_devices": (None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "ggml_hip_share_stream": (C.c_int, [C.c_int, C.c_int]),
     "ggml_hip_debug_prompt_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   C.c_int, C.c_int64, C.c_float, C.c_int]),
     "ggml_hip_debug_mul_mat_cols": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -66,6 +66,7 @@ int ggml_hip_device_count(void) { return 1; }
 int ggml_hip_slot_physical_device(int slot) { return slot >= 0 && slot < 4 ? 0 : -1; }
 int ggml_hip_thread_session_slot(void) { return -1; }
 void ggml_hip_set_option(const char *, int) {}
+int ggml_hip_share_stream(int, int) { return 0; }
 void ggml_hip_set_main_device(int d) { g_main_device = d; }
 int ggml_hip_get_main_device(void) { return g_main_device; }
 void ggml_hip_bind_thread_device(int) {}
