@@ -607,11 +607,13 @@ void ggml_hip_copy_between_devices(int dst_device, void *dst, int src_device, co
     g_cur = &S;
     bind_device();
     // one event per source slot, re-recorded per hop (a later record does not disturb a wait already enqueued on it)
-    if (!S.xfer_ev) HIP_CHECK(hipEventCreateWithFlags(&S.xfer_ev, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(S.xfer_ev, S.stream));
+    if (S.stream != D.stream) {  // (two slots that share a stream — ggml_hip_share_stream — are ordered by it)
+        if (!S.xfer_ev) HIP_CHECK(hipEventCreateWithFlags(&S.xfer_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(S.xfer_ev, S.stream));
+    }
     g_cur = &D;
     bind_device();
-    HIP_CHECK(hipStreamWaitEvent(D.stream, S.xfer_ev, 0));
+    if (S.stream != D.stream) HIP_CHECK(hipStreamWaitEvent(D.stream, S.xfer_ev, 0));
     if (S.device == D.device)
         HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, D.stream));
     else {

@@ -13,11 +13,11 @@ timeout 200 python tests/tools/wo_timeline.py 128 2>&1 | grep -v "^ROCm\|^Hostna
 timeout 200 python tests/tools/timeline.py 7b 256 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl" | head -40 > gpurun_out/r6f/r06_timeline_256.txt
 timeout 300 python bench.py --mode sessions --sessions 1,2,3 --weights blocks --steps 128 > gpurun_out/r6f/r06_sessions.json 2> gpurun_out/r6f/r06_sessions.err
 timeout 300 python bench.py --mode sessions --sessions 1,2,3 --sessions-unchanged-caller --weights blocks --steps 128 > gpurun_out/r6f/r06_sessions_unchanged_caller.json 2> gpurun_out/r6f/r06_sessions_unchanged_caller.err
-for G in 2 4; do timeout 300 python bench.py --mode split --split $G --weights blocks --steps 128 > gpurun_out/r6f/r06_split$G.json 2> gpurun_out/r6f/r06_split$G.err; done
+for G in 2 4 8; do timeout 300 python bench.py --mode split --split $G --weights blocks --steps 128 > gpurun_out/r6f/r06_split$G.json 2> gpurun_out/r6f/r06_split$G.err; done
 timeout 300 python bench.py --mode feed --weights blocks > gpurun_out/r6f/r06_feed8.json 2> gpurun_out/r6f/r06_feed8.err
 python - <<'PY'
 import json
-for f in ('r06_sessions','r06_sessions_unchanged_caller','r06_split2','r06_split4','r06_feed8'):
+for f in ('r06_sessions','r06_sessions_unchanged_caller','r06_split2','r06_split4','r06_split8','r06_feed8'):
     try:
         d=json.loads(open(f'gpurun_out/r6f/{f}.json').read().strip().splitlines()[-1])
         print(f, d['value'], [(r['sessions'], r['aggregate_tokens_per_s']) for r in d.get('runs',[])], d.get('overhead_per_hop_us'))
